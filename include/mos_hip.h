@@ -1,0 +1,199 @@
+/*
+ * mos_hip.h — C-ABI of libmos_hip.so: the MI355X (gfx950) kernels behind the
+ * Mix-of-Show hot path (ED-LoRA attention, regional attention, gradient fusion).
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative mos_status on error; never throw, never exit.
+ *     mos_last_error_string() returns a thread-local description of the last error.
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`.
+ *   - the caller allocates every output and workspace and owns all memory.
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*;
+ *     NULL = the legacy default stream). No entry point synchronises.
+ *   - `dtype` selects the storage/MFMA input type of activations and packed weights:
+ *     MOS_F16 or MOS_BF16. Accumulation is always fp32; statistics (lse, pcols, grads of
+ *     LoRA factors, Gram matrices) are fp32 or fp64 as documented.
+ *   - row strides (`ld*`) are in ELEMENTS and must be multiples of 8 (16-byte rows);
+ *     base pointers must be 16-byte aligned.
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to TencentARC/Mix-of-Show).
+ */
+#ifndef MOS_HIP_H
+#define MOS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MOS_F16 = 0, MOS_BF16 = 1 } mos_dtype;
+
+typedef enum {
+    MOS_OK = 0,
+    MOS_ERR_BAD_ARG = -1,      /* NULL pointer, bad size, misaligned stride */
+    MOS_ERR_UNSUPPORTED = -2,  /* head dim / dtype / rank not compiled */
+    MOS_ERR_LAUNCH = -3        /* hipGetLastError() after launch != hipSuccess */
+} mos_status;
+
+#define MOS_LORA_PAD 16   /* packed LoRA rank dimension (sum of ranks of fused sites <= 16) */
+#define MOS_MAX_PCOLS 4   /* max probability columns exported by the training cross-attn */
+#define MOS_MAX_SOURCES 9 /* context + up to 8 regions in one regional-attention launch */
+
+int mos_version(void);
+const char* mos_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * LoRA-augmented linear: replaces LoRALinearLayer.forward (mixofshow/models/edlora.py:244-246)
+ *     y = orig(x) + alpha * lora_up(lora_down(x))
+ * for one site or for several sites that share x (fused q/k/v: edlora.py:69-71,143-145).
+ *
+ * Packed operands (built by mos_lora_pack from the fp32 master parameters):
+ *   A16  [16, K]   rows g*r..g*r+r-1 = lora_down.weight of site g, other rows 0
+ *   A16T [K, 16]   its transpose
+ *   Bp16 [N, 16]   row n of site g: cols g*r.. = alpha_g * lora_up.weight[n - n0_g, :], else 0
+ *   BpT  [16, N]   its transpose
+ * ------------------------------------------------------------------------------------------ */
+
+/* Up to 4 fused sites; site g covers output rows [n_begin[g], n_begin[g]+n_rows[g]). */
+typedef struct {
+    int n_sites;
+    int rank;                 /* r, same for all sites; n_sites*rank <= 16 */
+    int K;                    /* in_features */
+    int N;                    /* total out_features (sum over sites) */
+    const float* down[4];     /* [r, K]    fp32 master lora_down.weight */
+    const float* up[4];       /* [n_rows, r] fp32 master lora_up.weight */
+    float alpha[4];
+    int n_begin[4];
+    int n_rows[4];
+} mos_lora_sites;
+
+int mos_lora_pack(const mos_lora_sites* sites_host, int dtype,
+                  void* A16, void* A16T, void* Bp16, void* BpT, void* stream);
+
+/* t[M,16] = x[M,K] . A16^T   (lora_down of all fused sites, one pass over x) */
+int mos_lora_down(const void* x, int64_t ldx, const void* A16, void* t,
+                  int M, int K, int dtype, void* stream);
+
+/* y[M,N] = x[M,K] . W[N,K]^T (+ t[M,16] . Bp16[N,16]^T) (+ bias[N])
+ * W is the frozen base weight in `dtype`; t/Bp16 may be NULL (plain linear).
+ * bias is fp32 or NULL. */
+int mos_lora_linear_fwd(const void* x, int64_t ldx, const void* W, int64_t ldw,
+                        const void* t, const void* Bp16, const float* bias,
+                        void* y, int64_t ldy, int M, int N, int K, int dtype, void* stream);
+
+/* Backward of the above w.r.t. x and the packed LoRA factors (W is frozen: no dW).
+ *   dt[M,16]  = dy . BpT^T                      (written to dt)
+ *   dx[M,K]   = dy[M,N] . Wt[K,N]^T + dt . A16T[K,16]^T   (Wt = W^T, cached by the caller)
+ *   dA16[16,K] (fp32) = dt^T . x
+ *   dBpT[16,N] (fp32) = t^T . dy               (caller scales by alpha and slices per site)
+ * ws: fp32 workspace of mos_lora_bwd_workspace_bytes(M,N,K) bytes.
+ * dx may be NULL (skip), dA16/dBpT may be NULL (no LoRA / frozen LoRA). */
+int64_t mos_lora_bwd_workspace_bytes(int M, int N, int K);
+int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                        const void* Wt, int64_t ldwt, const void* t,
+                        const void* A16T, const void* BpT,
+                        void* dt, void* dx, int64_t lddx, float* dA16, float* dBpT,
+                        void* ws, int M, int N, int K, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention core: softmax(scale * Q K^T) V with online softmax, no materialised P.
+ * Replaces attn.get_attention_scores + torch.bmm / xformers.memory_efficient_attention in
+ * EDLoRA_AttnProcessor / EDLoRA_Control_AttnProcessor (edlora.py:77-83,151-156), the default
+ * self-attention of diffusers Attention, and RegionT2I_AttnProcessor base attention
+ * (pipeline_regionally_t2iadapter.py:111-116).
+ *
+ * Layout: q is addressed as q[b*q_bs + n*q_rs + h*d + c]  (token-major "(B, N, H*d)" — the
+ * head_to_batch_dim permute of the reference is folded into the addressing, so q/k/v may be
+ * column slices of one fused projection output). Same for k, v, o.
+ *   lse   [B, H, Nq] fp32: log-sum-exp of scaled scores (saved for backward), may be NULL.
+ *   pcols [B, H, Nq, n_pcols] fp32 (optional, cross-attention training): softmax probability
+ *         of key index tok_idx[b*n_pcols + t] — all that cal_attn_reg (trainer_edlora.py:263-313)
+ *         consumes of the maps AttentionStore keeps (ptp_util.py:79-98).
+ * Supported head dims: 40, 80, 160 (SD-1.5, 8 heads at C = 320/640/1280).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, H, Nq, Nkv, d;
+    int64_t q_bs, q_rs;   /* batch / row strides in elements */
+    int64_t k_bs, k_rs;
+    int64_t v_bs, v_rs;
+    int64_t o_bs, o_rs;
+    float scale;
+} mos_attn_shape;
+
+int mos_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                 const int32_t* tok_idx, int n_pcols, float* pcols,
+                 const mos_attn_shape* shape_host, int dtype, void* stream);
+
+/* Backward. dO has o's layout; dq/dk/dv have q/k/v's layouts (strides given separately so
+ * they may be slices of one fused buffer). dpcols may be NULL.
+ * ws: mos_attn_bwd_workspace_bytes() bytes (fp32 D vector, split-q partials for dK/dV). */
+typedef struct {
+    int64_t do_bs, do_rs;
+    int64_t dq_bs, dq_rs;
+    int64_t dk_bs, dk_rs;
+    int64_t dv_bs, dv_rs;
+} mos_attn_grad_strides;
+
+int64_t mos_attn_bwd_workspace_bytes(const mos_attn_shape* shape_host);
+int mos_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse,
+                 const void* dO, const int32_t* tok_idx, int n_pcols, const float* pcols,
+                 const float* dpcols, void* dq, void* dk, void* dv, void* ws,
+                 const mos_attn_shape* shape_host, const mos_attn_grad_strides* gs_host,
+                 int dtype, void* stream);
+
+/* Names the reference-side binding uses (thin wrappers over mos_attn_fwd/bwd). */
+int mos_self_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                      const mos_attn_shape* shape_host, int dtype, void* stream);
+int mos_cross_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                       const int32_t* tok_idx, int n_pcols, float* pcols,
+                       const mos_attn_shape* shape_host, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Regional cross-attention mask-and-blend: replaces RegionT2I_AttnProcessor.region_rewrite
+ * (pipeline_regionally_t2iadapter.py:32-86) fused with the base cross-attention (:115-116).
+ *   out[q] = base(q)                                   if no region box covers q
+ *          = sum_{r covers q} attn(q, K_r, V_r) / count(q)   otherwise (replace_ratio = 1.0)
+ * Source 0 is the context prompt (base attention); sources 1..n_regions are regions with
+ * integer feature-map boxes [h0,h1) x [w0,w1) (already ceil/floor-rounded per :38-39 by host).
+ *   k_src / v_src: [n_src][B, Nkv, H*d] with strides src_stride (between sources), k_bs, k_rs.
+ * Inference only (no backward in the reference: pipeline __call__ is @torch.no_grad, :301).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int n_regions;                 /* <= MOS_MAX_SOURCES-1 */
+    int feat_h, feat_w;            /* Nq == feat_h*feat_w */
+    int box[MOS_MAX_SOURCES - 1][4]; /* h0, w0, h1, w1 in feature cells */
+    int64_t src_stride;            /* elements between consecutive sources in k_src/v_src */
+} mos_region_desc;
+
+int mos_region_cross_attn_fwd(const void* q, const void* k_src, const void* v_src, void* o,
+                              const mos_attn_shape* shape_host, const mos_region_desc* reg_host,
+                              int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gradient-fusion least squares: replaces chunk_compute_mse + the closure of
+ * update_quasi_newton (gradient_fusion.py:22-35,62-76). The loss
+ *     L(W) = mean((X W^T - Y)^2) = (tr(W G W^T) - 2 tr(W P^T) + c) / (n * Cout)
+ * depends on the data only through G = X^T X, P = Y^T X, c = sum(Y^2), which are accumulated
+ * ONCE per layer (streamed straight from the forward hooks, gradient_fusion.py:150-167)
+ * instead of re-uploading X and Y on every closure evaluation.
+ *   mos_gram_accumulate: G[Cin,Cin] += X^T X ; P[Cout,Cin] += Y^T X ; c += sum(Y^2)
+ *       X [n,Cin], Y [n,Cout] in `dtype` (the hooks record fp16 activations);
+ *       G, P, c are fp64 device accumulators (fp32 MFMA partials per row-chunk, fp64 combine).
+ *       ws: mos_gram_workspace_bytes(n,Cin,Cout) bytes.
+ *   mos_lsq_loss_grad_gram: loss (fp64 scalar on device) and grad[Cout,Cin] (fp64) of L at W (fp64);
+ *       ws: mos_lsq_workspace_bytes(Cout,Cin) bytes (per-block partial sums, combined in fixed order).
+ * ------------------------------------------------------------------------------------------ */
+int64_t mos_gram_workspace_bytes(int64_t n, int Cin, int Cout);
+int mos_gram_accumulate(const void* X, int64_t ldx, const void* Y, int64_t ldy, int64_t n,
+                        int Cin, int Cout, int dtype, double* G, double* P, double* c,
+                        void* ws, void* stream);
+int64_t mos_lsq_workspace_bytes(int Cout, int Cin);
+int mos_lsq_loss_grad_gram(const double* W, const double* G, const double* P, const double* c,
+                           double n_times_cout, int Cout, int Cin, double* loss, double* grad,
+                           void* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOS_HIP_H */

@@ -1,0 +1,876 @@
+// mos_attn.hip — fused attention for the SD-1.5 UNet on gfx950 (head dims 40 / 80 / 160, 8 heads).
+//
+// Replaces, in one kernel per direction, what the reference does with baddbmm + softmax + bmm on a
+// materialised (B*H, N, Nkv) probability tensor, or with xformers (reference
+// mixofshow/models/edlora.py:77-83,151-156; pipeline_regionally_t2iadapter.py:111-116), and the
+// per-region einsum/softmax/einsum + boolean-mask scatter of region_rewrite (:32-86).
+//
+// Design (CDNA4, wave64, v_mfma_f32_32x32x16_{f16,bf16}):
+//   * "swapped" products so that every softmax statistic is lane-local:
+//       S^T = K . Q^T      (A <- K rows from LDS, B <- Q rows held in registers)
+//       O^T = V^T . P^T    (A <- V^T from LDS,    B <- P^T = the S^T accumulator itself)
+//     MFMA 32x32x16: lane l supplies A[i=l&31][k=8*(l>>5)..+8], B[k=8*(l>>5)..+8][j=l&31];
+//     D: lane l holds D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31], r=0..15.
+//     With S^T in D-layout, lane l owns query column q=l&31 and 16 kv rows; registers 8s..8s+7 of
+//     the accumulator are EXACTLY a B operand for contraction step s if the A operand enumerates
+//     kv in the same order: k=8h+j  <->  kv = 16s + 4h + (j<4 ? j : j+4)   (h = l>>5).
+//     So P never leaves registers: no LDS round trip, no permlane.  V^T (and K^T, Q^T, dO^T in the
+//     backward) is produced once per tile by a transposing LDS store shared by the 4 waves.
+//   * the head_to_batch_dim permutes of the reference are folded into addressing: q/k/v/o are read
+//     and written in token-major (B, N, H*d) layout with explicit strides.
+//   * grid: blockIdx.x = head + H*(q_block + n_q_blocks*batch): blocks land on XCD (id % 8) = head,
+//     so all query blocks that re-read one head's K/V share one XCD's L2.
+#include "mos_common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+constexpr int KV_TILE = 64;
+constexpr int TS = KV_TILE + 4;  // transposed-tile row stride (68 el = 136 B = 8*17: b64 reads conflict-free)
+
+template <int D>
+struct HD {
+    static constexpr int DK = (D + 15) / 16 * 16;  // contraction length of Q.K^T (zero padded)
+    static constexpr int DV = (D + 31) / 32 * 32;  // rows of the transposed outputs (zero padded)
+    static constexpr int KS = DK / 16;
+    static constexpr int DT = DV / 32;
+    static constexpr int RS = DK + 8;  // row-major tile stride: (DK/8+1) odd -> b128 reads conflict-free
+    static constexpr int DCH = D / 8;  // 16-byte chunks per row
+    static constexpr int ROW_TILE_ELEMS = KV_TILE * RS;
+    static constexpr int TR_TILE_ELEMS = DV * TS;
+};
+
+struct AttnArgs {
+    const void* q; const void* k; const void* v; void* o;
+    float* lse; const int32_t* tok_idx; float* pcols; int n_pcols;
+    int B, H, Nq, Nkv, nqb;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    float scale;
+};
+
+struct AttnBwdArgs {
+    const void* q; const void* k; const void* v; const void* dO;
+    const float* lse; const float* Dvec; const int32_t* tok_idx; const float* dpcols; int n_pcols;
+    void* dq; void* dk; void* dv; float* part;  // part: fp32 split partials [2][nsplit][B*H][Nkv][D]
+    int B, H, Nq, Nkv, nqb, nkb, nsplit, q_per_split;
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    float scale;
+};
+
+// ---- LDS staging -----------------------------------------------------------------------------
+// Row-major tile [64][RS]: rows = tokens, 16-byte chunks; rows >= nvalid are zero-filled.
+template <typename T, int D>
+__device__ __forceinline__ void stage_rows(T* lds, const T* g, int64_t rs, int nvalid, int tid) {
+    constexpr int DCH = HD<D>::DCH, RS = HD<D>::RS;
+#pragma unroll
+    for (int c = tid; c < KV_TILE * DCH; c += 256) {
+        const int row = c / DCH, cc = c - row * DCH;
+        const u32x4 v = (row < nvalid) ? ld16(g + (int64_t)row * rs + cc * 8) : u32x4{0, 0, 0, 0};
+        st16(lds + row * RS + cc * 8, v);
+    }
+}
+// Transposed tile [DV][TS]: element (d, token). Two token rows are loaded per item and packed so the
+// store is one conflict-free ds_write_b32 per (d, token pair).
+template <typename T, int D>
+__device__ __forceinline__ void stage_transposed(T* ldsT, const T* g, int64_t rs, int nvalid, int tid) {
+    constexpr int DCH = HD<D>::DCH;
+#pragma unroll
+    for (int it = tid; it < 32 * DCH; it += 256) {
+        const int p = it & 31, cc = it >> 5;
+        const int r0 = 2 * p, r1 = 2 * p + 1;
+        const u32x4 v0 = (r0 < nvalid) ? ld16(g + (int64_t)r0 * rs + cc * 8) : u32x4{0, 0, 0, 0};
+        const u32x4 v1 = (r1 < nvalid) ? ld16(g + (int64_t)r1 * rs + cc * 8) : u32x4{0, 0, 0, 0};
+        uint32_t* dst = reinterpret_cast<uint32_t*>(ldsT + (cc * 8) * TS + 2 * p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i * (TS / 2)] = half_of(v0, i) | (half_of(v1, i) << 16);
+    }
+}
+template <typename T, int D>
+__device__ __forceinline__ void zero_row_pads(T* lds, int tid) {  // columns [D, DK) of a row-major tile
+    constexpr int DK = HD<D>::DK, RS = HD<D>::RS;
+    if constexpr (DK > D) {
+        for (int c = tid; c < KV_TILE * ((DK - D) / 8); c += 256) {
+            const int row = c / ((DK - D) / 8), cc = c % ((DK - D) / 8);
+            st16(lds + row * RS + D + cc * 8, u32x4{0, 0, 0, 0});
+        }
+    }
+}
+template <typename T, int D>
+__device__ __forceinline__ void zero_tr_pads(T* ldsT, int tid) {  // rows [D, DV) of a transposed tile
+    constexpr int DV = HD<D>::DV;
+    if constexpr (DV > D) {
+        uint32_t* p = reinterpret_cast<uint32_t*>(ldsT + D * TS);
+        for (int c = tid; c < (DV - D) * TS / 2; c += 256) p[c] = 0u;
+    }
+}
+// B-operand fragments of a register-resident row (query / dO / key / value row of this lane).
+template <typename T, int D>
+__device__ __forceinline__ void load_row_frags(typename MT<T>::v8 (&f)[HD<D>::KS], const T* row, bool valid, int hh) {
+#pragma unroll
+    for (int ks = 0; ks < HD<D>::KS; ++ks) {
+        const int col = ks * 16 + hh * 8;
+        f[ks] = as_v8<T>((valid && col < D) ? ld16(row + col) : u32x4{0, 0, 0, 0});
+    }
+}
+template <typename T>
+__device__ __forceinline__ typename MT<T>::v8 acc_to_bfrag(const f32x16& x, int s2) {
+    typename MT<T>::v8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (T)x[s2 * 8 + j];
+    return v;
+}
+// A operand of a transposed tile for contraction step (t, s2): rows = 32*dt + (l&31).
+template <typename T>
+__device__ __forceinline__ typename MT<T>::v8 tr_afrag(const T* ldsT_row, int t, int s2, int hh) {
+    const T* p = ldsT_row + 32 * t + 16 * s2 + 4 * hh;
+    const u32x2 lo = ld8(p), hi = ld8(p + 8);
+    return as_v8<T>(u32x4{lo[0], lo[1], hi[0], hi[1]});
+}
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// ---- one attention pass of a wave's NQ x 32 queries over all keys of one source ----------------
+// Returns unnormalised O^T accumulators, running max m (raw score units) and PER-LANE partial sums l.
+template <typename T, int D, int NQ, bool PCOLS>
+__device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vbase, int64_t v_rs, int Nkv,
+                                       float c /* scale*log2e */, T* Ks, T* Vt,
+                                       const typename MT<T>::v8 (&qf)[NQ][HD<D>::KS],
+                                       f32x16 (&o)[NQ][HD<D>::DT], float (&m)[NQ], float (&l)[NQ],
+                                       const int (&tok)[MOS_MAX_PCOLS], int n_pcols,
+                                       float (&cap)[NQ][MOS_MAX_PCOLS], int tid, int l31, int hh) {
+    typedef typename MT<T>::v8 v8;
+    constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+        m[iq] = NEG_BIG; l[iq] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[iq][dt][r] = 0.f;
+    }
+    for (int kv0 = 0; kv0 < Nkv; kv0 += KV_TILE) {
+        __syncthreads();  // all waves finished reading the previous tile
+        stage_rows<T, D>(Ks, kbase + (int64_t)kv0 * k_rs, k_rs, Nkv - kv0, tid);
+        stage_transposed<T, D>(Vt, vbase + (int64_t)kv0 * v_rs, v_rs, Nkv - kv0, tid);
+        __syncthreads();
+
+        f32x16 s[NQ][2];
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[iq][t][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v8 a = as_v8<T>(ld16(Ks + (32 * t + l31) * RS + ks * 16 + hh * 8));
+#pragma unroll
+                for (int iq = 0; iq < NQ; ++iq) s[iq][t] = MT<T>::mfma32(a, qf[iq][ks], s[iq][t]);
+            }
+        const bool tail = (kv0 + KV_TILE > Nkv);
+        v8 pf[NQ][2][2];
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq) {
+            if (tail) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + 32 * t + acc_row(r, hh) >= Nkv) s[iq][t][r] = NEG_BIG;
+            }
+            if constexpr (PCOLS) {
+#pragma unroll
+                for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
+                    if (tt < n_pcols) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                if (kv0 + 32 * t + acc_row(r, hh) == tok[tt]) cap[iq][tt] = s[iq][t][r];
+                    }
+            }
+            float mx = m[iq];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[iq][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float alpha = __builtin_amdgcn_exp2f((m[iq] - mx) * c);
+            m[iq] = mx;
+            const float mc = mx * c;
+            float ls = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[iq][t][r] * c - mc);
+                    s[iq][t][r] = p;
+                    ls += p;
+                }
+            l[iq] = l[iq] * alpha + ls;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[iq][dt][r] *= alpha;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) pf[iq][t][s2] = acc_to_bfrag<T>(s[iq][t], s2);
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const T* vrow = Vt + (32 * dt + l31) * TS;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const v8 a = tr_afrag<T>(vrow, t, s2, hh);
+#pragma unroll
+                    for (int iq = 0; iq < NQ; ++iq) o[iq][dt] = MT<T>::mfma32(a, pf[iq][t][s2], o[iq][dt]);
+                }
+        }
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void store_out_rows(T* orow, bool valid, const f32x16 (&o)[HD<D>::DT], float mul, int hh) {
+    if (!valid) return;
+#pragma unroll
+    for (int dt = 0; dt < HD<D>::DT; ++dt)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int db = 32 * dt + 8 * r4 + 4 * hh;
+            if (db < D)
+                st8(orow + db, pack4<T>(o[dt][4 * r4] * mul, o[dt][4 * r4 + 1] * mul, o[dt][4 * r4 + 2] * mul,
+                                         o[dt][4 * r4 + 3] * mul));
+        }
+}
+
+// ---- forward -----------------------------------------------------------------------------------
+template <typename T, int D, int QW, bool PCOLS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+    typedef typename MT<T>::v8 v8;
+    constexpr int NQ = QW / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);
+    T* Vt = Ks + HD<D>::ROW_TILE_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H;
+    const int rest = blockIdx.x / a.H;
+    const int qb = rest % a.nqb, b = rest / a.nqb;
+    const int q0 = qb * (4 * QW) + wave * QW;
+
+    zero_row_pads<T, D>(Ks, tid);
+    zero_tr_pads<T, D>(Vt, tid);
+
+    const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
+    const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * D;
+    const T* vp = (const T*)a.v + (int64_t)b * a.v_bs + h * D;
+    T* op = (T*)a.o + (int64_t)b * a.o_bs + h * D;
+
+    v8 qf[NQ][HD<D>::KS];
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+        const int qi = q0 + 32 * iq + l31;
+        load_row_frags<T, D>(qf[iq], qp + (int64_t)min(qi, a.Nq - 1) * a.q_rs, qi < a.Nq, hh);
+    }
+    int tok[MOS_MAX_PCOLS] = {-1, -1, -1, -1};
+    float cap[NQ][MOS_MAX_PCOLS];
+    if constexpr (PCOLS) {
+#pragma unroll
+        for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt) {
+            if (tt < a.n_pcols) tok[tt] = a.tok_idx[b * a.n_pcols + tt];
+#pragma unroll
+            for (int iq = 0; iq < NQ; ++iq) cap[iq][tt] = NEG_BIG;
+        }
+    }
+    f32x16 o[NQ][HD<D>::DT];
+    float m[NQ], l[NQ];
+    const float c = a.scale * LOG2E;
+    attend<T, D, NQ, PCOLS>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, a.n_pcols, cap, tid, l31, hh);
+
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+        const int qi = q0 + 32 * iq + l31;
+        const float lt = l[iq] + __shfl_xor(l[iq], 32);
+        const float inv = 1.0f / lt;
+        store_out_rows<T, D>(op + (int64_t)qi * a.o_rs, qi < a.Nq, o[iq], inv, hh);
+        const int64_t row = ((int64_t)b * a.H + h) * a.Nq + qi;
+        if (a.lse != nullptr && hh == 0 && qi < a.Nq) a.lse[row] = m[iq] * a.scale + __logf(lt);
+        if constexpr (PCOLS) {
+#pragma unroll
+            for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
+                if (tt < a.n_pcols) {
+                    float sv = cap[iq][tt];
+                    sv = fmaxf(sv, __shfl_xor(sv, 32));
+                    if (hh == 0 && qi < a.Nq)
+                        a.pcols[row * a.n_pcols + tt] = __builtin_amdgcn_exp2f((sv - m[iq]) * c) * inv;
+                }
+        }
+    }
+}
+
+// ---- regional cross-attention: sum over covering sources of attention / count ---------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void region_attn_kernel(AttnArgs a, mos_region_desc reg) {
+    typedef typename MT<T>::v8 v8;
+    constexpr int DT = HD<D>::DT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);
+    T* Vt = Ks + HD<D>::ROW_TILE_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H;
+    const int rest = blockIdx.x / a.H;
+    const int qb = rest % a.nqb, b = rest / a.nqb;
+    const int qi = qb * 128 + wave * 32 + l31;
+
+    zero_row_pads<T, D>(Ks, tid);
+    zero_tr_pads<T, D>(Vt, tid);
+
+    const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
+    T* op = (T*)a.o + (int64_t)b * a.o_bs + h * D;
+    v8 qf[1][HD<D>::KS];
+    load_row_frags<T, D>(qf[0], qp + (int64_t)min(qi, a.Nq - 1) * a.q_rs, qi < a.Nq, hh);
+
+    const int y = qi / reg.feat_w, x = qi - y * reg.feat_w;
+    int cnt = 0;
+    for (int r = 0; r < reg.n_regions; ++r)
+        cnt += (y >= reg.box[r][0] && y < reg.box[r][2] && x >= reg.box[r][1] && x < reg.box[r][3]) ? 1 : 0;
+
+    f32x16 fin[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fin[dt][r] = 0.f;
+    const float c = a.scale * LOG2E;
+    int tok[MOS_MAX_PCOLS] = {-1, -1, -1, -1};
+    float cap[1][MOS_MAX_PCOLS];
+
+    for (int src = 0; src <= reg.n_regions; ++src) {
+        float w;
+        if (src == 0) {
+            w = (cnt == 0) ? 1.f : 0.f;
+        } else {
+            const int r = src - 1;
+            const bool in = (y >= reg.box[r][0] && y < reg.box[r][2] && x >= reg.box[r][1] && x < reg.box[r][3]);
+            w = in ? 1.f / (float)cnt : 0.f;
+        }
+        if (qi >= a.Nq) w = 0.f;
+        if (!__syncthreads_or(w != 0.f)) continue;  // block-uniform: no query of this block uses src
+        const T* kp = (const T*)a.k + (int64_t)src * reg.src_stride + (int64_t)b * a.k_bs + h * D;
+        const T* vp = (const T*)a.v + (int64_t)src * reg.src_stride + (int64_t)b * a.v_bs + h * D;
+        f32x16 o[1][DT];
+        float m[1], l[1];
+        attend<T, D, 1, false>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, 0, cap, tid, l31, hh);
+        const float lt = l[0] + __shfl_xor(l[0], 32);
+        const float mul = w / lt;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[dt][r] += o[0][dt][r] * mul;
+    }
+    store_out_rows<T, D>(op + (int64_t)qi * a.o_rs, qi < a.Nq, fin, 1.0f, hh);
+}
+
+// ---- backward: D = rowsum(dO * O) + sum_t dpcols * pcols -------------------------------------------
+template <typename T, int D>
+__global__ void attn_bwd_prep_kernel(const T* __restrict__ o, int64_t o_bs, int64_t o_rs, const T* __restrict__ dO,
+                                     int64_t do_bs, int64_t do_rs, const float* __restrict__ pcols,
+                                     const float* __restrict__ dpcols, int n_pcols, float* __restrict__ Dvec, int B,
+                                     int H, int Nq) {
+    typedef typename MT<T>::v8 v8;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, q, h), h fastest
+    if (idx >= (int64_t)B * Nq * H) return;
+    const int h = idx % H;
+    const int64_t bq = idx / H;
+    const int q = bq % Nq;
+    const int b = bq / Nq;
+    const T* op = o + (int64_t)b * o_bs + (int64_t)q * o_rs + h * D;
+    const T* dp = dO + (int64_t)b * do_bs + (int64_t)q * do_rs + h * D;
+    float s = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < D / 8; ++cc) {
+        const v8 x = as_v8<T>(ld16(op + cc * 8)), y = as_v8<T>(ld16(dp + cc * 8));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)x[e] * (float)y[e];
+    }
+    const int64_t row = ((int64_t)b * H + h) * Nq + q;
+    if (pcols != nullptr && dpcols != nullptr)
+        for (int t = 0; t < n_pcols; ++t) s += pcols[row * n_pcols + t] * dpcols[row * n_pcols + t];
+    Dvec[row] = s;
+}
+
+// ---- backward dQ: one wave = 32 queries, loop over key tiles -----------------------------------------
+//   S^T = K Q^T ; P^T = exp(scale*S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - D) ; dQ^T += K^T dS^T
+template <typename T, int D, bool PCOLS>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+    typedef typename MT<T>::v8 v8;
+    constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks = reinterpret_cast<T*>(smem_raw);
+    T* Vs = Ks + HD<D>::ROW_TILE_ELEMS;
+    T* Kt = Vs + HD<D>::ROW_TILE_ELEMS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H;
+    const int rest = blockIdx.x / a.H;
+    const int qb = rest % a.nqb, b = rest / a.nqb;
+    const int qi = qb * 128 + wave * 32 + l31;
+    const bool qvalid = qi < a.Nq;
+    const int qc = min(qi, a.Nq - 1);
+
+    zero_row_pads<T, D>(Ks, tid);
+    zero_row_pads<T, D>(Vs, tid);
+    zero_tr_pads<T, D>(Kt, tid);
+
+    const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * D;
+    const T* vp = (const T*)a.v + (int64_t)b * a.v_bs + h * D;
+    v8 qf[KS], dof[KS];
+    load_row_frags<T, D>(qf, (const T*)a.q + (int64_t)b * a.q_bs + (int64_t)qc * a.q_rs + h * D, qvalid, hh);
+    load_row_frags<T, D>(dof, (const T*)a.dO + (int64_t)b * a.do_bs + (int64_t)qc * a.do_rs + h * D, qvalid, hh);
+    const int64_t row = ((int64_t)b * a.H + h) * a.Nq + qc;
+    const float lse2 = a.lse[row] * LOG2E;
+    const float Dq = a.Dvec[row];
+    const float c = a.scale * LOG2E;
+    int tok[MOS_MAX_PCOLS] = {-1, -1, -1, -1};
+    float dpc[MOS_MAX_PCOLS] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PCOLS) {
+#pragma unroll
+        for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
+            if (tt < a.n_pcols) {
+                tok[tt] = a.tok_idx[b * a.n_pcols + tt];
+                dpc[tt] = a.dpcols[row * a.n_pcols + tt];
+            }
+    }
+    f32x16 dq[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+
+    for (int kv0 = 0; kv0 < a.Nkv; kv0 += KV_TILE) {
+        __syncthreads();
+        stage_rows<T, D>(Ks, kp + (int64_t)kv0 * a.k_rs, a.k_rs, a.Nkv - kv0, tid);
+        stage_rows<T, D>(Vs, vp + (int64_t)kv0 * a.v_rs, a.v_rs, a.Nkv - kv0, tid);
+        stage_transposed<T, D>(Kt, kp + (int64_t)kv0 * a.k_rs, a.k_rs, a.Nkv - kv0, tid);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (32 * t + l31) * RS + ks * 16 + hh * 8;
+                s = MT<T>::mfma32(as_v8<T>(ld16(Ks + off)), qf[ks], s);
+                dp = MT<T>::mfma32(as_v8<T>(ld16(Vs + off)), dof[ks], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kvi = kv0 + 32 * t + acc_row(r, hh);
+                const float p = (kvi < a.Nkv) ? __builtin_amdgcn_exp2f(s[r] * c - lse2) : 0.f;
+                float g = dp[r];
+                if constexpr (PCOLS) {
+#pragma unroll
+                    for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
+                        if (kvi == tok[tt]) g += dpc[tt];
+                }
+                s[r] = p * (g - Dq);
+            }
+            v8 dsf[2];
+            dsf[0] = acc_to_bfrag<T>(s, 0);
+            dsf[1] = acc_to_bfrag<T>(s, 1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const T* krow = Kt + (32 * dt + l31) * TS;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) dq[dt] = MT<T>::mfma32(tr_afrag<T>(krow, t, s2, hh), dsf[s2], dq[dt]);
+            }
+        }
+    }
+    T* dqp = (T*)a.dq + (int64_t)b * a.dq_bs + (int64_t)qi * a.dq_rs + h * D;
+    store_out_rows<T, D>(dqp, qvalid, dq, a.scale, hh);
+}
+
+// ---- backward dK/dV: one wave = 32 keys, loop over query tiles of this split ------------------------
+//   S = Q K^T ; P = exp(scale*S - lse) ; dV^T += dO^T P ; dP = dO V^T ; dS = P o (dP - D) ; dK^T += Q^T dS
+template <typename T, int D, bool PCOLS>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
+    typedef typename MT<T>::v8 v8;
+    constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Qs = reinterpret_cast<T*>(smem_raw);
+    T* dOs = Qs + HD<D>::ROW_TILE_ELEMS;
+    T* Qt = dOs + HD<D>::ROW_TILE_ELEMS;
+    T* dOt = Qt + HD<D>::TR_TILE_ELEMS;
+    float* lse_s = reinterpret_cast<float*>(dOt + HD<D>::TR_TILE_ELEMS);  // [64] (already * log2e)
+    float* D_s = lse_s + KV_TILE;                                          // [64]
+    float* dpc_s = D_s + KV_TILE;                                          // [64][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H;
+    const int rest = blockIdx.x / a.H;
+    const int kb = rest % a.nkb, b = rest / a.nkb;
+    const int split = blockIdx.y;
+    const int kvi = kb * 128 + wave * 32 + l31;
+    const bool kvalid = kvi < a.Nkv;
+    const int kc = min(kvi, a.Nkv - 1);
+
+    zero_row_pads<T, D>(Qs, tid);
+    zero_row_pads<T, D>(dOs, tid);
+    zero_tr_pads<T, D>(Qt, tid);
+    zero_tr_pads<T, D>(dOt, tid);
+
+    v8 kf[KS], vf[KS];
+    load_row_frags<T, D>(kf, (const T*)a.k + (int64_t)b * a.k_bs + (int64_t)kc * a.k_rs + h * D, kvalid, hh);
+    load_row_frags<T, D>(vf, (const T*)a.v + (int64_t)b * a.v_bs + (int64_t)kc * a.v_rs + h * D, kvalid, hh);
+    const float c = a.scale * LOG2E;
+    int mytok = -1;  // index t of the exported column this lane's key corresponds to, if any
+    if constexpr (PCOLS) {
+#pragma unroll
+        for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
+            if (tt < a.n_pcols && a.tok_idx[b * a.n_pcols + tt] == kvi) mytok = tt;
+    }
+    f32x16 dkT[DT], dvT[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkT[dt][r] = 0.f; dvT[dt][r] = 0.f; }
+
+    const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
+    const T* dop = (const T*)a.dO + (int64_t)b * a.do_bs + h * D;
+    const int64_t rowbase = ((int64_t)b * a.H + h) * a.Nq;
+    const int qbeg = split * a.q_per_split;
+    const int qend = min(qbeg + a.q_per_split, a.Nq);
+
+    for (int q0 = qbeg; q0 < qend; q0 += KV_TILE) {
+        __syncthreads();
+        const int nv = qend - q0;
+        stage_rows<T, D>(Qs, qp + (int64_t)q0 * a.q_rs, a.q_rs, nv, tid);
+        stage_rows<T, D>(dOs, dop + (int64_t)q0 * a.do_rs, a.do_rs, nv, tid);
+        stage_transposed<T, D>(Qt, qp + (int64_t)q0 * a.q_rs, a.q_rs, nv, tid);
+        stage_transposed<T, D>(dOt, dop + (int64_t)q0 * a.do_rs, a.do_rs, nv, tid);
+        if (tid < KV_TILE) {
+            const bool ok = tid < nv;
+            lse_s[tid] = ok ? a.lse[rowbase + q0 + tid] * LOG2E : 0.f;
+            D_s[tid] = ok ? a.Dvec[rowbase + q0 + tid] : 0.f;
+            if constexpr (PCOLS) {
+#pragma unroll
+                for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
+                    dpc_s[tid * MOS_MAX_PCOLS + tt] =
+                        (ok && tt < a.n_pcols) ? a.dpcols[(rowbase + q0 + tid) * a.n_pcols + tt] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (32 * t + l31) * RS + ks * 16 + hh * 8;
+                s = MT<T>::mfma32(as_v8<T>(ld16(Qs + off)), kf[ks], s);
+                dp = MT<T>::mfma32(as_v8<T>(ld16(dOs + off)), vf[ks], dp);
+            }
+            // accumulator rows are query-local indices 32t + acc_row(r, hh); column = this lane's key
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int ql = 32 * t + 8 * r4 + 4 * hh;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(D_s + ql);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int r = 4 * r4 + rr;
+                    const float p = kvalid ? __builtin_amdgcn_exp2f(s[r] * c - l4[rr]) : 0.f;
+                    float g = dp[r];
+                    if constexpr (PCOLS) {
+                        if (mytok >= 0) g += dpc_s[(ql + rr) * MOS_MAX_PCOLS + mytok];
+                    }
+                    s[r] = p;
+                    dp[r] = p * (g - d4[rr]);
+                }
+            }
+            v8 pf[2], dsf[2];
+            pf[0] = acc_to_bfrag<T>(s, 0); pf[1] = acc_to_bfrag<T>(s, 1);
+            dsf[0] = acc_to_bfrag<T>(dp, 0); dsf[1] = acc_to_bfrag<T>(dp, 1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const T* dorow = dOt + (32 * dt + l31) * TS;
+                const T* qrow = Qt + (32 * dt + l31) * TS;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dvT[dt] = MT<T>::mfma32(tr_afrag<T>(dorow, t, s2, hh), pf[s2], dvT[dt]);
+                    dkT[dt] = MT<T>::mfma32(tr_afrag<T>(qrow, t, s2, hh), dsf[s2], dkT[dt]);
+                }
+            }
+        }
+    }
+    if (a.nsplit == 1) {
+        T* dkp = (T*)a.dk + (int64_t)b * a.dk_bs + (int64_t)kvi * a.dk_rs + h * D;
+        T* dvp = (T*)a.dv + (int64_t)b * a.dv_bs + (int64_t)kvi * a.dv_rs + h * D;
+        store_out_rows<T, D>(dkp, kvalid, dkT, a.scale, hh);
+        store_out_rows<T, D>(dvp, kvalid, dvT, 1.0f, hh);
+    } else if (kvalid) {
+        const int64_t bh = (int64_t)b * a.H + h;
+        const int64_t slab = (int64_t)a.B * a.H * a.Nkv * D;
+        float* pk = a.part + ((int64_t)split * slab) + (bh * a.Nkv + kvi) * D;
+        float* pv = pk + (int64_t)a.nsplit * slab;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int db = 32 * dt + 8 * r4 + 4 * hh;
+                if (db < D) {
+                    *reinterpret_cast<f32x4*>(pk + db) = f32x4{dkT[dt][4 * r4] * a.scale, dkT[dt][4 * r4 + 1] * a.scale,
+                                                              dkT[dt][4 * r4 + 2] * a.scale, dkT[dt][4 * r4 + 3] * a.scale};
+                    *reinterpret_cast<f32x4*>(pv + db) = f32x4{dvT[dt][4 * r4], dvT[dt][4 * r4 + 1], dvT[dt][4 * r4 + 2],
+                                                              dvT[dt][4 * r4 + 3]};
+                }
+            }
+    }
+}
+
+// sum split partials -> dK, dV in T with output strides
+template <typename T, int D>
+__global__ void attn_bwd_reduce_kernel(const float* __restrict__ part, int nsplit, T* __restrict__ dk, int64_t dk_bs,
+                                       int64_t dk_rs, T* __restrict__ dv, int64_t dv_bs, int64_t dv_rs, int B, int H,
+                                       int Nkv) {
+    const int64_t slab = (int64_t)B * H * Nkv * D;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over slab/4
+    if (idx * 4 >= slab) return;
+    const int64_t e = idx * 4;
+    const int d = e % D;
+    const int64_t r = e / D;
+    const int kv = r % Nkv;
+    const int64_t bh = r / Nkv;
+    const int h = bh % H, b = bh / H;
+    f32x4 sk = {0.f, 0.f, 0.f, 0.f}, sv = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+        sk += *reinterpret_cast<const f32x4*>(part + (int64_t)s * slab + e);
+        sv += *reinterpret_cast<const f32x4*>(part + ((int64_t)nsplit + s) * slab + e);
+    }
+    st8(dk + (int64_t)b * dk_bs + (int64_t)kv * dk_rs + h * D + d, pack4<T>(sk[0], sk[1], sk[2], sk[3]));
+    st8(dv + (int64_t)b * dv_bs + (int64_t)kv * dv_rs + h * D + d, pack4<T>(sv[0], sv[1], sv[2], sv[3]));
+}
+
+// ---- host dispatch -----------------------------------------------------------------------------
+template <int D> constexpr int fwd_qw() { return D <= 80 ? 64 : 32; }
+
+template <int D> constexpr size_t fwd_lds(size_t es) { return (HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
+template <int D> constexpr size_t dq_lds(size_t es) { return (2 * HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
+template <int D> constexpr size_t dkdv_lds(size_t es) {
+    return (2 * HD<D>::ROW_TILE_ELEMS + 2 * HD<D>::TR_TILE_ELEMS) * es + (2 * KV_TILE + KV_TILE * MOS_MAX_PCOLS) * sizeof(float);
+}
+
+template <typename K>
+void set_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int check_shape(const mos_attn_shape* s, const char* who) {
+    if (!s) return mos_set_error(MOS_ERR_BAD_ARG, "%s: NULL shape", who);
+    if (s->B <= 0 || s->H <= 0 || s->Nq <= 0 || s->Nkv <= 0)
+        return mos_set_error(MOS_ERR_BAD_ARG, "%s: B=%d H=%d Nq=%d Nkv=%d", who, s->B, s->H, s->Nq, s->Nkv);
+    if (s->d != 40 && s->d != 80 && s->d != 160)
+        return mos_set_error(MOS_ERR_UNSUPPORTED, "%s: head dim %d not in {40, 80, 160}", who, s->d);
+    if (s->q_rs % 8 || s->k_rs % 8 || s->v_rs % 8 || s->o_rs % 4 || s->q_bs % 8 || s->k_bs % 8 || s->v_bs % 8 || s->o_bs % 4)
+        return mos_set_error(MOS_ERR_BAD_ARG, "%s: strides must be multiples of 8 elements", who);
+    return MOS_OK;
+}
+
+AttnArgs make_args(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* tok, int np,
+                   float* pcols, const mos_attn_shape* s, int q_tile) {
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.tok_idx = tok; a.pcols = pcols; a.n_pcols = np;
+    a.B = s->B; a.H = s->H; a.Nq = s->Nq; a.Nkv = s->Nkv; a.nqb = (s->Nq + q_tile - 1) / q_tile;
+    a.q_bs = s->q_bs; a.q_rs = s->q_rs; a.k_bs = s->k_bs; a.k_rs = s->k_rs;
+    a.v_bs = s->v_bs; a.v_rs = s->v_rs; a.o_bs = s->o_bs; a.o_rs = s->o_rs; a.scale = s->scale;
+    return a;
+}
+
+template <typename T, int D>
+int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* tok, int np,
+               float* pcols, const mos_attn_shape* s, hipStream_t st) {
+    constexpr int QW = fwd_qw<D>();
+    AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 4 * QW);
+    const dim3 grid((unsigned)(a.H * a.nqb * a.B));
+    const size_t lds = fwd_lds<D>(sizeof(T));
+    if (np > 0) {
+        set_lds(&attn_fwd_kernel<T, D, QW, true>, lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, QW, true>), grid, dim3(256), lds, st, a);
+    } else {
+        set_lds(&attn_fwd_kernel<T, D, QW, false>, lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, D, QW, false>), grid, dim3(256), lds, st, a);
+    }
+    return mos_check_launch("attn_fwd");
+}
+
+template <typename T, int D>
+int launch_region(const void* q, const void* k, const void* v, void* o, const mos_attn_shape* s,
+                  const mos_region_desc* reg, hipStream_t st) {
+    AttnArgs a = make_args(q, k, v, o, nullptr, nullptr, 0, nullptr, s, 128);
+    const dim3 grid((unsigned)(a.H * a.nqb * a.B));
+    const size_t lds = fwd_lds<D>(sizeof(T));
+    set_lds(&region_attn_kernel<T, D>, lds);
+    hipLaunchKernelGGL((region_attn_kernel<T, D>), grid, dim3(256), lds, st, a, *reg);
+    return mos_check_launch("region_attn");
+}
+
+struct BwdPlan { int nkb, nsplit, q_per_split; };
+BwdPlan plan_bwd(const mos_attn_shape* s) {
+    BwdPlan p;
+    p.nkb = (s->Nkv + 127) / 128;
+    const int64_t base = (int64_t)p.nkb * s->B * s->H;
+    const int qtiles = (s->Nq + KV_TILE - 1) / KV_TILE;
+    int ns = (int)((512 + base - 1) / base);
+    if (ns > qtiles) ns = qtiles;
+    if (ns < 1) ns = 1;
+    int tps = (qtiles + ns - 1) / ns;  // tiles per split
+    ns = (qtiles + tps - 1) / tps;
+    p.nsplit = ns;
+    p.q_per_split = tps * KV_TILE;
+    return p;
+}
+
+template <typename T, int D>
+int launch_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dO,
+               const int32_t* tok, int np, const float* pcols, const float* dpcols, void* dq, void* dk, void* dv,
+               void* ws, const mos_attn_shape* s, const mos_attn_grad_strides* g, hipStream_t st) {
+    const BwdPlan p = plan_bwd(s);
+    float* Dvec = (float*)ws;
+    const int64_t nrows = (int64_t)s->B * s->H * s->Nq;
+    float* part = Dvec + ((nrows + 3) / 4) * 4;
+    {
+        const int64_t tot = nrows;
+        hipLaunchKernelGGL((attn_bwd_prep_kernel<T, D>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
+                           (const T*)o, s->o_bs, s->o_rs, (const T*)dO, g->do_bs, g->do_rs, pcols, dpcols, np, Dvec,
+                           s->B, s->H, s->Nq);
+        int rc = mos_check_launch("attn_bwd_prep");
+        if (rc) return rc;
+    }
+    AttnBwdArgs a;
+    a.q = q; a.k = k; a.v = v; a.dO = dO; a.lse = lse; a.Dvec = Dvec; a.tok_idx = tok; a.dpcols = dpcols;
+    a.n_pcols = (dpcols != nullptr) ? np : 0;
+    a.dq = dq; a.dk = dk; a.dv = dv; a.part = part;
+    a.B = s->B; a.H = s->H; a.Nq = s->Nq; a.Nkv = s->Nkv; a.nqb = (s->Nq + 127) / 128; a.nkb = p.nkb;
+    a.nsplit = p.nsplit; a.q_per_split = p.q_per_split;
+    a.q_bs = s->q_bs; a.q_rs = s->q_rs; a.k_bs = s->k_bs; a.k_rs = s->k_rs; a.v_bs = s->v_bs; a.v_rs = s->v_rs;
+    a.do_bs = g->do_bs; a.do_rs = g->do_rs; a.dq_bs = g->dq_bs; a.dq_rs = g->dq_rs;
+    a.dk_bs = g->dk_bs; a.dk_rs = g->dk_rs; a.dv_bs = g->dv_bs; a.dv_rs = g->dv_rs; a.scale = s->scale;
+    const bool pc = a.n_pcols > 0;
+    {
+        const dim3 grid((unsigned)(a.H * a.nqb * a.B));
+        const size_t lds = dq_lds<D>(sizeof(T));
+        if (pc) {
+            set_lds(&attn_bwd_dq_kernel<T, D, true>, lds);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), grid, dim3(256), lds, st, a);
+        } else {
+            set_lds(&attn_bwd_dq_kernel<T, D, false>, lds);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), grid, dim3(256), lds, st, a);
+        }
+        int rc = mos_check_launch("attn_bwd_dq");
+        if (rc) return rc;
+    }
+    {
+        const dim3 grid((unsigned)(a.H * a.nkb * a.B), (unsigned)a.nsplit);
+        const size_t lds = dkdv_lds<D>(sizeof(T));
+        if (pc) {
+            set_lds(&attn_bwd_dkdv_kernel<T, D, true>, lds);
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true>), grid, dim3(256), lds, st, a);
+        } else {
+            set_lds(&attn_bwd_dkdv_kernel<T, D, false>, lds);
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, false>), grid, dim3(256), lds, st, a);
+        }
+        int rc = mos_check_launch("attn_bwd_dkdv");
+        if (rc) return rc;
+    }
+    if (a.nsplit > 1) {
+        const int64_t slab4 = (int64_t)s->B * s->H * s->Nkv * D / 4;
+        hipLaunchKernelGGL((attn_bwd_reduce_kernel<T, D>), dim3((unsigned)((slab4 + 255) / 256)), dim3(256), 0, st, part,
+                           a.nsplit, (T*)dk, g->dk_bs, g->dk_rs, (T*)dv, g->dv_bs, g->dv_rs, s->B, s->H, s->Nkv);
+        return mos_check_launch("attn_bwd_reduce");
+    }
+    return MOS_OK;
+}
+
+#define MOS_DISPATCH_TD(dtype, d, CALL)                                                     \
+    do {                                                                                    \
+        if ((dtype) == MOS_F16) {                                                           \
+            typedef f16_t TT;                                                               \
+            if ((d) == 40) { constexpr int DD = 40; return CALL; }                          \
+            if ((d) == 80) { constexpr int DD = 80; return CALL; }                          \
+            if ((d) == 160) { constexpr int DD = 160; return CALL; }                        \
+        } else if ((dtype) == MOS_BF16) {                                                   \
+            typedef bf16_t TT;                                                              \
+            if ((d) == 40) { constexpr int DD = 40; return CALL; }                          \
+            if ((d) == 80) { constexpr int DD = 80; return CALL; }                          \
+            if ((d) == 160) { constexpr int DD = 160; return CALL; }                        \
+        }                                                                                   \
+        return mos_set_error(MOS_ERR_UNSUPPORTED, "unsupported dtype %d / head dim %d", (int)(dtype), (int)(d)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mos_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* tok_idx, int n_pcols,
+                 float* pcols, const mos_attn_shape* s, int dtype, void* stream) {
+    int rc = check_shape(s, "mos_attn_fwd");
+    if (rc) return rc;
+    MOS_REQUIRE(q && k && v && o, "mos_attn_fwd: NULL tensor");
+    MOS_REQUIRE(n_pcols >= 0 && n_pcols <= MOS_MAX_PCOLS, "mos_attn_fwd: n_pcols=%d (max %d)", n_pcols, MOS_MAX_PCOLS);
+    MOS_REQUIRE(n_pcols == 0 || (tok_idx && pcols), "mos_attn_fwd: n_pcols>0 needs tok_idx and pcols");
+    hipStream_t st = (hipStream_t)stream;
+    MOS_DISPATCH_TD(dtype, s->d, (launch_fwd<TT, DD>(q, k, v, o, lse, tok_idx, n_pcols, pcols, s, st)));
+}
+
+int mos_self_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const mos_attn_shape* s,
+                      int dtype, void* stream) {
+    return mos_attn_fwd(q, k, v, o, lse, nullptr, 0, nullptr, s, dtype, stream);
+}
+
+int mos_cross_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* tok_idx,
+                       int n_pcols, float* pcols, const mos_attn_shape* s, int dtype, void* stream) {
+    return mos_attn_fwd(q, k, v, o, lse, tok_idx, n_pcols, pcols, s, dtype, stream);
+}
+
+int64_t mos_attn_bwd_workspace_bytes(const mos_attn_shape* s) {
+    if (!s) return 0;
+    const BwdPlan p = plan_bwd(s);
+    const int64_t nrows = (int64_t)s->B * s->H * s->Nq;
+    int64_t fl = ((nrows + 3) / 4) * 4;
+    if (p.nsplit > 1) fl += 2 * (int64_t)p.nsplit * s->B * s->H * s->Nkv * s->d;
+    return fl * (int64_t)sizeof(float);
+}
+
+int mos_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dO,
+                 const int32_t* tok_idx, int n_pcols, const float* pcols, const float* dpcols, void* dq, void* dk,
+                 void* dv, void* ws, const mos_attn_shape* s, const mos_attn_grad_strides* g, int dtype, void* stream) {
+    int rc = check_shape(s, "mos_attn_bwd");
+    if (rc) return rc;
+    MOS_REQUIRE(q && k && v && o && lse && dO && dq && dk && dv && ws && g, "mos_attn_bwd: NULL argument");
+    MOS_REQUIRE(n_pcols >= 0 && n_pcols <= MOS_MAX_PCOLS, "mos_attn_bwd: n_pcols=%d", n_pcols);
+    MOS_REQUIRE(dpcols == nullptr || (n_pcols > 0 && tok_idx && pcols), "mos_attn_bwd: dpcols needs tok_idx, pcols");
+    MOS_REQUIRE(g->do_rs % 8 == 0 && g->dq_rs % 4 == 0 && g->dk_rs % 4 == 0 && g->dv_rs % 4 == 0,
+                "mos_attn_bwd: gradient strides misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    MOS_DISPATCH_TD(dtype, s->d,
+                    (launch_bwd<TT, DD>(q, k, v, o, lse, dO, tok_idx, n_pcols, pcols, dpcols, dq, dk, dv, ws, s, g, st)));
+}
+
+int mos_region_cross_attn_fwd(const void* q, const void* k_src, const void* v_src, void* o, const mos_attn_shape* s,
+                              const mos_region_desc* reg, int dtype, void* stream) {
+    int rc = check_shape(s, "mos_region_cross_attn_fwd");
+    if (rc) return rc;
+    MOS_REQUIRE(q && k_src && v_src && o && reg, "mos_region_cross_attn_fwd: NULL argument");
+    MOS_REQUIRE(reg->n_regions >= 0 && reg->n_regions <= MOS_MAX_SOURCES - 1, "mos_region_cross_attn_fwd: n_regions=%d",
+                reg->n_regions);
+    MOS_REQUIRE(reg->feat_h > 0 && reg->feat_w > 0 && reg->feat_h * reg->feat_w == s->Nq,
+                "mos_region_cross_attn_fwd: feat %dx%d != Nq %d", reg->feat_h, reg->feat_w, s->Nq);
+    hipStream_t st = (hipStream_t)stream;
+    MOS_DISPATCH_TD(dtype, s->d, (launch_region<TT, DD>(q, k_src, v_src, o, s, reg, st)));
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// mos_common.h — shared device helpers for the gfx950 (CDNA4) kernels of libmos_hip.
+// Wave = 64 lanes everywhere; MFMA fragment conventions are documented at each use.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mos_hip.h"
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- per-dtype traits: 8-wide / 4-wide MFMA operand vectors and the MFMA builtins ----------
+template <typename T> struct MT;
+
+template <> struct MT<f16_t> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 v8;
+    typedef __attribute__((ext_vector_type(4))) _Float16 v4;
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16k16(v4 a, v4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <> struct MT<bf16_t> {
+    typedef __attribute__((ext_vector_type(8))) __bf16 v8;
+    typedef __attribute__((ext_vector_type(4))) __bf16 v4;
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16k16(v4 a, v4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4, a),
+                                                         __builtin_bit_cast(s4, b), c, 0, 0, 0);
+    }
+};
+
+// 16-byte / 8-byte raw views used for global<->LDS staging.
+template <typename T>
+__device__ __forceinline__ typename MT<T>::v8 as_v8(u32x4 x) {
+    return __builtin_bit_cast(typename MT<T>::v8, x);
+}
+template <typename T>
+__device__ __forceinline__ u32x4 from_v8(typename MT<T>::v8 x) {
+    return __builtin_bit_cast(u32x4, x);
+}
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ __forceinline__ void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
+
+// Pack 4 floats to 4 T (round-to-nearest-even) as 8 bytes.
+template <typename T>
+__device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+    typename MT<T>::v4 v;
+    v[0] = (T)a; v[1] = (T)b; v[2] = (T)c; v[3] = (T)d;
+    return __builtin_bit_cast(u32x2, v);
+}
+template <typename T>
+__device__ __forceinline__ typename MT<T>::v8 pack8(const float* p) {
+    typename MT<T>::v8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)p[i];
+    return v;
+}
+
+// 16-bit element i of a 16-byte chunk, as raw bits.
+__device__ __forceinline__ uint32_t half_of(u32x4 v, int i) {
+    uint32_t w = v[i >> 1];
+    return (i & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ---- host-side error plumbing (defined in mos_api.hip) --------------------------------------
+int mos_set_error(int code, const char* fmt, ...);
+int mos_check_launch(const char* what);
+
+#define MOS_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return mos_set_error(MOS_ERR_BAD_ARG, __VA_ARGS__); \
+    } while (0)
