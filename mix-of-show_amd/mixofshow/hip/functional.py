@@ -1,0 +1,220 @@
+"""Autograd wrappers around the HIP primitives (mixofshow.hip.ops).
+
+`lora_linear`   — y = x W^T + sum_g alpha_g (x A_g^T) B_g^T + b for 1..4 LoRA sites sharing x
+                  (reference LoRALinearLayer.forward, mixofshow/models/edlora.py:244-246; W frozen).
+`attention`     — fused softmax(scale q k^T) v, optionally exporting the probabilities of a few
+                  key positions (what cal_attn_reg needs, trainer_edlora.py:289-298).
+Both save only what the backward kernels need (no (B*H, N, 77) probability tensors).
+"""
+import torch
+
+from . import ops
+
+_default_compute_dtype = torch.float16
+
+
+def set_default_compute_dtype(dtype):
+    global _default_compute_dtype
+    assert dtype in (torch.float16, torch.bfloat16)
+    _default_compute_dtype = dtype
+
+
+def compute_dtype_for(x):
+    """Half dtype the kernels run in: the autocast dtype if autocast is on, else x's half dtype, else default."""
+    if torch.is_autocast_enabled('cuda'):
+        dt = torch.get_autocast_dtype('cuda')
+        if dt in (torch.float16, torch.bfloat16):
+            return dt
+    if x.dtype in (torch.float16, torch.bfloat16):
+        return x.dtype
+    return _default_compute_dtype
+
+
+class WeightCache:
+    """Half-precision (and transposed) copies of frozen base weights, rebuilt when a weight changes."""
+
+    def __init__(self):
+        self._store = {}
+
+    @staticmethod
+    def _key(tensors):
+        return tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in tensors)
+
+    def weight(self, name, weights, dtype, transposed=False):
+        key = (name, dtype)
+        ver = self._key(weights)
+        ent = self._store.get(key)
+        if ent is None or ent['ver'] != ver:
+            w = [x.detach().reshape(x.shape[0], -1) for x in weights]  # 1x1 conv (N,K,1,1) -> (N,K)
+            W = (w[0] if len(w) == 1 else torch.cat(w, 0)).to(dtype).contiguous()
+            ent = {'ver': ver, 'W': W, 'Wt': None}
+            self._store[key] = ent
+        if transposed:
+            if ent['Wt'] is None:
+                ent['Wt'] = ent['W'].t().contiguous()
+            return ent['W'], ent['Wt']
+        return ent['W'], None
+
+    def bias(self, name, biases):
+        if all(b is None for b in biases):
+            return None
+        key = (name, 'bias')
+        present = [b for b in biases if b is not None]
+        ver = self._key(present)
+        ent = self._store.get(key)
+        if ent is None or ent['ver'] != ver:
+            assert len(present) == len(biases), 'fused sites must all have a bias or none'
+            b = torch.cat([x.detach().float() for x in biases], 0).contiguous()
+            ent = {'ver': ver, 'b': b}
+            self._store[key] = ent
+        return ent['b']
+
+
+class _LoRALinear(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, W16, Wt16, bias32, alphas, *params):
+        cd = W16.dtype
+        K = W16.shape[1]
+        N = W16.shape[0]
+        x2 = x.reshape(-1, K)
+        if x2.dtype != cd:
+            x2 = x2.to(cd)
+        if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
+            x2 = x2.contiguous()
+        n_sites = len(params) // 2
+        if n_sites:
+            downs, ups = params[0::2], params[1::2]
+            A16, A16T, Bp16, BpT = ops.lora_pack(downs, ups, alphas, K, cd, x2.device)
+            t = ops.lora_down(x2, A16)
+            y = ops.linear_fwd(x2, W16, t, Bp16, bias32)
+            ctx.save_for_backward(x2, t, A16T, BpT, Wt16)
+        else:
+            y = ops.linear_fwd(x2, W16, None, None, bias32)
+            ctx.save_for_backward(x2, None, None, None, Wt16)
+        ctx.alphas = alphas
+        ctx.n_sites = n_sites
+        ctx.site_rows = [p.shape[0] for p in params[1::2]]
+        ctx.rank = params[0].shape[0] if n_sites else 0
+        ctx.param_shapes = [p.shape for p in params]
+        ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, t, A16T, BpT, Wt16 = ctx.saved_tensors
+        N = dy.shape[-1]
+        dy2 = dy.reshape(-1, N)
+        if dy2.dtype != x2.dtype:
+            dy2 = dy2.to(x2.dtype)
+        if dy2.stride(1) != 1 or dy2.stride(0) % 8 != 0:
+            dy2 = dy2.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        need_lora = ctx.n_sites > 0 and any(ctx.needs_input_grad[5:])
+        if need_dx and Wt16 is None:
+            raise RuntimeError('mixofshow.hip: backward to the input needs the transposed weight (Wt16)')
+        dx, dA16, dBpT = ops.linear_bwd(dy2, x2, Wt16, t, A16T, BpT, need_dx=need_dx, need_lora=need_lora)
+        grads = []
+        if ctx.n_sites:
+            r = ctx.rank
+            n0 = 0
+            for g in range(ctx.n_sites):
+                n_g = ctx.site_rows[g]
+                if need_lora:
+                    gd = dA16[g * r:(g + 1) * r].reshape(ctx.param_shapes[2 * g])
+                    gu = (dBpT[g * r:(g + 1) * r, n0:n0 + n_g].t() * ctx.alphas[g]).reshape(ctx.param_shapes[2 * g + 1])
+                    grads += [gd, gu.contiguous()]
+                else:
+                    grads += [None, None]
+                n0 += n_g
+        if dx is not None:
+            dx = dx.view(ctx.x_shape)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        return (dx, None, None, None, None, *grads)
+
+
+def lora_linear(x, W16, Wt16, bias32, sites):
+    """sites: list of (lora_down.weight (r,K[,1,1]), lora_up.weight (n,r[,1,1]), alpha float)."""
+    params, alphas = [], []
+    for down, up, alpha in sites:
+        params += [down, up]
+        alphas.append(float(alpha))
+    return _LoRALinear.apply(x, W16, Wt16, bias32, tuple(alphas), *params)
+
+
+class _Attention(torch.autograd.Function):
+    """mode 'qkv': a = (B,N,3C) fused projection; mode 'q_kv': a = q (B,N,C), b = (B,M,2C); mode 'sep': a,b,c."""
+
+    @staticmethod
+    def forward(ctx, mode, heads, scale, tok_idx, a, b, c):
+        if mode == 'qkv':
+            C = a.shape[-1] // 3
+            q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
+        elif mode == 'q_kv':
+            C = a.shape[-1]
+            q, k, v = a, b[..., :C], b[..., C:]
+        else:
+            q, k, v = a, b, c
+        need_grad = any(ctx.needs_input_grad[4:])
+        o, lse, pcols = ops.attn_fwd(q, k, v, heads, scale, tok_idx=tok_idx, need_lse=need_grad)
+        ctx.mode, ctx.heads, ctx.scale = mode, heads, scale
+        ctx.has_pcols = pcols is not None
+        if need_grad:
+            ctx.save_for_backward(a, b, c, o, lse, tok_idx, pcols)
+        if pcols is None:
+            pcols = o.new_zeros((), dtype=torch.float32)
+            ctx.mark_non_differentiable(pcols)
+        return o, pcols
+
+    @staticmethod
+    def backward(ctx, dO, dpcols):
+        a, b, c, o, lse, tok_idx, pcols = ctx.saved_tensors
+        mode = ctx.mode
+        if dO.stride(-1) != 1 or dO.stride(1) % 8 != 0 or dO.dtype != o.dtype:
+            dO = dO.to(o.dtype).contiguous()
+        da = torch.empty_like(a)
+        db = torch.empty_like(b) if b is not None else None
+        dc = torch.empty_like(c) if c is not None else None
+        if mode == 'qkv':
+            C = a.shape[-1] // 3
+            q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
+            dq, dk, dv = da[..., :C], da[..., C:2 * C], da[..., 2 * C:]
+        elif mode == 'q_kv':
+            C = a.shape[-1]
+            q, k, v = a, b[..., :C], b[..., C:]
+            dq, dk, dv = da, db[..., :C], db[..., C:]
+        else:
+            q, k, v = a, b, c
+            dq, dk, dv = da, db, dc
+        if ctx.has_pcols and dpcols is not None:
+            dpc = dpcols.float().contiguous()
+        else:
+            dpc = None
+        ops.attn_bwd(q, k, v, o, lse, dO, ctx.heads, ctx.scale, dq, dk, dv, tok_idx=tok_idx if dpc is not None else None,
+                     pcols=pcols if dpc is not None else None, dpcols=dpc)
+        return None, None, None, None, da, db, dc
+
+
+def _check_half(*ts):
+    for t in ts:
+        if t is not None and t.dtype not in (torch.float16, torch.bfloat16):
+            raise TypeError(f'mixofshow.hip.attention needs float16/bfloat16 activations, got {t.dtype}')
+
+
+def attention_qkv(qkv, heads, scale):
+    _check_half(qkv)
+    return _Attention.apply('qkv', heads, scale, None, qkv, None, None)[0]
+
+
+def attention_q_kv(q, kv, heads, scale, tok_idx=None):
+    """Returns (o, pcols or None)."""
+    _check_half(q, kv)
+    o, pcols = _Attention.apply('q_kv', heads, scale, tok_idx, q, kv, None)
+    return o, (pcols if tok_idx is not None else None)
+
+
+def attention(q, k, v, heads, scale, tok_idx=None):
+    _check_half(q, k, v)
+    o, pcols = _Attention.apply('sep', heads, scale, tok_idx, q, k, v)
+    return o, (pcols if tok_idx is not None else None)

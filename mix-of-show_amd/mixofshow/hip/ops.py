@@ -1,0 +1,247 @@
+"""Primitive kernel-backed ops: torch tensors in, torch tensors out, arithmetic in libmos_hip.so.
+
+Every function requires device (HIP) tensors and raises otherwise — there is no eager fallback.
+Shapes follow the reference's token-major `(B, N, H*d)` activations; see include/mos_hip.h.
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+from .lib import MOS_BF16, MOS_F16, MOS_LORA_PAD, MOS_MAX_PCOLS, MOS_MAX_SOURCES
+
+_DT = {torch.float16: MOS_F16, torch.bfloat16: MOS_BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f'mixofshow.hip: dtype {t.dtype} not supported by the HIP kernels (float16 / bfloat16 only)')
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('mixofshow.hip: kernel-backed ops need tensors on a HIP device (cuda:N); got '
+                               f'{t.device}. There is no CPU fallback in the product path.')
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _rows(t):
+    """2-D view requirements: last dim contiguous, row stride multiple of 8 elements, 16-B aligned base."""
+    assert t.dim() == 2 and t.stride(1) == 1, f'need a row-major 2-D view, got strides {t.stride()}'
+    return t.stride(0)
+
+
+# ------------------------------------------------------------------------------------------------
+# LoRA-augmented linear
+# ------------------------------------------------------------------------------------------------
+def lora_pack(downs, ups, alphas, K, dtype, device):
+    """Pack fp32 master LoRA factors of up to 4 sites sharing one input into MFMA operands.
+
+    downs[g]: (r, K) fp32, ups[g]: (n_g, r) fp32. Returns A16 (16,K), A16T (K,16), Bp16 (N,16), BpT (16,N)."""
+    _dev(*downs, *ups)
+    n_sites = len(downs)
+    r = downs[0].shape[0]
+    assert 1 <= n_sites <= 4 and n_sites * r <= MOS_LORA_PAD, f'{n_sites} sites of rank {r} exceed the packed rank 16'
+    s = _lib.LoraSites()
+    s.n_sites, s.rank, s.K = n_sites, r, K
+    keep = []
+    n0 = 0
+    for g in range(n_sites):
+        d = downs[g].detach().reshape(r, K)
+        u = ups[g].detach().reshape(-1, r)
+        if d.dtype != torch.float32 or not d.is_contiguous():
+            d = d.float().contiguous()
+        if u.dtype != torch.float32 or not u.is_contiguous():
+            u = u.float().contiguous()
+        keep += [d, u]
+        s.down[g] = d.data_ptr()
+        s.up[g] = u.data_ptr()
+        s.alpha[g] = float(alphas[g])
+        s.n_begin[g] = n0
+        s.n_rows[g] = u.shape[0]
+        n0 += u.shape[0]
+    s.N = n0
+    A16 = torch.empty((MOS_LORA_PAD, K), dtype=dtype, device=device)
+    A16T = torch.empty((K, MOS_LORA_PAD), dtype=dtype, device=device)
+    Bp16 = torch.empty((n0, MOS_LORA_PAD), dtype=dtype, device=device)
+    BpT = torch.empty((MOS_LORA_PAD, n0), dtype=dtype, device=device)
+    L = _lib.load()
+    _lib.check(L.mos_lora_pack(ctypes.byref(s), _DT[dtype], _p(A16), _p(A16T), _p(Bp16), _p(BpT), _stream()),
+               'mos_lora_pack')
+    return A16, A16T, Bp16, BpT
+
+
+def lora_down(x, A16):
+    """t[M,16] = x[M,K] . A16^T"""
+    _dev(x, A16)
+    M, K = x.shape
+    t = torch.empty((M, MOS_LORA_PAD), dtype=x.dtype, device=x.device)
+    L = _lib.load()
+    _lib.check(L.mos_lora_down(_p(x), _rows(x), _p(A16), _p(t), M, K, _dt(x), _stream()), 'mos_lora_down')
+    return t
+
+
+def linear_fwd(x, W, t=None, Bp16=None, bias=None, out=None):
+    """y[M,N] = x . W^T (+ t . Bp16^T) (+ bias);  W (N,K) in x.dtype, bias fp32."""
+    _dev(x, W, t, Bp16, bias)
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and W.dtype == x.dtype
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+    y = out if out is not None else torch.empty((M, N), dtype=x.dtype, device=x.device)
+    L = _lib.load()
+    _lib.check(L.mos_lora_linear_fwd(_p(x), _rows(x), _p(W), _rows(W), _p(t), _p(Bp16), _p(bias), _p(y), _rows(y),
+                                     M, N, K, _dt(x), _stream()), 'mos_lora_linear_fwd')
+    return y
+
+
+def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True):
+    """Backward of linear_fwd. Returns (dx | None, dA16 (16,K) fp32 | None, dBpT (16,N) fp32 | None)."""
+    _dev(dy, x, Wt, t, A16T, BpT)
+    M, N = dy.shape
+    lora = BpT is not None
+    K = Wt.shape[0] if Wt is not None else x.shape[1]
+    dev = dy.device
+    dx = torch.empty((M, K), dtype=dy.dtype, device=dev) if need_dx else None
+    dt = torch.empty((M, MOS_LORA_PAD), dtype=dy.dtype, device=dev) if lora else None
+    dA16 = torch.empty((MOS_LORA_PAD, K), dtype=torch.float32, device=dev) if (lora and need_lora) else None
+    dBpT = torch.empty((MOS_LORA_PAD, N), dtype=torch.float32, device=dev) if (lora and need_lora) else None
+    L = _lib.load()
+    ws = None
+    if lora:
+        ws = torch.empty((L.mos_lora_bwd_workspace_bytes(M, N, K) + 3) // 4, dtype=torch.float32, device=dev)
+    _lib.check(L.mos_lora_linear_bwd(_p(dy), _rows(dy), _p(x), _rows(x) if x is not None else 0,
+                                     _p(Wt), _rows(Wt) if Wt is not None else 0, _p(t), _p(A16T), _p(BpT),
+                                     _p(dt), _p(dx), _rows(dx) if dx is not None else 0, _p(dA16), _p(dBpT), _p(ws),
+                                     M, N, K, _dt(dy), _stream()), 'mos_lora_linear_bwd')
+    return dx, dA16, dBpT
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attn_view(t):
+    """(B, N, C) tensor, last dim contiguous; returns (batch_stride, row_stride)."""
+    assert t.dim() == 3 and t.stride(2) == 1, f'need (B, N, C) with contiguous channels, got strides {t.stride()}'
+    return t.stride(0), t.stride(1)
+
+
+def _shape(q, k, v, o, heads, scale):
+    B, Nq, C = q.shape
+    s = _lib.AttnShape()
+    s.B, s.H, s.Nq, s.Nkv, s.d = B, heads, Nq, k.shape[1], C // heads
+    s.q_bs, s.q_rs = _attn_view(q)
+    s.k_bs, s.k_rs = _attn_view(k)
+    s.v_bs, s.v_rs = _attn_view(v)
+    s.o_bs, s.o_rs = _attn_view(o)
+    s.scale = float(scale)
+    return s
+
+
+def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True):
+    """softmax(scale q k^T) v per head. q (B,Nq,C), k/v (B,Nkv,C) views (may be slices of fused buffers).
+
+    Returns (o (B,Nq,C), lse (B,H,Nq) fp32 | None, pcols (B,H,Nq,T) fp32 | None).
+    tok_idx: int32 (B,T) key indices whose softmax probabilities are exported (T <= 4)."""
+    _dev(q, k, v, tok_idx)
+    B, Nq, C = q.shape
+    o = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+    s = _shape(q, k, v, o, heads, scale)
+    lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device) if need_lse else None
+    T = 0
+    pcols = None
+    if tok_idx is not None:
+        assert tok_idx.dtype == torch.int32 and tok_idx.is_contiguous() and tok_idx.shape[0] == B
+        T = tok_idx.shape[1]
+        assert 1 <= T <= MOS_MAX_PCOLS
+        pcols = torch.empty((B, heads, Nq, T), dtype=torch.float32, device=q.device)
+    L = _lib.load()
+    _lib.check(L.mos_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(tok_idx), T, _p(pcols), ctypes.byref(s),
+                              _dt(q), _stream()), 'mos_attn_fwd')
+    return o, lse, pcols
+
+
+def attn_bwd(q, k, v, o, lse, dO, heads, scale, dq, dk, dv, tok_idx=None, pcols=None, dpcols=None):
+    """Backward of attn_fwd; dq/dk/dv are preallocated (B,N,C) views (e.g. slices of one fused buffer)."""
+    _dev(q, k, v, o, lse, dO, dq, dk, dv, tok_idx, pcols, dpcols)
+    s = _shape(q, k, v, o, heads, scale)
+    g = _lib.AttnGradStrides()
+    g.do_bs, g.do_rs = _attn_view(dO)
+    g.dq_bs, g.dq_rs = _attn_view(dq)
+    g.dk_bs, g.dk_rs = _attn_view(dk)
+    g.dv_bs, g.dv_rs = _attn_view(dv)
+    T = tok_idx.shape[1] if tok_idx is not None else 0
+    if dpcols is not None:
+        assert dpcols.dtype == torch.float32 and dpcols.is_contiguous() and pcols is not None
+    L = _lib.load()
+    ws = torch.empty((L.mos_attn_bwd_workspace_bytes(ctypes.byref(s)) + 3) // 4, dtype=torch.float32, device=q.device)
+    _lib.check(L.mos_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(lse), _p(dO), _p(tok_idx), T, _p(pcols), _p(dpcols),
+                              _p(dq), _p(dk), _p(dv), _p(ws), ctypes.byref(s), ctypes.byref(g), _dt(q), _stream()),
+               'mos_attn_bwd')
+    return dq, dk, dv
+
+
+def region_attn_fwd(q, k_src, v_src, heads, scale, boxes, feat_h, feat_w):
+    """Regional mask-and-blend cross attention.
+
+    q (B,Nq,C); k_src/v_src (S,B,Nkv,C) views with contiguous channels, source 0 = context prompt,
+    sources 1.. = regions; boxes: list of (h0, w0, h1, w1) integer feature-cell boxes per region."""
+    _dev(q, k_src, v_src)
+    assert k_src.dim() == 4 and v_src.dim() == 4 and k_src.shape[0] == len(boxes) + 1
+    assert len(boxes) <= MOS_MAX_SOURCES - 1, f'at most {MOS_MAX_SOURCES - 1} regions per launch'
+    assert k_src.stride() == v_src.stride() or True
+    B, Nq, C = q.shape
+    o = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+    s = _shape(q, k_src[0], v_src[0], o, heads, scale)
+    assert k_src.stride(0) == v_src.stride(0), 'k_src and v_src must share the source stride'
+    r = _lib.RegionDesc()
+    r.n_regions, r.feat_h, r.feat_w = len(boxes), int(feat_h), int(feat_w)
+    for i, b in enumerate(boxes):
+        for j in range(4):
+            r.box[i][j] = int(b[j])
+    r.src_stride = k_src.stride(0)
+    L = _lib.load()
+    _lib.check(L.mos_region_cross_attn_fwd(_p(q), _p(k_src), _p(v_src), _p(o), ctypes.byref(s), ctypes.byref(r),
+                                           _dt(q), _stream()), 'mos_region_cross_attn_fwd')
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+# gradient-fusion least squares (Gram form)
+# ------------------------------------------------------------------------------------------------
+def gram_accumulate(X, Y, G, P, c):
+    """G += X^T X ; P += Y^T X ; c += sum(Y^2).  X (n,Cin), Y (n,Cout) half/bf16; G,P,c fp64 on device."""
+    _dev(X, Y, G, P, c)
+    n, Cin = X.shape
+    Cout = Y.shape[1]
+    assert Y.shape[0] == n and G.shape == (Cin, Cin) and P.shape == (Cout, Cin) and c.numel() == 1
+    assert G.dtype == P.dtype == c.dtype == torch.float64 and G.is_contiguous() and P.is_contiguous()
+    L = _lib.load()
+    ws = torch.empty((L.mos_gram_workspace_bytes(n, Cin, Cout) + 3) // 4, dtype=torch.float32, device=X.device)
+    _lib.check(L.mos_gram_accumulate(_p(X), _rows(X), _p(Y), _rows(Y), n, Cin, Cout, _dt(X), _p(G), _p(P), _p(c),
+                                     _p(ws), _stream()), 'mos_gram_accumulate')
+
+
+def lsq_loss_grad(W, G, P, c, n_times_cout):
+    """loss (0-dim fp64) and grad (Cout,Cin fp64) of mean((X W^T - Y)^2) from the Gram statistics."""
+    _dev(W, G, P, c)
+    Cout, Cin = W.shape
+    assert W.dtype == torch.float64 and W.is_contiguous()
+    loss = torch.empty((), dtype=torch.float64, device=W.device)
+    grad = torch.empty_like(W)
+    L = _lib.load()
+    ws = torch.empty((L.mos_lsq_workspace_bytes(Cout, Cin) + 7) // 8, dtype=torch.float64, device=W.device)
+    _lib.check(L.mos_lsq_loss_grad_gram(_p(W), _p(G), _p(P), _p(c), float(n_times_cout), Cout, Cin, _p(loss), _p(grad),
+                                        _p(ws), _stream()), 'mos_lsq_loss_grad_gram')
+    return loss, grad

@@ -1,0 +1,134 @@
+"""ORACLE — test infrastructure. Torch (CPU or GPU) emulation of the kernel-backed primitives of
+mixofshow.hip.ops with the SAME signatures. Two uses, both in tests only:
+  * `emulated_hip` fixture: run the product's host orchestration (autograd Functions, processors, trainer)
+    on CPU and compare it with the oracle restatement of the reference;
+  * GPU parity tests: each HIP primitive against its emulation on the same inputs.
+Emulations compute in fp32 from the (possibly half) inputs and round the result to the output dtype once.
+"""
+import torch
+
+EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
+            'gram_accumulate', 'lsq_loss_grad')
+PAD = 16
+
+
+def lora_pack(downs, ups, alphas, K, dtype, device):
+    r = downs[0].shape[0]
+    N = sum(u.reshape(-1, r).shape[0] for u in ups)
+    A16 = torch.zeros(PAD, K, dtype=torch.float32, device=device)
+    Bp16 = torch.zeros(N, PAD, dtype=torch.float32, device=device)
+    n0 = 0
+    for g, (d, u, a) in enumerate(zip(downs, ups, alphas)):
+        d = d.detach().reshape(r, K).float()
+        u = u.detach().reshape(-1, r).float()
+        A16[g * r:(g + 1) * r] = d
+        Bp16[n0:n0 + u.shape[0], g * r:(g + 1) * r] = a * u
+        n0 += u.shape[0]
+    A16, Bp16 = A16.to(dtype), Bp16.to(dtype)
+    return A16, A16.t().contiguous(), Bp16, Bp16.t().contiguous()
+
+
+def lora_down(x, A16):
+    return (x.float() @ A16.float().t()).to(x.dtype)
+
+
+def linear_fwd(x, W, t=None, Bp16=None, bias=None, out=None):
+    y = x.float() @ W.float().t()
+    if t is not None:
+        y = y + t.float() @ Bp16.float().t()
+    if bias is not None:
+        y = y + bias
+    y = y.to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True):
+    dyf = dy.float()
+    lora = BpT is not None
+    dt = (dyf @ BpT.float().t()).to(dy.dtype) if lora else None
+    dx = None
+    if need_dx:
+        dx = dyf @ Wt.float().t()
+        if lora:
+            dx = dx + dt.float() @ A16T.float().t()
+        dx = dx.to(dy.dtype)
+    dA16 = dBpT = None
+    if lora and need_lora:
+        dA16 = dt.float().t() @ x.float()
+        dBpT = t.float().t() @ dyf
+    return dx, dA16, dBpT
+
+
+def _heads(t, H):
+    B, N, C = t.shape
+    return t.float().reshape(B, N, H, C // H).permute(0, 2, 1, 3)
+
+
+def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True):
+    B, Nq, C = q.shape
+    qh, kh, vh = _heads(q, heads), _heads(k, heads), _heads(v, heads)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.exp(s - lse[..., None])
+    o = (p @ vh).permute(0, 2, 1, 3).reshape(B, Nq, C).to(q.dtype)
+    pcols = None
+    if tok_idx is not None:
+        idx = tok_idx.long()[:, None, None, :].expand(B, heads, Nq, tok_idx.shape[1])
+        pcols = torch.gather(p, 3, idx).contiguous()
+    return o, (lse.contiguous() if need_lse else None), pcols
+
+
+def attn_bwd(q, k, v, o, lse, dO, heads, scale, dq, dk, dv, tok_idx=None, pcols=None, dpcols=None):
+    B, Nq, C = q.shape
+    qh, kh, vh, doh = _heads(q, heads), _heads(k, heads), _heads(v, heads), _heads(dO, heads)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    p = torch.exp(s - lse[..., None])
+    dvh = p.transpose(-1, -2) @ doh
+    dp = doh @ vh.transpose(-1, -2)
+    if dpcols is not None:
+        idx = tok_idx.long()[:, None, None, :].expand(B, heads, Nq, tok_idx.shape[1])
+        dp = dp.scatter_add(3, idx, dpcols.float())
+    ds = p * (dp - (p * dp).sum(-1, keepdim=True))
+    dqh = (ds @ kh) * scale
+    dkh = (ds.transpose(-1, -2) @ qh) * scale
+
+    def back(t):
+        return t.permute(0, 2, 1, 3).reshape(t.shape[0], t.shape[2], -1)
+
+    dq.copy_(back(dqh).to(dq.dtype)); dk.copy_(back(dkh).to(dk.dtype)); dv.copy_(back(dvh).to(dv.dtype))
+    return dq, dk, dv
+
+
+def region_attn_fwd(q, k_src, v_src, heads, scale, boxes, feat_h, feat_w):
+    B, Nq, C = q.shape
+    count = torch.zeros(feat_h, feat_w, device=q.device)
+    for h0, w0, h1, w1 in boxes:
+        count[h0:h1, w0:w1] += 1
+    count = count.reshape(-1)
+    out = torch.zeros(B, Nq, C, dtype=torch.float32, device=q.device)
+    base, _, _ = attn_fwd(q.float(), k_src[0].float(), v_src[0].float(), heads, scale, need_lse=False)
+    out[:, count == 0] = base[:, count == 0]
+    for r, (h0, w0, h1, w1) in enumerate(boxes):
+        inbox = torch.zeros(feat_h, feat_w, dtype=torch.bool, device=q.device)
+        inbox[h0:h1, w0:w1] = True
+        inbox = inbox.reshape(-1)
+        if inbox.any():
+            o_r, _, _ = attn_fwd(q.float(), k_src[r + 1].float(), v_src[r + 1].float(), heads, scale, need_lse=False)
+            out[:, inbox] += o_r[:, inbox] / count[inbox][None, :, None]
+    return out.to(q.dtype)
+
+
+def gram_accumulate(X, Y, G, P, c):
+    Xd, Yd = X.double(), Y.double()
+    G += Xd.t() @ Xd
+    P += Yd.t() @ Xd
+    c += (Yd * Yd).sum()
+
+
+def lsq_loss_grad(W, G, P, c, n_times_cout):
+    R = W @ G - P
+    loss = ((R * W).sum() - (P * W).sum() + c.reshape(())) / n_times_cout
+    return loss, 2.0 * R / n_times_cout

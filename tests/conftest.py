@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mos_path  # noqa: E402,F401  (puts mix-of-show_amd/ on sys.path -> `import mixofshow`)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden', 'reference_golden.pt')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with `-m gpu` on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import torch
+    return torch.load(GOLDEN, weights_only=False)
+
+
+@pytest.fixture()
+def emulated_hip(monkeypatch):
+    """CPU tests of the HOST orchestration: replace the kernel-backed primitives (mixofshow.hip.ops) with the
+    oracle's torch emulation. Test infrastructure only — the product never imports oracle/."""
+    from oracle import emu_ops
+    import mixofshow.hip.ops as ops
+    for name in emu_ops.EMULATED:
+        monkeypatch.setattr(ops, name, getattr(emu_ops, name))
+    monkeypatch.setenv('MOS_TEST_ALLOW_CPU', '1')
+    yield

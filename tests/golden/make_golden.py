@@ -1,0 +1,299 @@
+"""Generate golden vectors by executing the REAL reference code (read-only at /root/reference).
+
+Runs only in the authoring container (the reference does not exist on the GPU box); the outputs are
+committed as small fixtures next to this script and pin oracle/*.py (tests/test_oracle_golden.py).
+
+The reference imports diffusers / omegaconf / torchvision / cv2 / IPython / xformers at module top and
+none of them is installed. Their NAMES are satisfied with empty stub modules (a meta-path finder below);
+no arithmetic comes from a stub. The one third-party object the reference's processors really compute
+with — diffusers' `Attention` — is oracle/attention_shim.py (restated from diffusers 0.19.3, see
+SURVEY.md App. A). Everything else that runs here is the reference's own code:
+  mixofshow/models/edlora.py            LoRALinearLayer, EDLoRA_AttnProcessor, EDLoRA_Control_AttnProcessor
+  mixofshow/utils/ptp_util.py           AttentionStore
+  mixofshow/pipelines/trainer_edlora.py EDLoRATrainer.cal_attn_reg (unbound, fake self)
+  mixofshow/pipelines/pipeline_edlora.py bind_concept_prompt
+  mixofshow/pipelines/pipeline_regionally_t2iadapter.py RegionT2I_AttnProcessor
+  mixofshow/utils/convert_edlora_to_diffusers.py merge_lora_into_weight
+  gradient_fusion.py                    chunk_compute_mse, update_quasi_newton, merge_lora_into_weight
+  regionally_controlable_sampling.py    prepare_text
+
+Usage:  python tests/golden/make_golden.py
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.normpath(os.path.join(HERE, '..', '..'))
+REF = '/root/reference'
+STUB_ROOTS = ('diffusers', 'omegaconf', 'torchvision', 'cv2', 'IPython', 'xformers')
+
+
+class _Anything:
+    """Placeholder class for names imported from stubbed modules (never called for arithmetic)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        return _Anything()
+
+
+class _StubMeta(type):
+    """Class attributes of stubbed names (e.g. `diffusers.utils.logging.get_logger`) resolve to no-op callables."""
+
+    def __getattr__(cls, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return _Anything()
+
+
+class _StubModule(types.ModuleType):
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        if name == 'is_xformers_available':
+            return lambda: False
+        if name == 'check_min_version':
+            return lambda *_a, **_k: None
+        cls = _StubMeta(name, (_Anything,), {})
+        setattr(self, name, cls)
+        return cls
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split('.')[0] in STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _StubModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def _import_reference():
+    # resolve the transformers / accelerate names the reference imports BEFORE the stub finder exists: their
+    # lazy importers probe find_spec('torchvision') and would otherwise mistake the stub for the real thing
+    import accelerate  # noqa: F401
+    import accelerate.logging  # noqa: F401
+    import accelerate.utils  # noqa: F401
+    import transformers
+    from transformers import CLIPTextModel, CLIPTokenizer  # noqa: F401
+    sys.meta_path.insert(0, _StubFinder())
+    np.Inf = np.inf  # gradient_fusion.py:59 uses np.Inf (removed in numpy 2)
+    # only the NAME is needed (type annotation in RegionallyT2IAdapterPipeline.__init__); transformers 5 dropped it
+    sys.path.insert(0, REF)
+    sys.path.insert(0, REPO)
+    import gradient_fusion as ref_fusion
+    # (the transformers module object in sys.modules is swapped during the imports above, so patch it late)
+    sys.modules['transformers'].__dict__['CLIPFeatureExtractor'] = type('CLIPFeatureExtractor', (), {})
+    import regionally_controlable_sampling as ref_region_cli
+    from mixofshow.models import edlora as ref_edlora
+    from mixofshow.pipelines import pipeline_edlora as ref_pipe
+    from mixofshow.pipelines import pipeline_regionally_t2iadapter as ref_region
+    from mixofshow.pipelines import trainer_edlora as ref_trainer
+    from mixofshow.utils import convert_edlora_to_diffusers as ref_convert
+    from mixofshow.utils import ptp_util as ref_ptp
+    assert ref_edlora.__file__.startswith(REF), ref_edlora.__file__
+    return dict(fusion=ref_fusion, region_cli=ref_region_cli, edlora=ref_edlora, pipe=ref_pipe, region=ref_region,
+                trainer=ref_trainer, convert=ref_convert, ptp=ref_ptp)
+
+
+def _seeded_attention(shim_cls, C, cross, heads, seed):
+    torch.manual_seed(seed)
+    attn = shim_cls(C, cross_attention_dim=cross, heads=heads, dim_head=C // heads)
+    with torch.no_grad():
+        for p in attn.parameters():
+            p.copy_(torch.randn_like(p) * (0.5 / p.shape[-1]**0.5 if p.dim() > 1 else 0.02))
+    return attn
+
+
+def _attach_lora(ref_edlora, attn, rank, alpha, seed):
+    torch.manual_seed(seed)
+    loras = {}
+    for name, lin in (('to_q', attn.to_q), ('to_k', attn.to_k), ('to_v', attn.to_v), ('to_out.0', attn.to_out[0])):
+        l = ref_edlora.LoRALinearLayer(name, lin, rank=rank, alpha=alpha)
+        with torch.no_grad():
+            l.lora_up.weight.copy_(torch.randn_like(l.lora_up.weight) * 0.05)  # non-zero: zero would hide the branch
+        loras[name] = l
+    return loras
+
+
+def main():
+    ref = _import_reference()
+    from oracle.attention_shim import Attention as Shim
+    out = {}
+    torch.set_grad_enabled(True)
+
+    # ---- G1: LoRALinearLayer on Linear and on 1x1 Conv ----------------------------------------
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(48, 24, bias=True)
+    l1 = ref['edlora'].LoRALinearLayer('lin', lin, rank=4, alpha=0.7)
+    with torch.no_grad():
+        l1.lora_up.weight.copy_(torch.randn_like(l1.lora_up.weight) * 0.1)
+    x = torch.randn(3, 5, 48)
+    conv = torch.nn.Conv2d(16, 8, 1)
+    l2 = ref['edlora'].LoRALinearLayer('conv', conv, rank=4, alpha=1.0)
+    with torch.no_grad():
+        l2.lora_up.weight.copy_(torch.randn_like(l2.lora_up.weight) * 0.1)
+    xc = torch.randn(2, 16, 6, 6)
+    out['lora'] = dict(
+        lin_w=lin.weight.detach(), lin_b=lin.bias.detach(), lin_down=l1.lora_down.weight.detach(),
+        lin_up=l1.lora_up.weight.detach(), lin_alpha=0.7, x=x, y=lin(x).detach(),
+        conv_w=conv.weight.detach(), conv_b=conv.bias.detach(), conv_down=l2.lora_down.weight.detach(),
+        conv_up=l2.lora_up.weight.detach(), xc=xc, yc=conv(xc).detach(),
+        default_up_is_zero=bool((ref['edlora'].LoRALinearLayer('z', torch.nn.Linear(8, 8)).lora_up.weight == 0).all()))
+
+    # ---- G2: EDLoRA_AttnProcessor (cross with layer-wise states, and self) -----------------------------
+    C, H, N, B = 64, 8, 64, 2  # golden vectors pin the CPU oracle; real SD shapes are covered oracle-vs-HIP
+    attn = _seeded_attention(Shim, C, 64, H, seed=2)
+    loras = _attach_lora(ref['edlora'], attn, 4, 1.0, seed=3)
+    torch.manual_seed(4)
+    hs = torch.randn(B, N, C)
+    ehs = torch.randn(B, 6, 77, 64)  # 6 layers x 64-dim text states keep the fixture small
+    proc = ref['edlora'].EDLoRA_AttnProcessor(5)
+    y_cross = proc(attn, hs, encoder_hidden_states=ehs)
+    attn_self = _seeded_attention(Shim, C, None, H, seed=5)
+    y_self = ref['edlora'].EDLoRA_AttnProcessor(0)(attn_self, hs)
+    out['edlora_attn'] = dict(
+        state={k: v.detach() for k, v in attn.state_dict().items()},
+        lora={k: dict(down=l.lora_down.weight.detach(), up=l.lora_up.weight.detach()) for k, l in loras.items()},
+        self_state={k: v.detach() for k, v in attn_self.state_dict().items()},
+        hs=hs, ehs=ehs, idx=5, y_cross=y_cross.detach(), y_self=y_self.detach())
+
+    # ---- G3: control processor + AttentionStore(training) + cal_attn_reg, with gradients -----------------
+    torch.manual_seed(6)
+    store = ref['ptp'].AttentionStore(training=True)
+    store.num_att_layers = 4
+    res_list = (64, 32, 16, 8)
+    attns, places, hss = [], ('down', 'down', 'mid', 'up'), []
+    ehs3 = torch.randn(B, 4, 77, 32)
+    outs3 = []
+    for i, res in enumerate(res_list):
+        Cc = 8  # tiny width keeps the fixture small; heads=2 -> d=4 (oracle-only case)
+        a = _seeded_attention(Shim, Cc, 32, 2, seed=10 + i)
+        attns.append(a)
+        h = torch.randn(B, res * res, Cc).requires_grad_(True)
+        hss.append(h)
+        p = ref['edlora'].EDLoRA_Control_AttnProcessor(i, places[i], store)
+        outs3.append(p(a, h, encoder_hidden_states=ehs3))
+    masks = torch.zeros(B, 1, 64, 64)
+    masks[:, :, 16:48, 20:44] = 1
+    ids = torch.full((B * 16, 77), 49407, dtype=torch.long)
+    ids[:, 0] = 49406
+    concept_ids = list(range(49408, 49408 + 32))
+    for b in range(B):
+        for layer in range(16):
+            ids[b * 16 + layer, 1:4] = torch.tensor([320, 1125, 539])
+            ids[b * 16 + layer, 4 + b] = 49408 + layer       # adjective token (position differs per sample)
+            ids[b * 16 + layer, 5 + b] = 49424 + layer       # subject token
+    fake_self = types.SimpleNamespace(attn_reg_weight=0.01, reg_full_identity=False,
+                                      get_all_concept_token_ids=lambda: concept_ids)
+    maps = store.get_average_attention()
+    reg_false = ref['trainer'].EDLoRATrainer.cal_attn_reg(fake_self, maps, masks, ids)
+    fake_self.reg_full_identity = True
+    reg_true = ref['trainer'].EDLoRATrainer.cal_attn_reg(fake_self, maps, masks, ids)
+    total = reg_false + sum(o.square().mean() for o in outs3)
+    grads = torch.autograd.grad(total, hss)
+    out['control'] = dict(
+        states=[{k: v.detach() for k, v in a.state_dict().items()} for a in attns], places=places,
+        hs=[h.detach() for h in hss], ehs=ehs3, masks=masks, ids=ids, concept_ids=concept_ids,
+        outs=[o.detach() for o in outs3], reg_false=reg_false.detach(), reg_true=reg_true.detach(),
+        grads=[g.detach() for g in grads],
+        n_stored={k: len(v) for k, v in maps.items()})
+
+    # ---- G4: RegionT2I_AttnProcessor --------------------------------------------------------------
+    torch.manual_seed(7)
+    attn_r = _seeded_attention(Shim, C, 64, H, seed=8)
+    fh, fw = 8, 12
+    hs_r = torch.randn(2, fh * fw, C)
+    ctx = torch.randn(2, 4, 77, 64)
+    height, width = 512, 768
+    px_boxes = [[2, 2, 512, 184], [7, 184, 512, 345], [1, 488, 512, 747], [100, 150, 400, 300]]  # last overlaps 1 & 2
+    region_list = []
+    for bx in px_boxes:
+        frac = [bx[0] / height, bx[1] / width, bx[2] / height, bx[3] / width]
+        region_list.append((torch.randn(2, 4, 77, 64), frac))
+    procr = ref['region'].RegionT2I_AttnProcessor(3)
+    kw = dict(region_list=region_list, height=height, width=width)
+    y_reg = procr(attn_r, hs_r, encoder_hidden_states=ctx, **kw)
+    y_reg_none = procr(attn_r, hs_r, encoder_hidden_states=ctx, region_list=[], height=height, width=width)
+    attn_rs = _seeded_attention(Shim, C, None, H, seed=9)
+    y_reg_self = procr(attn_rs, hs_r, **kw)
+    out['region'] = dict(
+        state={k: v.detach() for k, v in attn_r.state_dict().items()},
+        self_state={k: v.detach() for k, v in attn_rs.state_dict().items()},
+        hs=hs_r, ctx=ctx, regions=[(r[0], r[1]) for r in region_list], height=height, width=width, idx=3,
+        fh=fh, fw=fw, y=y_reg.detach(), y_none=y_reg_none.detach(), y_self=y_reg_self.detach())
+    prompt_rewrite = ('[a <potter1> <potter2>, in Hogwarts uniform]-*-[lowres]-*-[4, 6, 1024, 490]|'
+                      '[a <hermione1> <hermione2>, girl]-*-[bad hands]-*-[14, 490, 1024, 920]|[x]-*-[]-*-[]')
+    out['prepare_text'] = dict(arg=prompt_rewrite, height=1024, width=2048,
+                               result=ref['region_cli'].prepare_text('three people', prompt_rewrite, 1024, 2048))
+
+    # ---- G5: update_quasi_newton ---------------------------------------------------------------------
+    cases = {}
+    for name, (n, cin, cout, iters, seed) in dict(under=(12, 48, 24, 60, 20), over=(300, 32, 16, 40, 21),
+                                                  spatial=(6000, 24, 24, 15, 22)).items():
+        torch.manual_seed(seed)
+        X = torch.randn(n, cin)
+        W0 = torch.randn(cout, cin) * 0.1
+        Wt = W0 + torch.randn(cout, cin) * 0.02
+        Y = X @ Wt.T + 0.01 * torch.randn(n, cout)
+        Wn = ref['fusion'].update_quasi_newton(X, Y, W0.clone(), iters, 'cpu')
+        cases[name] = dict(X=X, Y=Y, W0=W0, iters=iters, W=Wn.detach(),
+                           loss0=ref['fusion'].chunk_compute_mse(X, Y, W0, 'cpu').item(),
+                           loss=ref['fusion'].chunk_compute_mse(X, Y, Wn, 'cpu').item())
+    torch.manual_seed(23)
+    X4 = torch.randn(4, 16, 6, 6)
+    W40 = torch.randn(8, 16, 1, 1) * 0.1
+    Y4 = torch.nn.functional.conv2d(X4, W40 + 0.02 * torch.randn_like(W40))
+    W4 = ref['fusion'].update_quasi_newton(X4, Y4, W40.clone(), 30, 'cpu')
+    cases['conv'] = dict(X=X4, Y=Y4, W0=W40, iters=30, W=W4.detach())
+    out['lbfgs'] = cases
+
+    # ---- G6: small host-side pieces ---------------------------------------------------------------------
+    cfg = {'<potter1>': {'concept_token_names': [f'<new{i}>' for i in range(16)]},
+           '<potter2>': {'concept_token_names': [f'<new{16 + i}>' for i in range(16)]}}
+    prompts = ['a <potter1> <potter2> in the park', 'photo of a cat']
+    out['bind'] = dict(cfg=cfg, prompts=prompts, result=ref['pipe'].bind_concept_prompt(prompts, cfg))
+    torch.manual_seed(30)
+    sd = {'blk.attn1.to_q.weight': torch.randn(8, 8), 'blk.attn2.to_out.0.weight': torch.randn(8, 8),
+          'blk.proj_in.weight': torch.randn(8, 8, 1, 1), 'blk.norm.weight': torch.randn(8)}
+    lora_sd = {}
+    for k in ('blk.attn1.to_q', 'blk.attn2.to_out.0'):
+        lora_sd[k + '.lora_down.weight'] = torch.randn(4, 8)
+        lora_sd[k + '.lora_up.weight'] = torch.randn(8, 4)
+    lora_sd['blk.proj_in.lora_down.weight'] = torch.randn(4, 8, 1, 1)
+    lora_sd['blk.proj_in.lora_up.weight'] = torch.randn(8, 4, 1, 1)
+    merged = ref['convert'].merge_lora_into_weight(sd, lora_sd, model_type='unet', alpha=0.6)
+    te_sd = {'text_model.encoder.layers.0.self_attn.q_proj.weight': torch.randn(8, 8),
+             'text_model.encoder.layers.0.mlp.fc1.weight': torch.randn(16, 8)}
+    te_lora = {'text_model.encoder.layers.0.self_attn.q_proj.lora_down.weight': torch.randn(4, 8),
+               'text_model.encoder.layers.0.self_attn.q_proj.lora_up.weight': torch.randn(8, 4)}
+    merged_te = ref['fusion'].merge_lora_into_weight(te_sd, te_lora, list(te_sd.keys()), model_type='text_encoder',
+                                                     alpha=0.8, device='cpu')
+    out['merge'] = dict(sd=sd, lora=lora_sd, alpha=0.6, merged=merged, te_sd=te_sd, te_lora=te_lora, te_alpha=0.8,
+                        merged_te=merged_te)
+
+    path = os.path.join(HERE, 'reference_golden.pt')
+    torch.save(out, path)
+    print(f'wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
+
+
+if __name__ == '__main__':
+    main()
