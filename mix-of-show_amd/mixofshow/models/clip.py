@@ -1,0 +1,139 @@
+"""CLIP ViT-L/14 text encoder (the SD-1.5 text tower) with the module tree and state-dict keys of the
+transformers version the reference was written against (`text_model.encoder.layers.N.self_attn.q_proj`,
+...): ED-LoRA checkpoints name their text-encoder LoRA weights by `named_modules()` path
+(reference trainer_edlora.py:106-112), and the `where:` option matches the class names
+`CLIPAttention` / `CLIPEncoderLayer`. transformers 5.x renamed those paths, so the tower is restated here.
+The 77-token causal self-attention is plumbing (torch SDPA); the q/k/v/out_proj Linear layers are LoRA sites
+and run through the HIP LoRA-linear kernel once wrapped by LoRALinearLayer.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class CLIPTextEmbeddings(nn.Module):
+
+    def __init__(self, vocab_size, hidden, max_pos):
+        super().__init__()
+        self.token_embedding = nn.Embedding(vocab_size, hidden)
+        self.position_embedding = nn.Embedding(max_pos, hidden)
+        self.register_buffer('position_ids', torch.arange(max_pos).unsqueeze(0), persistent=False)
+
+    def forward(self, input_ids):
+        return self.token_embedding(input_ids) + self.position_embedding(self.position_ids[:, :input_ids.shape[1]])
+
+
+class CLIPAttention(nn.Module):
+
+    def __init__(self, hidden, heads):
+        super().__init__()
+        self.num_heads, self.head_dim = heads, hidden // heads
+        self.k_proj = nn.Linear(hidden, hidden)
+        self.v_proj = nn.Linear(hidden, hidden)
+        self.q_proj = nn.Linear(hidden, hidden)
+        self.out_proj = nn.Linear(hidden, hidden)
+
+    def forward(self, x):
+        b, s, c = x.shape
+        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        shape = (b, s, self.num_heads, self.head_dim)
+        q, k, v = (t.view(shape).transpose(1, 2) for t in (q, k, v))
+        o = F.scaled_dot_product_attention(q, k, v, is_causal=True)
+        return self.out_proj(o.transpose(1, 2).reshape(b, s, c))
+
+
+class CLIPMLP(nn.Module):
+
+    def __init__(self, hidden, inter):
+        super().__init__()
+        self.fc1 = nn.Linear(hidden, inter)
+        self.fc2 = nn.Linear(inter, hidden)
+
+    def forward(self, x):
+        x = self.fc1(x)
+        return self.fc2(x * torch.sigmoid(1.702 * x))  # quick_gelu
+
+
+class CLIPEncoderLayer(nn.Module):
+
+    def __init__(self, hidden, heads, inter):
+        super().__init__()
+        self.self_attn = CLIPAttention(hidden, heads)
+        self.layer_norm1 = nn.LayerNorm(hidden)
+        self.mlp = CLIPMLP(hidden, inter)
+        self.layer_norm2 = nn.LayerNorm(hidden)
+
+    def forward(self, x):
+        x = x + self.self_attn(self.layer_norm1(x))
+        return x + self.mlp(self.layer_norm2(x))
+
+
+class CLIPEncoder(nn.Module):
+
+    def __init__(self, hidden, heads, inter, layers):
+        super().__init__()
+        self.layers = nn.ModuleList([CLIPEncoderLayer(hidden, heads, inter) for _ in range(layers)])
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+class CLIPTextTransformer(nn.Module):
+
+    def __init__(self, vocab_size, hidden, heads, inter, layers, max_pos):
+        super().__init__()
+        self.embeddings = CLIPTextEmbeddings(vocab_size, hidden, max_pos)
+        self.encoder = CLIPEncoder(hidden, heads, inter, layers)
+        self.final_layer_norm = nn.LayerNorm(hidden)
+
+    def forward(self, input_ids):
+        return self.final_layer_norm(self.encoder(self.embeddings(input_ids)))
+
+
+SD15_CLIP_CONFIG = dict(vocab_size=49408, hidden_size=768, num_attention_heads=12, intermediate_size=3072,
+                        num_hidden_layers=12, max_position_embeddings=77)
+
+
+class CLIPTextModel(nn.Module):
+
+    def __init__(self, vocab_size=49408, hidden_size=768, num_attention_heads=12, intermediate_size=3072,
+                 num_hidden_layers=12, max_position_embeddings=77):
+        super().__init__()
+        self.config = SimpleNamespace(vocab_size=vocab_size, hidden_size=hidden_size,
+                                      num_attention_heads=num_attention_heads, intermediate_size=intermediate_size,
+                                      num_hidden_layers=num_hidden_layers,
+                                      max_position_embeddings=max_position_embeddings)
+        self.text_model = CLIPTextTransformer(vocab_size, hidden_size, num_attention_heads, intermediate_size,
+                                              num_hidden_layers, max_position_embeddings)
+
+    @property
+    def dtype(self):
+        return self.text_model.final_layer_norm.weight.dtype
+
+    @property
+    def device(self):
+        return self.text_model.final_layer_norm.weight.device
+
+    def get_input_embeddings(self):
+        return self.text_model.embeddings.token_embedding
+
+    def resize_token_embeddings(self, new_num_tokens):
+        old = self.text_model.embeddings.token_embedding
+        if new_num_tokens == old.num_embeddings:
+            return old
+        new = nn.Embedding(new_num_tokens, old.embedding_dim, device=old.weight.device, dtype=old.weight.dtype)
+        new.weight.requires_grad_(old.weight.requires_grad)
+        n = min(old.num_embeddings, new_num_tokens)
+        with torch.no_grad():
+            new.weight[:n] = old.weight[:n]
+        self.text_model.embeddings.token_embedding = new
+        self.config.vocab_size = new_num_tokens
+        return new
+
+    def forward(self, input_ids, attention_mask=None):
+        assert attention_mask is None
+        return (self.text_model(input_ids), )

@@ -1,0 +1,362 @@
+"""SD-1.5 UNet2DConditionModel — the caller of every attention processor on the hot path.
+
+diffusers is not available; this is a from-scratch implementation of the SD-1.5 configuration of
+`UNet2DConditionModel` (block_out_channels (320, 640, 1280, 1280), 2 layers per block, 8 heads,
+cross_attention_dim 768) whose module tree and state-dict keys match diffusers so real
+SD-1.5 / ChilloutMix weights load unchanged and the reference's name-based logic keeps working
+(`named_modules()` paths used as LoRA checkpoint keys, trainer_edlora.py:106-133; class names `Attention`,
+`Transformer2DModel`; `down_blocks` / `mid_block` / `up_blocks` traversal order, edlora.py:186-189).
+
+Non-attention operators (3x3 convs, GroupNorm, SiLU, GEGLU feed-forward) are plumbing and run on
+PyTorch-ROCm (MIOpen / hipBLASLt); every `Attention` goes through its processor -> HIP kernels.
+`cross_attention_kwargs` reach BOTH attn1 and attn2 of each block, and `down_block_additional_residuals`
+(T2I-Adapter features) are consumed in the diffusers 0.19 order (pipeline_regionally_t2iadapter.py:556-566).
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mixofshow.models.attention import Attention
+
+
+def get_timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift=0.0, max_period=10000):
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
+    exponent = exponent / (half - downscale_freq_shift)
+    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+class TimestepEmbedding(nn.Module):
+
+    def __init__(self, in_channels, time_embed_dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample):
+        return self.linear_2(self.act(self.linear_1(sample)))
+
+
+class ResnetBlock2D(nn.Module):
+
+    def __init__(self, in_channels, out_channels, temb_channels=1280, groups=32, eps=1e-5):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels is not None else None
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps)
+        self.dropout = nn.Dropout(0.0)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        self.nonlinearity = nn.SiLU()
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+
+    def forward(self, x, temb=None):
+        h = self.conv1(self.nonlinearity(self.norm1(x)))
+        if self.time_emb_proj is not None and temb is not None:
+            h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
+        h = self.conv2(self.dropout(self.nonlinearity(self.norm2(h))))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Downsample2D(nn.Module):
+
+    def __init__(self, channels, padding=1):
+        super().__init__()
+        self.padding = padding
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=padding)
+
+    def forward(self, x):
+        if self.padding == 0:  # VAE encoder: asymmetric pad
+            x = F.pad(x, (0, 1, 0, 1))
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))
+
+
+class GEGLU(nn.Module):
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        x, gate = self.proj(x).chunk(2, dim=-1)
+        return x * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
+
+    def forward(self, x):
+        for m in self.net:
+            x = m(x)
+        return x
+
+
+class BasicTransformerBlock(nn.Module):
+
+    def __init__(self, dim, heads, dim_head, cross_attention_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(query_dim=dim, heads=heads, dim_head=dim_head)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(query_dim=dim, cross_attention_dim=cross_attention_dim, heads=heads, dim_head=dim_head)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, encoder_hidden_states=None, cross_attention_kwargs=None):
+        cak = cross_attention_kwargs if cross_attention_kwargs is not None else {}
+        x = self.attn1(self.norm1(x), encoder_hidden_states=None, **cak) + x
+        x = self.attn2(self.norm2(x), encoder_hidden_states=encoder_hidden_states, **cak) + x
+        return self.ff(self.norm3(x)) + x
+
+
+class Transformer2DModel(nn.Module):
+
+    def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups=32):
+        super().__init__()
+        inner = heads * dim_head
+        self.norm = nn.GroupNorm(groups, in_channels, eps=1e-6)
+        self.proj_in = nn.Conv2d(in_channels, inner, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
+        self.proj_out = nn.Conv2d(inner, in_channels, 1)
+
+    def forward(self, x, encoder_hidden_states=None, cross_attention_kwargs=None):
+        b, c, h, w = x.shape
+        residual = x
+        x = self.proj_in(self.norm(x))
+        x = x.permute(0, 2, 3, 1).reshape(b, h * w, -1)
+        for blk in self.transformer_blocks:
+            x = blk(x, encoder_hidden_states=encoder_hidden_states, cross_attention_kwargs=cross_attention_kwargs)
+        x = x.reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous()
+        return self.proj_out(x) + residual
+
+
+class CrossAttnDownBlock2D(nn.Module):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, out_channels, temb, heads, cross_dim, add_downsample, layers=2):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb) for i in range(layers)])
+        self.attentions = nn.ModuleList(
+            [Transformer2DModel(heads, out_channels // heads, out_channels, cross_dim) for _ in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def forward(self, x, temb, encoder_hidden_states=None, cross_attention_kwargs=None, additional_residuals=None):
+        outs = ()
+        n = len(self.resnets)
+        for i, (res, att) in enumerate(zip(self.resnets, self.attentions)):
+            x = att(res(x, temb), encoder_hidden_states, cross_attention_kwargs)
+            if i == n - 1 and additional_residuals is not None:
+                x = x + additional_residuals
+            outs += (x, )
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            outs += (x, )
+        return x, outs
+
+
+class DownBlock2D(nn.Module):
+    has_cross_attention = False
+
+    def __init__(self, in_channels, out_channels, temb, add_downsample, layers=2):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb) for i in range(layers)])
+        self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
+
+    def forward(self, x, temb):
+        outs = ()
+        for res in self.resnets:
+            x = res(x, temb)
+            outs += (x, )
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+            outs += (x, )
+        return x, outs
+
+
+class UNetMidBlock2DCrossAttn(nn.Module):
+
+    def __init__(self, channels, temb, heads, cross_dim):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(channels, channels, temb), ResnetBlock2D(channels, channels, temb)])
+        self.attentions = nn.ModuleList([Transformer2DModel(heads, channels // heads, channels, cross_dim)])
+
+    def forward(self, x, temb, encoder_hidden_states=None, cross_attention_kwargs=None):
+        x = self.resnets[0](x, temb)
+        x = self.attentions[0](x, encoder_hidden_states, cross_attention_kwargs)
+        return self.resnets[1](x, temb)
+
+
+class _UpBase(nn.Module):
+
+    def _resnets(self, in_channels, prev_channels, out_channels, temb, layers):
+        blocks = []
+        for i in range(layers):
+            skip = in_channels if i == layers - 1 else out_channels
+            rin = prev_channels if i == 0 else out_channels
+            blocks.append(ResnetBlock2D(rin + skip, out_channels, temb))
+        return nn.ModuleList(blocks)
+
+
+class UpBlock2D(_UpBase):
+    has_cross_attention = False
+
+    def __init__(self, in_channels, prev_channels, out_channels, temb, add_upsample, layers=3):
+        super().__init__()
+        self.resnets = self._resnets(in_channels, prev_channels, out_channels, temb, layers)
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+    def forward(self, x, res_tuple, temb):
+        for res in self.resnets:
+            x = res(torch.cat([x, res_tuple[-1]], dim=1), temb)
+            res_tuple = res_tuple[:-1]
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class CrossAttnUpBlock2D(_UpBase):
+    has_cross_attention = True
+
+    def __init__(self, in_channels, prev_channels, out_channels, temb, heads, cross_dim, add_upsample, layers=3):
+        super().__init__()
+        self.resnets = self._resnets(in_channels, prev_channels, out_channels, temb, layers)
+        self.attentions = nn.ModuleList(
+            [Transformer2DModel(heads, out_channels // heads, out_channels, cross_dim) for _ in range(layers)])
+        self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
+
+    def forward(self, x, res_tuple, temb, encoder_hidden_states=None, cross_attention_kwargs=None):
+        for res, att in zip(self.resnets, self.attentions):
+            x = res(torch.cat([x, res_tuple[-1]], dim=1), temb)
+            res_tuple = res_tuple[:-1]
+            x = att(x, encoder_hidden_states, cross_attention_kwargs)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class UNetOutput(SimpleNamespace):
+    pass
+
+
+SD15_UNET_CONFIG = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                        layers_per_block=2, attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32)
+
+
+class UNet2DConditionModel(nn.Module):
+
+    def __init__(self, sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                 layers_per_block=2, attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32):
+        super().__init__()
+        self.config = SimpleNamespace(sample_size=sample_size, in_channels=in_channels, out_channels=out_channels,
+                                      block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+                                      attention_head_dim=attention_head_dim, cross_attention_dim=cross_attention_dim,
+                                      norm_num_groups=norm_num_groups)
+        self.in_channels = in_channels
+        heads = attention_head_dim  # SD-1.5 quirk: `attention_head_dim` is the NUMBER of heads
+        ch = list(block_out_channels)
+        temb = ch[0] * 4
+        self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        self.time_embedding = TimestepEmbedding(ch[0], temb)
+        self._time_dim = ch[0]
+        n = len(ch)
+        downs = []
+        out_c = ch[0]
+        for i in range(n):
+            in_c, out_c = out_c, ch[i]
+            last = i == n - 1
+            if not last:
+                downs.append(CrossAttnDownBlock2D(in_c, out_c, temb, heads, cross_attention_dim, True, layers_per_block))
+            else:
+                downs.append(DownBlock2D(in_c, out_c, temb, False, layers_per_block))
+        self.down_blocks = nn.ModuleList(downs)
+        self.mid_block = UNetMidBlock2DCrossAttn(ch[-1], temb, heads, cross_attention_dim)
+        rev = ch[::-1]
+        ups = []
+        out_c = rev[0]
+        for i in range(n):
+            prev_c, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, n - 1)]
+            last = i == n - 1
+            if i == 0:
+                ups.append(UpBlock2D(in_c, prev_c, out_c, temb, not last, layers_per_block + 1))
+            else:
+                ups.append(CrossAttnUpBlock2D(in_c, prev_c, out_c, temb, heads, cross_attention_dim, not last,
+                                              layers_per_block + 1))
+        self.up_blocks = nn.ModuleList(ups)
+        self.conv_norm_out = nn.GroupNorm(norm_num_groups, ch[0], eps=1e-5)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
+        self.gradient_checkpointing = False
+
+    def enable_gradient_checkpointing(self):
+        self.gradient_checkpointing = True
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    def forward(self, sample, timestep, encoder_hidden_states, cross_attention_kwargs=None,
+                down_block_additional_residuals=None, return_dict=True):
+        if not torch.is_tensor(timestep):
+            timestep = torch.tensor([timestep], dtype=torch.long, device=sample.device)
+        elif timestep.dim() == 0:
+            timestep = timestep[None].to(sample.device)
+        timestep = timestep.expand(sample.shape[0])
+        t_emb = get_timestep_embedding(timestep, self._time_dim).to(dtype=sample.dtype)
+        emb = self.time_embedding(t_emb)
+
+        sample = self.conv_in(sample)
+        res = (sample, )
+        is_adapter = down_block_additional_residuals is not None
+        for blk in self.down_blocks:
+            if blk.has_cross_attention:
+                extra = None
+                if is_adapter and len(down_block_additional_residuals) > 0:
+                    extra = down_block_additional_residuals.pop(0)
+                sample, outs = self._run(blk, sample, emb, encoder_hidden_states, cross_attention_kwargs, extra)
+            else:
+                sample, outs = blk(sample, emb)
+                if is_adapter and len(down_block_additional_residuals) > 0:
+                    sample += down_block_additional_residuals.pop(0)  # in place, as diffusers 0.19 (also hits the skip)
+            res += outs
+        sample = self.mid_block(sample, emb, encoder_hidden_states, cross_attention_kwargs)
+        for blk in self.up_blocks:
+            k = len(blk.resnets)
+            take, res = res[-k:], res[:-k]
+            if blk.has_cross_attention:
+                sample = blk(sample, take, emb, encoder_hidden_states, cross_attention_kwargs)
+            else:
+                sample = blk(sample, take, emb)
+        sample = self.conv_out(self.conv_act(self.conv_norm_out(sample)))
+        return UNetOutput(sample=sample) if return_dict else (sample, )
+
+    def _run(self, blk, sample, emb, ehs, cak, extra):
+        if self.gradient_checkpointing and self.training and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(blk, sample, emb, ehs, cak, extra, use_reentrant=False)
+        return blk(sample, emb, ehs, cak, extra)

@@ -1,0 +1,298 @@
+"""EDLoRATrainer — same constructor kwargs, methods and checkpoint format as the reference's
+mixofshow/pipelines/trainer_edlora.py (:20-380), running the attention path on the HIP kernels.
+
+What is done differently (results equivalent):
+  * concept embeddings: the reference marks the WHOLE (49408+16k) x 768 token table trainable, lets AdamW and
+    DDP touch all 38 M entries and then overwrites every non-concept row with its original value after each
+    step (train_edlora.py:123-136). Here the 16k concept rows are one small parameter (`concept_embedding`)
+    substituted into the embedding lookup; AdamW is element-wise, so the updates of those rows are identical,
+    and data-parallel training all-reduces 24.6 k floats instead of 152 MB.
+  * attention regulariser: the controller receives the probabilities of the concept-token columns only
+    ((B,H,N,T) per layer, produced inside the cross-attention kernel) instead of sixteen (B*H,N,77) maps;
+    boolean-mask means are written as masked sums (no device->host sync); the NaN guard of :257 is a `where`.
+  * `forward` accepts optional pre-drawn `noise` / `timesteps` / `latents` so that parity tests and multi-rank
+    runs can use device-independent (CPU-generated) randomness.
+"""
+import itertools
+import logging
+import math
+import re
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from mixofshow.models.edlora import (LoRALinearLayer, revise_edlora_unet_attention_controller_forward,
+                                     revise_edlora_unet_attention_forward)
+from mixofshow.pipelines.pipeline_edlora import bind_concept_prompt
+from mixofshow.utils import pretrained
+from mixofshow.utils.ptp_util import AttentionStore
+
+logger = logging.getLogger('mixofshow')
+
+
+class EDLoRATrainer(nn.Module):
+
+    def __init__(self, pretrained_path, new_concept_token, initializer_token, enable_edlora, finetune_cfg=None,
+                 noise_offset=None, attn_reg_weight=None, reg_full_identity=True, use_mask_loss=True,
+                 enable_xformers=False, gradient_checkpoint=False):
+        super().__init__()
+        # 1. models (real weights if `pretrained_path` is a diffusers directory, seeded random init for synthetic://)
+        self.vae = pretrained.load_vae(pretrained_path)
+        self.tokenizer = pretrained.load_tokenizer(pretrained_path)
+        self.text_encoder = pretrained.load_text_encoder(pretrained_path)
+        self.unet = pretrained.load_unet(pretrained_path)
+        if gradient_checkpoint:
+            self.unet.enable_gradient_checkpointing()
+        # `enable_xformers` is accepted for YAML compatibility: the fused HIP attention is always used.
+        self.scheduler = pretrained.load_scheduler(pretrained_path, 'ddpm')
+
+        self.enable_edlora = enable_edlora
+        self.concept_embedding = None
+        self.new_concept_cfg = self.init_new_concept(new_concept_token, initializer_token, enable_edlora=enable_edlora)
+
+        self.attn_reg_weight = attn_reg_weight
+        self.reg_full_identity = reg_full_identity
+        if self.attn_reg_weight is not None:
+            self.controller = AttentionStore(training=True)
+            revise_edlora_unet_attention_controller_forward(self.unet, self.controller)
+        else:
+            revise_edlora_unet_attention_forward(self.unet)
+
+        self.text_encoder_lora = nn.ModuleList()
+        self.unet_lora = nn.ModuleList()
+        if finetune_cfg:
+            self.set_finetune_cfg(finetune_cfg)
+        self.noise_offset = noise_offset
+        self.use_mask_loss = use_mask_loss
+
+    # ------------------------------------------------------------------------------------------
+    def set_finetune_cfg(self, finetune_cfg):
+        for p in itertools.chain(self.vae.parameters(), self.text_encoder.parameters(), self.unet.parameters()):
+            p.requires_grad = False
+        groups = []
+        # 1. text embedding (reference :82-94) — the concept rows only, see module docstring
+        emb_cfg = finetune_cfg['text_embedding']
+        if emb_cfg['enable_tuning']:
+            self.concept_embedding.requires_grad_(True)
+            g = {'params': [self.concept_embedding], 'lr': emb_cfg['lr']}
+            if 'weight_decay' in emb_cfg:
+                g['weight_decay'] = emb_cfg['weight_decay']
+            groups.append(g)
+            logger.info(f"optimizing embedding using lr: {emb_cfg['lr']}")
+        else:
+            self.concept_embedding.requires_grad_(False)
+        # 2. text encoder LoRA (:97-115)
+        te_cfg = finetune_cfg['text_encoder']
+        if te_cfg['enable_tuning'] and te_cfg.get('lora_cfg'):
+            lora_cfg = dict(te_cfg['lora_cfg'])
+            where = lora_cfg.pop('where')
+            assert where in ['CLIPEncoderLayer', 'CLIPAttention']
+            params = []
+            for name, module in self.text_encoder.named_modules():
+                if module.__class__.__name__ == where:
+                    for child_name, child in module.named_modules():
+                        if child.__class__.__name__ == 'Linear':
+                            lora = LoRALinearLayer(name + '.' + child_name, child, **lora_cfg)
+                            self.text_encoder_lora.append(lora)
+                            params.extend(lora.parameters())
+            groups.append({'params': params, 'lr': te_cfg['lr']})
+            logger.info(f"optimizing text_encoder ({len(self.text_encoder_lora)} LoRAs), using lr: {te_cfg['lr']}")
+        # 3. unet LoRA (:118-136)
+        unet_cfg = finetune_cfg['unet']
+        if unet_cfg['enable_tuning'] and unet_cfg.get('lora_cfg'):
+            lora_cfg = dict(unet_cfg['lora_cfg'])
+            where = lora_cfg.pop('where')
+            assert where in ['Transformer2DModel', 'Attention']
+            params = []
+            for name, module in self.unet.named_modules():
+                if module.__class__.__name__ == where:
+                    for child_name, child in module.named_modules():
+                        cls = child.__class__.__name__
+                        if cls == 'Linear' or (cls == 'Conv2d' and child.kernel_size == (1, 1)):
+                            lora = LoRALinearLayer(name + '.' + child_name, child, **lora_cfg)
+                            self.unet_lora.append(lora)
+                            params.extend(lora.parameters())
+            groups.append({'params': params, 'lr': unet_cfg['lr']})
+            logger.info(f"optimizing unet ({len(self.unet_lora)} LoRAs), using lr: {unet_cfg['lr']}")
+        self.params_to_optimize_iterator = groups
+
+    def get_params_to_optimize(self):
+        return self.params_to_optimize_iterator
+
+    def trainable_parameters(self):
+        """Flat list of what data-parallel training must all-reduce: concept rows + every LoRA factor."""
+        return [p for g in self.params_to_optimize_iterator for p in g['params']]
+
+    # ------------------------------------------------------------------------------------------
+    def init_new_concept(self, new_concept_tokens, initializer_tokens, enable_edlora=True):
+        """reference :144-194 — 16 (ED-LoRA) or 1 new token per concept, `<rand-σ>` or copy-of-token init."""
+        cfg = {}
+        names = new_concept_tokens.split('+')
+        inits = ['<rand-0.017>'] * len(names) if initializer_tokens is None else initializer_tokens.split('+')
+        assert len(names) == len(inits), 'concept token should match init token.'
+        n_per = 16 if enable_edlora else 1
+        rows = []
+        for idx, (concept_name, init_token) in enumerate(zip(names, inits)):
+            tok_names = [f'<new{idx * n_per + layer}>' for layer in range(n_per)]
+            added = self.tokenizer.add_tokens(tok_names)
+            assert added == len(tok_names), 'some token is already in tokenizer'
+            tok_ids = [self.tokenizer.convert_tokens_to_ids(t) for t in tok_names]
+            self.text_encoder.resize_token_embeddings(len(self.tokenizer))
+            table = self.text_encoder.get_input_embeddings().weight.data
+            if init_token.startswith('<rand'):
+                sigma = float(re.findall(r'<rand-(.*)>', init_token)[0])
+                feat = torch.randn_like(table[0]) * sigma
+            else:
+                ids = self.tokenizer.encode(init_token, add_special_tokens=False)
+                if len(ids) > 1 or ids[0] == 40497:  # (sic) reference :179
+                    raise ValueError('The initializer token must be a single existing token.')
+                feat = table[ids[0]]
+            for t in tok_ids:
+                table[t] = feat.clone()
+            rows.append(table[tok_ids].clone())
+            cfg[concept_name] = {'concept_token_ids': tok_ids, 'concept_token_names': tok_names}
+            logger.info(f'{concept_name} ({min(tok_ids)}-{max(tok_ids)}) initialised by {init_token}')
+        all_ids = [i for c in cfg.values() for i in c['concept_token_ids']]
+        assert all_ids == list(range(all_ids[0], all_ids[0] + len(all_ids))), 'concept ids must be contiguous'
+        self.concept_embedding = nn.Parameter(torch.cat(rows, 0).float())
+        emb = self.text_encoder.text_model.embeddings
+        object.__setattr__(emb, 'concept_rows', self.concept_embedding)
+        emb.concept_base = all_ids[0]
+        return cfg
+
+    def get_all_concept_token_ids(self):
+        return [i for c in self.new_concept_cfg.values() for i in c['concept_token_ids']]
+
+    @torch.no_grad()
+    def sync_concept_rows_to_table(self):
+        """Write the trained rows back into the token table (what the reference's table holds after a step)."""
+        table = self.text_encoder.get_input_embeddings().weight
+        ids = self.get_all_concept_token_ids()
+        table[ids[0]:ids[0] + len(ids)] = self.concept_embedding.to(table.dtype)
+
+    def concept_norm_mean(self):
+        return self.concept_embedding.detach().norm(dim=-1).mean()
+
+    # ------------------------------------------------------------------------------------------
+    def _concept_positions(self, input_ids_cpu, batch):
+        """Positions of the concept tokens in the FIRST of each sample's 16 prompts (reference :275-279)."""
+        ids = input_ids_cpu.reshape(batch, -1, input_ids_cpu.shape[-1])[:, 0]
+        concept = set(self.get_all_concept_token_ids())
+        pos = [[i for i, t in enumerate(row.tolist()) if t in concept] for row in ids]
+        n = len(pos[0])
+        assert all(len(p) == n for p in pos) and 1 <= n <= 4, \
+            f'each prompt must contain the same number (1..4) of concept tokens, got {[len(p) for p in pos]}'
+        return torch.tensor(pos, dtype=torch.int32)
+
+    def forward(self, images, prompts, masks, img_masks, noise=None, timesteps=None, latents=None):
+        if latents is None:
+            latents = self.vae.encode(images).latent_dist.sample() * 0.18215
+        bsz = latents.shape[0]
+        if noise is None:
+            noise = torch.randn_like(latents)
+            if self.noise_offset is not None:
+                noise = noise + self.noise_offset * torch.randn((bsz, latents.shape[1], 1, 1), device=latents.device)
+        if timesteps is None:
+            timesteps = torch.randint(0, self.scheduler.config.num_train_timesteps, (bsz, ), device=latents.device)
+        timesteps = timesteps.long()
+        noisy_latents = self.scheduler.add_noise(latents, noise.to(latents.dtype), timesteps)
+
+        if self.enable_edlora:
+            prompts = bind_concept_prompt(prompts, new_concept_cfg=self.new_concept_cfg)
+        ids_cpu = self.tokenizer(prompts, padding='max_length', max_length=self.tokenizer.model_max_length,
+                                 truncation=True, return_tensors='pt').input_ids
+        text_input_ids = ids_cpu.to(latents.device)
+        encoder_hidden_states = self.text_encoder(text_input_ids)[0]
+        if self.enable_edlora:
+            encoder_hidden_states = encoder_hidden_states.reshape(bsz, -1, *encoder_hidden_states.shape[1:])
+
+        if self.attn_reg_weight is not None:
+            self.controller.set_token_positions(self._concept_positions(ids_cpu, bsz).to(latents.device))
+        model_pred = self.unet(noisy_latents, timesteps, encoder_hidden_states).sample
+
+        if self.scheduler.config.prediction_type == 'epsilon':
+            target = noise
+        elif self.scheduler.config.prediction_type == 'v_prediction':
+            target = self.scheduler.get_velocity(latents, noise, timesteps)
+        else:
+            raise ValueError(f'Unknown prediction type {self.scheduler.config.prediction_type}')
+        loss_mask = masks if self.use_mask_loss else img_masks
+        loss = F.mse_loss(model_pred.float(), target.float(), reduction='none')
+        loss = ((loss * loss_mask).sum([1, 2, 3]) / loss_mask.sum([1, 2, 3])).mean()
+
+        if self.attn_reg_weight is not None:
+            attention_loss = self.cal_attn_reg(self.controller.get_average_attention(), masks)
+            loss = loss + torch.where(torch.isnan(attention_loss), torch.zeros_like(attention_loss), attention_loss)
+            self.controller.reset()
+        return loss
+
+    def cal_attn_reg(self, attention_maps, masks, text_input_ids=None):
+        """reference :263-313 on column-sliced maps: attention_maps[place] = [(B, H, N, T), ...]; column 0 is the
+        adjective token (penalised outside the mask), column 1 the subject token (aligned with the mask)."""
+        groups = {}
+        for maps in attention_maps.values():
+            for m in maps:
+                B, H, N, T = m.shape
+                res = int(math.sqrt(N))
+                groups.setdefault(res, []).append(m.reshape(B, H, res, res, T))
+        total = 0
+        for res in sorted(groups, reverse=True):
+            cm = torch.cat(groups[res], dim=1)
+            cm = cm.sum(1) / cm.shape[1]                       # mean over heads of all layers: (B, res, res, T)
+            adj, subj = cm[..., 0], cm[..., 1]
+            subj = subj / subj.max()
+            adj = adj / adj.max()
+            gt = F.interpolate(masks.float(), size=subj.shape[1:], mode='nearest').squeeze(1)
+            outside = (gt == 0).to(subj.dtype)
+            n_out = outside.sum()
+            if self.reg_full_identity:
+                l_subj = F.mse_loss(subj.float(), gt.float(), reduction='mean')
+            else:
+                l_subj = (subj * outside).sum() / n_out
+            l_adj = (adj * outside).sum() / n_out
+            total = total + self.attn_reg_weight * (l_subj + l_adj)
+        return total
+
+    # ------------------------------------------------------------------------------------------
+    def delta_state_dict(self):
+        """reference :362-380 — {'new_concept_embedding': {name: (16,768)}, 'text_encoder': {...}, 'unet': {...}}."""
+        self.sync_concept_rows_to_table()
+        delta = {'new_concept_embedding': {}, 'text_encoder': {}, 'unet': {}}
+        table = self.text_encoder.get_input_embeddings().weight
+        for name, cfg in self.new_concept_cfg.items():
+            delta['new_concept_embedding'][name] = table[cfg['concept_token_ids']].detach().float().cpu()
+        for lora in self.text_encoder_lora:
+            for n, p in lora.named_parameters():
+                delta['text_encoder'][f'{lora.name}.{n}'] = p.detach().cpu().clone()
+        for lora in self.unet_lora:
+            for n, p in lora.named_parameters():
+                delta['unet'][f'{lora.name}.{n}'] = p.detach().cpu().clone()
+        return delta
+
+    @torch.no_grad()
+    def load_delta_state_dict(self, delta):
+        """reference :315-360."""
+        emb = delta.get('new_concept_embedding') or {}
+        if emb:
+            if set(emb.keys()) != set(self.new_concept_cfg.keys()):
+                logger.warning('Your checkpoint have different concept with your model, loading existing concepts')
+            base = self.get_all_concept_token_ids()[0]
+            for name, cfg in self.new_concept_cfg.items():
+                if name in emb:
+                    ids = cfg['concept_token_ids']
+                    self.concept_embedding[ids[0] - base:ids[0] - base + len(ids)] = emb[name].to(self.concept_embedding)
+            self.sync_concept_rows_to_table()
+        for key, loras, module in (('text_encoder', self.text_encoder_lora, self.text_encoder),
+                                   ('unet', self.unet_lora, self.unet)):
+            sd = delta.get(key) or {}
+            if not sd:
+                continue
+            if len(loras) and len(sd) == 2 * len(loras):
+                for lora in loras:
+                    for n, p in lora.named_parameters():
+                        p.copy_(sd[f'{lora.name}.{n}'])
+            else:
+                for n, p in module.named_parameters():
+                    if n in sd and 'token_embedding' not in n:
+                        p.copy_(sd[n])

@@ -1,0 +1,241 @@
+"""GPU parity of every HIP primitive (through the C-ABI via mixofshow.hip.ops) against the oracle's torch
+emulation (oracle/emu_ops.py, fp32 math on the same half-precision inputs) at the SD-1.5 shapes.
+
+Tolerances: outputs are rounded once to fp16/bf16; we allow a few ulps of the output dtype relative to the
+largest magnitude in the tensor (fp16 eps = 9.8e-4, bf16 eps = 7.8e-3) — the 1e-3 fp16 tolerance of
+BASELINE.json is checked end-to-end on denoised latents in test_gpu_end_to_end.py.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+
+
+def _tol(dtype, ref, ulps=4.0):
+    eps = 9.8e-4 if dtype == torch.float16 else 7.9e-3
+    return ulps * eps * max(1.0, float(ref.abs().max()))
+
+
+def _check(name, got, ref, dtype, ulps=4.0):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, f'{name}: shape {got.shape} vs {ref.shape}'
+    assert torch.isfinite(got).all(), f'{name}: non-finite output'
+    err = (got - ref).abs().max().item()
+    tol = _tol(dtype, ref, ulps)
+    print(f'[parity] {name}: max_abs_err={err:.3e} tol={tol:.3e} ref_max={ref.abs().max().item():.3e}')
+    assert err <= tol, f'{name}: max abs err {err:.3e} > {tol:.3e}'
+
+
+@pytest.fixture(scope='module')
+def ops():
+    import mixofshow.hip.ops as ops
+    from mixofshow.hip import lib
+    lib.load()
+    return ops
+
+
+@pytest.fixture(scope='module')
+def emu():
+    from oracle import emu_ops
+    return emu_ops
+
+
+def _lora_factors(sites, r, K, dev, seed):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    downs = [(torch.randn(r, K, generator=g) * 0.05).to(dev) for _ in sites]
+    ups = [(torch.randn(n, r, generator=g) * 0.05).to(dev) for n in sites]
+    return downs, ups
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_lora_pack_exact(ops, emu, dtype):
+    dev = 'cuda'
+    downs, ups = _lora_factors([320, 320, 320], 4, 320, dev, 0)
+    got = ops.lora_pack(downs, ups, [1.0, 0.7, 0.3], 320, dtype, dev)
+    ref = emu.lora_pack(downs, ups, [1.0, 0.7, 0.3], 320, dtype, dev)
+    for g, r, n in zip(got, ref, ('A16', 'A16T', 'Bp16', 'BpT')):
+        assert torch.equal(g, r), n
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K,sites', [
+    (16384, 960, 320, [320, 320, 320]),   # L0 fused qkv, B=4
+    (16384, 320, 320, [320]),             # L0 out-proj
+    (308, 640, 768, [320, 320]),          # cross K/V on 4x77 text tokens (ragged M)
+    (4096, 1920, 640, [640, 640, 640]),   # L1 fused qkv
+    (1024, 1280, 1280, [1280]),           # L2
+    (100, 320, 320, [320]),               # ragged tile
+    (4928, 768, 768, [768]),              # CLIP q_proj on 64x77 tokens
+])
+def test_lora_linear_fwd_bwd(ops, emu, dtype, M, N, K, sites):
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(1)
+    x = torch.randn(M, K, generator=g).to(dev, dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev, dtype)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dev)
+    downs, ups = _lora_factors(sites, 4, K, dev, 2)
+    alphas = [1.0] * len(sites)
+    A16, A16T, Bp16, BpT = ops.lora_pack(downs, ups, alphas, K, dtype, dev)
+    t = ops.lora_down(x, A16)
+    t_ref = emu.lora_down(x, A16)
+    _check('lora_down', t, t_ref, dtype)
+    y = ops.linear_fwd(x, W, t_ref, Bp16, bias)
+    y_ref = emu.linear_fwd(x, W, t_ref, Bp16, bias)
+    _check(f'linear_fwd[{M}x{N}x{K}]', y, y_ref, dtype)
+    y0 = ops.linear_fwd(x, W)
+    _check('linear_fwd_plain', y0, emu.linear_fwd(x, W), dtype)
+    # backward
+    dy = torch.randn(M, N, generator=g).to(dev, dtype)
+    Wt = W.t().contiguous()
+    dx, dA, dB = ops.linear_bwd(dy, x, Wt, t_ref, A16T, BpT)
+    dx_r, dA_r, dB_r = emu.linear_bwd(dy, x, Wt, t_ref, A16T, BpT)
+    _check('linear_bwd.dx', dx, dx_r, dtype)
+    # LoRA factor grads are fp32 sums over M tokens of half-precision products
+    _check('linear_bwd.dA16', dA, dA_r, dtype, ulps=2.0)
+    _check('linear_bwd.dBpT', dB, dB_r, dtype, ulps=2.0)
+    dx2, _, _ = ops.linear_bwd(dy, x, Wt, None, None, None)
+    _check('linear_bwd_plain.dx', dx2, emu.linear_bwd(dy, x, Wt, None, None, None)[0], dtype)
+
+
+def _qkv(B, Nq, Nkv, C, dtype, seed, fused):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    if fused and Nq == Nkv:
+        buf = (torch.randn(B, Nq, 3 * C, generator=g)).to('cuda', dtype)
+        return buf[..., :C], buf[..., C:2 * C], buf[..., 2 * C:]
+    q = torch.randn(B, Nq, C, generator=g).to('cuda', dtype)
+    kv = torch.randn(B, Nkv, 2 * C, generator=g).to('cuda', dtype)
+    return q, kv[..., :C], kv[..., C:]
+
+
+ATTN_CASES = [
+    # B, H, Nq, Nkv, d
+    (2, 8, 4096, 4096, 40),
+    (2, 8, 1024, 1024, 80),
+    (2, 8, 256, 256, 160),
+    (2, 8, 64, 64, 160),
+    (1, 8, 96, 96, 160),      # 8x12 map of 512x768: ragged kv tile
+    (1, 8, 1536, 1536, 80),
+    (2, 8, 4096, 77, 40),     # cross attention
+    (2, 8, 1024, 77, 80),
+    (2, 8, 256, 77, 160),
+    (1, 8, 70, 77, 40),       # ragged queries
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,Nq,Nkv,d', ATTN_CASES)
+def test_attention_fwd_bwd(ops, emu, dtype, B, H, Nq, Nkv, d):
+    C = H * d
+    q, k, v = _qkv(B, Nq, Nkv, C, dtype, 3, fused=True)
+    scale = d**-0.5
+    cross = Nkv == 77
+    tok = None
+    if cross:
+        tok = torch.tensor([[5, 70], [76, 0]][:B], dtype=torch.int32, device='cuda').contiguous()
+    o, lse, pcols = ops.attn_fwd(q, k, v, H, scale, tok_idx=tok)
+    o_r, lse_r, pcols_r = emu.attn_fwd(q, k, v, H, scale, tok_idx=tok)
+    _check(f'attn_fwd.o[{Nq}x{Nkv}x{d}]', o, o_r, dtype)
+    _check('attn_fwd.lse', lse, lse_r, torch.float16, ulps=2.0)
+    if cross:
+        _check('attn_fwd.pcols', pcols, pcols_r, torch.float16, ulps=1.0)
+    g = torch.Generator(device='cpu').manual_seed(4)
+    dO = torch.randn(B, Nq, C, generator=g).to('cuda', dtype)
+    dpc = (torch.randn(B, H, Nq, 2, generator=g) * 3.0).to('cuda') if cross else None
+    dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
+    ops.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq, dk, dv, tok_idx=tok, pcols=pcols_r, dpcols=dpc)
+    dq_r, dk_r, dv_r = torch.empty_like(dq), torch.empty_like(dk), torch.empty_like(dv)
+    emu.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq_r, dk_r, dv_r, tok_idx=tok, pcols=pcols_r, dpcols=dpc)
+    _check('attn_bwd.dq', dq, dq_r, dtype, ulps=6.0)
+    _check('attn_bwd.dk', dk, dk_r, dtype, ulps=6.0)
+    _check('attn_bwd.dv', dv, dv_r, dtype, ulps=6.0)
+
+
+def test_attention_softmax_rescale_branch(ops, emu):
+    """Force the online-softmax rescale: one key far above the rest in a LATE kv tile (cdna guide 5.4 rule 26)."""
+    B, H, N, d = 1, 8, 512, 40
+    g = torch.Generator(device='cpu').manual_seed(5)
+    q = torch.randn(B, N, H * d, generator=g)
+    k = torch.randn(B, N, H * d, generator=g)
+    v = torch.randn(B, N, H * d, generator=g)
+    k[:, 300] = q[:, 17] * 4.0          # spikes q.k for query 17 (and correlates for others) in tile 4
+    k[:, 450] = -q[:, 99] * 4.0
+    q, k, v = (t.to('cuda', torch.float16) for t in (q, k, v))
+    o, lse, _ = ops.attn_fwd(q, k, v, H, d**-0.5)
+    o_r, lse_r, _ = emu.attn_fwd(q, k, v, H, d**-0.5)
+    _check('attn_fwd.spike.o', o, o_r, torch.float16)
+    _check('attn_fwd.spike.lse', lse, lse_r, torch.float16, ulps=2.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('fh,fw,d', [(64, 96, 40), (32, 48, 80), (16, 24, 160), (8, 12, 160)])
+def test_region_attention(ops, emu, dtype, fh, fw, d):
+    B, H = 2, 8
+    C = H * d
+    N = fh * fw
+    g = torch.Generator(device='cpu').manual_seed(6)
+    q = torch.randn(B, N, C, generator=g).to('cuda', dtype)
+    S = 5
+    kv = torch.randn(S, B, 77, 2 * C, generator=g).to('cuda', dtype)
+    k_src, v_src = kv[..., :C], kv[..., C:]
+    # regionally_sample.sh boxes at 512x768 (+ one overlapping box), rounded like region_rewrite
+    px = [[2, 2, 512, 184], [7, 184, 512, 345], [1, 488, 512, 747], [100, 150, 400, 300]]
+    boxes = [(math.ceil(b[0] / 512 * fh), math.ceil(b[1] / 768 * fw), math.floor(b[2] / 512 * fh),
+              math.floor(b[3] / 768 * fw)) for b in px]
+    o = ops.region_attn_fwd(q, k_src, v_src, H, d**-0.5, boxes, fh, fw)
+    o_r = emu.region_attn_fwd(q, k_src, v_src, H, d**-0.5, boxes, fh, fw)
+    _check(f'region_attn[{fh}x{fw}x{d}]', o, o_r, dtype)
+    # known answers: no regions == plain cross attention with the context keys
+    o0 = ops.region_attn_fwd(q, k_src[:1], v_src[:1], H, d**-0.5, [], fh, fw)
+    base, _, _ = emu.attn_fwd(q, k_src[0], v_src[0], H, d**-0.5)
+    _check('region_attn.empty', o0, base, dtype)
+    # one region covering everything with the context keys == base
+    both = torch.stack([kv[0], kv[0]])
+    o1 = ops.region_attn_fwd(q, both[..., :C], both[..., C:], H, d**-0.5, [(0, 0, fh, fw)], fh, fw)
+    _check('region_attn.full_cover', o1, base, dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('n,cin,cout', [(20000, 320, 320), (3000, 768, 320), (5000, 1280, 1280), (84, 768, 640),
+                                        (777, 320, 2560)])
+def test_gram_and_lsq(ops, emu, dtype, n, cin, cout):
+    g = torch.Generator(device='cpu').manual_seed(7)
+    X = torch.randn(n, cin, generator=g).to('cuda', dtype)
+    Y = torch.randn(n, cout, generator=g).to('cuda', dtype)
+
+    def fresh():
+        return (torch.zeros(cin, cin, dtype=torch.float64, device='cuda'),
+                torch.zeros(cout, cin, dtype=torch.float64, device='cuda'),
+                torch.zeros(1, dtype=torch.float64, device='cuda'))
+
+    G, P, c = fresh()
+    ops.gram_accumulate(X, Y, G, P, c)
+    ops.gram_accumulate(X, Y, G, P, c)     # accumulation across calls (concepts)
+    Gr, Pr, cr = fresh()
+    emu.gram_accumulate(X, Y, Gr, Pr, cr)
+    emu.gram_accumulate(X, Y, Gr, Pr, cr)
+    for name, a, b in (('G', G, Gr), ('P', P, Pr), ('c', c, cr)):
+        rel = ((a - b).abs().max() / b.abs().max()).item()
+        print(f'[parity] gram.{name}: rel_err={rel:.3e}')
+        assert rel < 2e-5, f'gram {name} rel err {rel}'
+    W = (torch.randn(cout, cin, generator=g, dtype=torch.float64) * 0.05).cuda()
+    loss, grad = ops.lsq_loss_grad(W, Gr, Pr, cr, 2.0 * n * cout)
+    loss_r, grad_r = emu.lsq_loss_grad(W, Gr, Pr, cr, 2.0 * n * cout)
+    assert abs(loss.item() - loss_r.item()) <= 1e-10 * abs(loss_r.item()) + 1e-14
+    assert ((grad - grad_r).abs().max() / grad_r.abs().max()).item() < 1e-10
+    # and the Gram-form loss equals the direct mean((X W^T - Y)^2) of the reference closure
+    direct = ((torch.cat([X, X]).double() @ W.t() - torch.cat([Y, Y]).double())**2).mean()
+    assert abs(loss.item() - direct.item()) <= 1e-8 * abs(direct.item())
+
+
+def test_errors_are_loud(ops):
+    x = torch.randn(64, 320)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.lora_down(x.half(), x.half())
+    q = torch.randn(1, 64, 8 * 48, device='cuda', dtype=torch.float16)
+    from mixofshow.hip.lib import MosHipError
+    with pytest.raises(MosHipError, match='head dim'):
+        ops.attn_fwd(q, q, q, 8, 1.0)
