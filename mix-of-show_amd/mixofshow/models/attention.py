@@ -116,9 +116,7 @@ def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_i
     tok_idx: int32 (B, T) key positions whose probabilities are returned (training regulariser).
     region: None or dict(k_src, v_src, boxes, feat_h, feat_w) -> regional mask-and-blend attention.
     Returns (out (B, N, C), pcols (B, H, N, T) fp32 | None)."""
-    if not hidden_states.is_cuda:
-        raise RuntimeError('mixofshow: attention processors run on the HIP device only (no CPU fallback); '
-                           f'got a tensor on {hidden_states.device}')
+    # (device guard: every primitive in mixofshow.hip.ops raises on non-HIP tensors — there is no fallback)
     cd = F_hip.compute_dtype_for(hidden_states)
     out_dtype = cd if (torch.is_autocast_enabled('cuda') or hidden_states.dtype in (torch.float16, torch.bfloat16)) \
         else hidden_states.dtype

@@ -21,8 +21,19 @@ class CLIPTextEmbeddings(nn.Module):
         self.position_embedding = nn.Embedding(max_pos, hidden)
         self.register_buffer('position_ids', torch.arange(max_pos).unsqueeze(0), persistent=False)
 
+    # Trainable concept rows (EDLoRATrainer): ids >= concept_base read from the small `concept_rows` parameter
+    # instead of the frozen table, so only 16k x 768 values carry gradients / optimizer state / all-reduce.
+    concept_rows = None
+    concept_base = None
+
     def forward(self, input_ids):
-        return self.token_embedding(input_ids) + self.position_embedding(self.position_ids[:, :input_ids.shape[1]])
+        tok = self.token_embedding(input_ids)
+        if self.concept_rows is not None:
+            is_new = input_ids >= self.concept_base
+            new = F.embedding((input_ids - self.concept_base).clamp(min=0, max=self.concept_rows.shape[0] - 1),
+                              self.concept_rows)
+            tok = torch.where(is_new[..., None], new.to(tok.dtype), tok)
+        return tok + self.position_embedding(self.position_ids[:, :input_ids.shape[1]])
 
 
 class CLIPAttention(nn.Module):

@@ -187,9 +187,6 @@ class LoRALinearLayer(nn.Module):
 
     def forward(self, hidden_states):
         mod = self._wrapped
-        if not hidden_states.is_cuda:
-            raise RuntimeError('mixofshow: LoRALinearLayer runs on the HIP device only (no CPU fallback); got '
-                               f'{hidden_states.device}')
         cd = F_hip.compute_dtype_for(hidden_states)
         out_dtype = cd if (torch.is_autocast_enabled('cuda') or hidden_states.dtype == cd) else hidden_states.dtype
         need_wt = torch.is_grad_enabled()

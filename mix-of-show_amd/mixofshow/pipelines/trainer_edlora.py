@@ -37,6 +37,7 @@ class EDLoRATrainer(nn.Module):
                  noise_offset=None, attn_reg_weight=None, reg_full_identity=True, use_mask_loss=True,
                  enable_xformers=False, gradient_checkpoint=False):
         super().__init__()
+        self.pretrained_path = pretrained_path
         # 1. models (real weights if `pretrained_path` is a diffusers directory, seeded random init for synthetic://)
         self.vae = pretrained.load_vae(pretrained_path)
         self.tokenizer = pretrained.load_tokenizer(pretrained_path)

@@ -171,7 +171,8 @@ class AttentionStoreRef:
 
 
 # ---- mixofshow/pipelines/trainer_edlora.py:263-313 --------------------------------------------------
-def cal_attn_reg_ref(attention_maps, masks, text_input_ids, concept_token_ids, attn_reg_weight, reg_full_identity):
+def cal_attn_reg_ref(attention_maps, masks, text_input_ids, concept_token_ids, attn_reg_weight, reg_full_identity,
+                     strict_resolutions=True):
     """attention_maps: {'down_cross': [(B*H, N, 77), ...], ...}; masks (B,1,64,64); ids (B*16, 77)."""
     B = masks.shape[0]
     ids = text_input_ids.reshape(B, -1, text_input_ids.shape[-1])
@@ -186,6 +187,8 @@ def cal_attn_reg_ref(attention_maps, masks, text_input_ids, concept_token_ids, a
             groups[str(res)].append(m.reshape(B, -1, res, res, m.shape[-1]))
     total = 0
     for res, maps in groups.items():
+        if not maps and not strict_resolutions:      # the reference itself needs all 4 groups (512x512 inputs only)
+            continue
         cm = torch.cat(maps, dim=-4)                 # concat heads of all layers at this resolution
         cm = cm.sum(-4) / cm.shape[-4]
         cm = torch.stack([bm[..., p] for p, bm in zip(pos, cm)])

@@ -1,0 +1,277 @@
+"""CPU tests of the HOST side: the product's processors / LoRA layers / trainer orchestration run with the HIP
+primitives replaced by the oracle's torch emulation (fixture `emulated_hip`) and are compared with the oracle's
+restatement of the reference. The kernels themselves are covered on the GPU (test_gpu_*.py)."""
+import copy
+
+import pytest
+import torch
+
+from oracle import edlora_ref as R
+from oracle import region_ref, trainer_ref
+
+
+def _copy_attention(dst, src):
+    dst.load_state_dict(src.state_dict())
+
+
+def _mk_layers(cross_dim, C=64, heads=8, seed=0):
+    from mixofshow.models.attention import Attention
+    from oracle.attention_shim import Attention as Shim
+    torch.manual_seed(seed)
+    prod = Attention(C, cross_attention_dim=cross_dim, heads=heads, dim_head=C // heads)
+    with torch.no_grad():
+        for p in prod.parameters():
+            p.copy_(torch.randn_like(p) * (0.5 / p.shape[-1]**0.5 if p.dim() > 1 else 0.02))
+            p.copy_(p.half().float())          # half-representable weights: both paths see identical values
+    ref = Shim(C, cross_attention_dim=cross_dim, heads=heads, dim_head=C // heads)
+    _copy_attention(ref, prod)
+    return prod, ref
+
+
+def _wrap_both(prod, ref, seed=1):
+    from mixofshow.models.edlora import LoRALinearLayer
+    torch.manual_seed(seed)
+    pl, rl = [], []
+    for name in ('to_q', 'to_k', 'to_v', 'to_out.0'):
+        pm = prod.to_out[0] if name == 'to_out.0' else getattr(prod, name)
+        rm = ref.to_out[0] if name == 'to_out.0' else getattr(ref, name)
+        a = LoRALinearLayer(name, pm, rank=4, alpha=1.0)
+        b = R.LoRALinearLayerRef(name, rm, rank=4, alpha=1.0)
+        with torch.no_grad():
+            a.lora_up.weight.copy_((torch.randn_like(a.lora_up.weight) * 0.05).half().float())
+            a.lora_down.weight.copy_(a.lora_down.weight.half().float())
+            b.lora_up.weight.copy_(a.lora_up.weight)
+            b.lora_down.weight.copy_(a.lora_down.weight)
+        pl.append(a)
+        rl.append(b)
+    return pl, rl
+
+
+@pytest.mark.parametrize('cross', [None, 48])
+def test_edlora_processor_forward_backward(emulated_hip, cross):
+    from mixofshow.models.edlora import EDLoRA_AttnProcessor
+    prod, ref = _mk_layers(cross)
+    pl, rl = _wrap_both(prod, ref)
+    prod.set_processor(EDLoRA_AttnProcessor(2))
+    ref.set_processor(R.EDLoRA_AttnProcessorRef(2))
+    torch.manual_seed(3)
+    x = torch.randn(2, 64, 64).half()
+    ehs = torch.randn(2, 4, 77, 48).half() if cross else None
+    xp = x.clone().requires_grad_(True)
+    xr = x.float().clone().requires_grad_(True)
+    yp = prod(xp, encoder_hidden_states=ehs)
+    yr = ref(xr, encoder_hidden_states=ehs.float() if cross else None)
+    assert yp.dtype == torch.float16
+    torch.testing.assert_close(yp.float(), yr, rtol=2e-2, atol=3e-3)
+    w = torch.randn_like(yr)
+    (yp.float() * w).sum().backward()
+    (yr * w).sum().backward()
+    torch.testing.assert_close(xp.grad.float(), xr.grad, rtol=3e-2, atol=5e-3)
+    for a, b in zip(pl, rl):
+        for n in ('lora_down', 'lora_up'):
+            ga, gb = getattr(a, n).weight.grad, getattr(b, n).weight.grad
+            assert ga is not None and ga.dtype == torch.float32
+            torch.testing.assert_close(ga, gb, rtol=3e-2, atol=2e-2 * gb.abs().max().item())
+
+
+def test_lora_layer_standalone_and_conv(emulated_hip):
+    from mixofshow.models.edlora import LoRALinearLayer
+    torch.manual_seed(0)
+    lin_p, lin_r = torch.nn.Linear(48, 24), torch.nn.Linear(48, 24)
+    lin_r.load_state_dict(lin_p.state_dict())
+    a = LoRALinearLayer('x', lin_p, rank=4, alpha=0.7)
+    b = R.LoRALinearLayerRef('x', lin_r, rank=4, alpha=0.7)
+    with torch.no_grad():
+        a.lora_up.weight.normal_(0, 0.1)
+        b.lora_up.weight.copy_(a.lora_up.weight); b.lora_down.weight.copy_(a.lora_down.weight)
+    x = torch.randn(3, 5, 48)
+    y = lin_p(x)                       # fp32 in, no autocast -> fp32 out, computed in half inside
+    assert y.dtype == torch.float32
+    torch.testing.assert_close(y, lin_r(x), rtol=2e-2, atol=1e-2)
+    # default init: up == 0 -> identical to the wrapped layer (known answer)
+    lin2 = torch.nn.Linear(16, 8)
+    ref_out = torch.nn.functional.linear(torch.ones(2, 16), lin2.weight, lin2.bias)
+    LoRALinearLayer('z', lin2)
+    torch.testing.assert_close(lin2(torch.ones(2, 16)), ref_out, rtol=1e-2, atol=1e-2)
+    # 1x1 conv site
+    conv_p, conv_r = torch.nn.Conv2d(16, 8, 1), torch.nn.Conv2d(16, 8, 1)
+    conv_r.load_state_dict(conv_p.state_dict())
+    c = LoRALinearLayer('c', conv_p, rank=4, alpha=1.0)
+    d = R.LoRALinearLayerRef('c', conv_r, rank=4, alpha=1.0)
+    with torch.no_grad():
+        c.lora_up.weight.normal_(0, 0.1)
+        d.lora_up.weight.copy_(c.lora_up.weight); d.lora_down.weight.copy_(c.lora_down.weight)
+    xc = torch.randn(2, 16, 6, 6)
+    torch.testing.assert_close(conv_p(xc), conv_r(xc), rtol=2e-2, atol=1e-2)
+    assert sorted(k for k, _ in c.named_parameters()) == ['lora_down.weight', 'lora_up.weight']
+    assert 'alpha' in dict(c.named_buffers())
+
+
+def test_processor_installation_order_and_controller_contract():
+    from mixofshow.models.edlora import (EDLoRA_AttnProcessor, EDLoRA_Control_AttnProcessor,
+                                         revise_edlora_unet_attention_controller_forward,
+                                         revise_edlora_unet_attention_forward)
+    from mixofshow.utils.pretrained import load_unet
+    from mixofshow.utils.ptp_util import AttentionStore
+    unet = load_unet('synthetic://tiny')
+    n = revise_edlora_unet_attention_forward(unet)
+    idx = [m.processor.cross_attention_idx for name, m in unet.named_modules()
+           if m.__class__.__name__ == 'Attention' and name.endswith('attn2')]
+    # named_modules order is down -> mid -> up; indices must be 0..n-1 in that order (edlora.py:186-189)
+    assert idx == list(range(n)) and n == 4
+    attn1 = [m.processor for name, m in unet.named_modules() if name.endswith('attn1')]
+    assert not any(isinstance(p, EDLoRA_AttnProcessor) for p in attn1)
+    store = AttentionStore(training=True)
+    revise_edlora_unet_attention_controller_forward(unet, store)
+    assert store.num_att_layers == n
+    places = [m.processor.place_in_unet for name, m in unet.named_modules() if name.endswith('attn2')]
+    assert places == ['down', 'mid', 'up', 'up']
+    assert all(isinstance(m.processor, EDLoRA_Control_AttnProcessor) for name, m in unet.named_modules()
+               if name.endswith('attn2'))
+
+
+def _trainer(attn_reg_weight=0.01, reg_full_identity=False):
+    from mixofshow.pipelines.trainer_edlora import EDLoRATrainer
+    cfg = dict(text_embedding=dict(enable_tuning=True, lr=1e-3),
+               text_encoder=dict(enable_tuning=True, lora_cfg=dict(rank=4, alpha=1.0, where='CLIPAttention'), lr=1e-5),
+               unet=dict(enable_tuning=True, lora_cfg=dict(rank=4, alpha=1.0, where='Attention'), lr=1e-4))
+    torch.manual_seed(0)
+    tr = EDLoRATrainer('synthetic://tiny', '<potter1>+<potter2>', '<rand-0.013>+man', True, finetune_cfg=cfg,
+                       noise_offset=0.01, attn_reg_weight=attn_reg_weight, reg_full_identity=reg_full_identity,
+                       use_mask_loss=True)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+            l.lora_up.weight.normal_(0, 0.02)      # zero `up` would hide the LoRA branch
+    return tr
+
+
+def _batch(B=2):
+    g = torch.Generator().manual_seed(5)
+    latents = torch.randn(B, 4, 16, 16, generator=g)
+    noise = torch.randn(B, 4, 16, 16, generator=g)
+    t = torch.randint(0, 1000, (B, ), generator=g)
+    masks = torch.zeros(B, 1, 16, 16)
+    masks[:, :, 4:12, 4:12] = 1
+    prompts = ['a <potter1> <potter2> in the park'] * B
+    return dict(images=None, prompts=prompts, masks=masks, img_masks=torch.ones_like(masks), noise=noise,
+                timesteps=t, latents=latents)
+
+
+@pytest.mark.parametrize('full_identity', [False, True])
+def test_trainer_forward_backward_vs_reference_path(emulated_hip, full_identity):
+    tr = _trainer(reg_full_identity=full_identity)
+    assert len(tr.unet_lora) == 4 * 8 and len(tr.text_encoder_lora) == 4
+    assert tr.new_concept_cfg['<potter2>']['concept_token_ids'] == list(range(49424, 49440))
+    b = _batch()
+    with torch.autocast('cpu', enabled=False):
+        loss = tr(**b)
+    loss.backward()
+    twin = trainer_ref.make_reference_twin(tr)
+    loss_ref = trainer_ref.reference_forward(twin, **b)
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 2e-2 * abs(loss_ref.item())
+    got, ref = tr.trainable_parameters(), trainer_ref.twin_parameters(twin)
+    assert len(got) == len(ref) == 1 + 2 * (32 + 4)
+    num = den = 0.0
+    for a, r in zip(got, ref):
+        assert a.grad is not None, 'every trainable tensor must receive a gradient'
+        num += (a.grad.float() - r.grad).pow(2).sum().item()
+        den += r.grad.pow(2).sum().item()
+    assert (num / den)**0.5 < 5e-2, f'relative grad error {(num / den) ** 0.5}'
+    # concept rows: only the rows of tokens that occur in the prompts get gradient
+    g = got[0].grad
+    assert g.shape == (32, tr.text_encoder.config.hidden_size) and g.abs().sum() > 0
+
+
+def test_attn_reg_full_mask_nan_guard(emulated_hip):
+    tr = _trainer()
+    b = _batch()
+    b['masks'] = torch.ones_like(b['masks'])          # no pixel outside the mask -> regulariser is NaN -> skipped
+    loss = tr(**b)
+    assert torch.isfinite(loss)
+
+
+def test_concept_rows_equal_full_table_adamw():
+    """The small `concept_embedding` parameter is step-for-step identical to AdamW over the whole table followed by
+    restoring the other rows (train_edlora.py:123-136)."""
+    torch.manual_seed(0)
+    V, Dm, ids = 200, 16, list(range(150, 182))
+    table = torch.randn(V, Dm)
+    grads = []
+    for _ in range(5):
+        g = torch.randn(V, Dm)
+        grads.append(g)
+    ref = trainer_ref.full_table_adamw_reference(table, ids, grads, lr=1e-3)
+    rows = torch.nn.Parameter(table[ids].clone())
+    opt = torch.optim.AdamW([rows], lr=1e-3, weight_decay=0.01, betas=(0.9, 0.999))
+    for g in grads:
+        rows.grad = g[ids].clone()
+        opt.step(); opt.zero_grad()
+    torch.testing.assert_close(rows.detach(), ref[ids], rtol=0, atol=0)
+    keep = torch.ones(V, dtype=torch.bool); keep[ids] = False
+    torch.testing.assert_close(ref[keep], table[keep], rtol=0, atol=0)
+
+
+def test_delta_state_dict_roundtrip(emulated_hip):
+    tr = _trainer(attn_reg_weight=None)
+    d = tr.delta_state_dict()
+    assert set(d) == {'new_concept_embedding', 'text_encoder', 'unet'}
+    assert d['new_concept_embedding']['<potter1>'].shape == (16, 64)
+    assert 'text_model.encoder.layers.0.self_attn.q_proj.lora_down.weight' in d['text_encoder']
+    k = 'down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q.lora_up.weight'
+    assert k in d['unet'] and len(d['unet']) == 2 * 32
+    tr2 = _trainer(attn_reg_weight=None)
+    with torch.no_grad():
+        for p in tr2.trainable_parameters():
+            p.add_(1.0)
+    tr2.load_delta_state_dict(copy.deepcopy(d))
+    for a, b in zip(tr.trainable_parameters(), tr2.trainable_parameters()):
+        torch.testing.assert_close(a, b)
+
+
+def test_bind_and_scheduler_and_tokenizer():
+    from mixofshow.models.schedulers import DDPMScheduler, DPMSolverMultistepScheduler
+    from mixofshow.pipelines.pipeline_edlora import bind_concept_prompt
+    from mixofshow.utils.tokenizer import SyntheticCLIPTokenizer
+    cfg = {'<potter1>': {'concept_token_names': [f'<new{i}>' for i in range(16)]}}
+    out = bind_concept_prompt('a <potter1> cat', cfg)
+    assert out == R.bind_concept_prompt_ref('a <potter1> cat', cfg) and out[3] == 'a <new3> cat'
+    tok = SyntheticCLIPTokenizer()
+    assert tok.add_tokens(['<new0>', '<new1>']) == 2 and tok.convert_tokens_to_ids('<new1>') == 49409
+    ids = tok(['a <new0> <new1> man'], padding='max_length', max_length=77, truncation=True, return_tensors='pt').input_ids
+    assert ids.shape == (1, 77) and ids[0, 0] == 49406 and ids[0, 2] == 49408 and ids[0, -1] == 49407
+    s = DPMSolverMultistepScheduler()
+    s.set_timesteps(50)
+    assert s.timesteps[0] == 999 and len(s.timesteps) == 50 and s.timesteps[-1] == 20
+    # exactness on a linear "model": eps = 0 -> x0_pred = x/alpha; the update must stay finite and deterministic
+    x = torch.ones(1, 4, 8, 8)
+    for t in s.timesteps:
+        x = s.step(torch.zeros_like(x), t, x).prev_sample
+    assert torch.isfinite(x).all()
+    d = DDPMScheduler()
+    xx = d.add_noise(torch.ones(2, 4, 2, 2), torch.zeros(2, 4, 2, 2), torch.tensor([0, 999]))
+    assert abs(xx[0, 0, 0, 0].item() - (1 - 0.00085)**0.5) < 1e-6 and xx[1, 0, 0, 0] < 0.1
+
+
+def test_region_processor_host_logic(emulated_hip, golden):
+    """RegionT2I processor (product, emulated kernels) against the golden output of the REAL reference processor."""
+    from mixofshow.models.attention import Attention
+    from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionT2I_AttnProcessor
+    g = golden['region']
+    C = g['hs'].shape[-1]
+    attn = Attention(C, cross_attention_dim=g['ctx'].shape[-1], heads=8, dim_head=C // 8)
+    attn.load_state_dict(g['state'])
+    proc = RegionT2I_AttnProcessor(g['idx'])
+    kw = dict(region_list=g['regions'], height=g['height'], width=g['width'])
+    y = proc(attn, g['hs'].half(), encoder_hidden_states=g['ctx'].half(), **kw)
+    torch.testing.assert_close(y.float(), g['y'], rtol=3e-2, atol=4e-3)
+    y0 = proc(attn, g['hs'].half(), encoder_hidden_states=g['ctx'].half(), region_list=[], height=g['height'],
+              width=g['width'])
+    torch.testing.assert_close(y0.float(), g['y_none'], rtol=3e-2, atol=4e-3)
+    attn_s = Attention(C, heads=8, dim_head=C // 8)
+    attn_s.load_state_dict(g['self_state'])
+    ys = proc(attn_s, g['hs'].half(), **kw)
+    torch.testing.assert_close(ys.float(), g['y_self'], rtol=3e-2, atol=4e-3)
+    with pytest.raises(KeyError):
+        proc(attn, g['hs'].half(), encoder_hidden_states=g['ctx'].half())
