@@ -1,0 +1,340 @@
+"""Gradient fusion (multi-concept ED-LoRA merge) — same CLI and stages as the reference's gradient_fusion.py
+(:750-843): merge token embeddings -> text-encoder Linear layers -> UNet cross-attention K/V -> UNet "spatial"
+attention Linear layers; every layer is one least-squares problem  min_W ||X W^T - Y||^2  started at the
+pretrained weight and solved by L-BFGS, where X are the layer inputs under each concept's LoRA-merged model and Y its
+bias-free outputs.
+
+MI355X-first differences (results equivalent; see mixofshow/utils/lsq.py):
+  * features are never stored: forward hooks (and feature taps on the fused attention projections) stream every
+    (input, output) pair straight into per-layer Gram statistics on the device (mos_gram_accumulate). The reference
+    keeps ~77 GB of fp16 features on the host for 14 concepts and re-uploads them on every closure evaluation.
+  * L-BFGS evaluates loss/gradient from the Gram form in fp64 (mos_lsq_loss_grad_gram).
+
+  python gradient_fusion.py --concept_cfg <json> --save_path <dir> --pretrained_models <diffusers dir | synthetic://..>
+         --optimize_unet_iters 50 --optimize_textenc_iters 500 [--suffix base]
+"""
+import argparse
+import copy
+import itertools
+import json
+import logging
+import os
+
+import mos_path  # noqa: F401
+import torch
+
+from mixofshow.models.edlora import revise_edlora_unet_attention_forward
+from mixofshow.models.schedulers import DPMSolverMultistepScheduler
+from mixofshow.pipelines.pipeline_edlora import StableDiffusionPipeline, bind_concept_prompt
+from mixofshow.utils.convert_edlora_to_diffusers import lora_down_name
+from mixofshow.utils.lsq import GramAccumulator, lbfgs_on_gram, update_quasi_newton  # noqa: F401 (re-exported)
+
+TEMPLATE_SIMPLE = 'photo of a {}'
+NUM_CROSS_ATTENTION_LAYERS = 16
+
+
+def merge_lora_into_weight(original_state_dict, lora_state_dict, modification_layer_names, model_type, alpha, device):
+    """W' = W + alpha * up @ down for the listed weights (reference :99-143)."""
+    assert model_type in ['unet', 'text_encoder']
+    new_sd = copy.copy(original_state_dict)
+    count = 0
+    for k in modification_layer_names:
+        down = lora_down_name(k, model_type)
+        up = down.replace('lora_down', 'lora_up')
+        if up in lora_state_dict:
+            count += 1
+            W = new_sd[k]
+            d, u = lora_state_dict[down].to(device).float(), lora_state_dict[up].to(device).float()
+            delta = (u.squeeze() @ d.squeeze())[..., None, None] if W.dim() == 4 else u @ d
+            new_sd[k] = (W.to(device).float() + alpha * delta).to(W.dtype)
+    logging.info(f'load {count} LoRAs of {model_type}')
+    return new_sd
+
+
+def init_stable_diffusion(pretrained_model_path, device):
+    pipe = StableDiffusionPipeline.from_pretrained(pretrained_model_path, torch_dtype=torch.float16).to(device)
+    pipe.scheduler = DPMSolverMultistepScheduler()
+    return pipe, None, pipe.scheduler
+
+
+@torch.no_grad()
+def get_text_feature(prompts, tokenizer, text_encoder, device, return_type='category_embedding'):
+    if return_type == 'category_embedding':
+        feats = []
+        for text in prompts:
+            tokens = tokenizer(text, truncation=True, max_length=tokenizer.model_max_length, padding='do_not_pad').input_ids
+            ids = torch.tensor(tokens, dtype=torch.long)
+            pos = torch.where(ids >= 49407)[0]          # new tokens AND the end token (reference :197-198)
+            out = text_encoder(ids.reshape(1, -1).to(device))[0][:, pos.to(device)]
+            feats.append(out.reshape(-1, out.shape[-1]))
+        return torch.cat(feats, 0).float()
+    if return_type == 'full_embedding':
+        ids = tokenizer(prompts, padding='max_length', max_length=tokenizer.model_max_length, truncation=True,
+                        return_tensors='pt').input_ids
+        return text_encoder(ids.to(device))[0]
+    raise NotImplementedError
+
+
+def merge_new_concepts_(embedding_list, concept_list, tokenizer, text_encoder):
+    """reference :217-267 — token numbering `<new{start_idx+layer}>` advances by 16 per `<...>` word over ALL concepts."""
+    new_concept_cfg, features = {}, {}
+    start_idx = 0
+    for embedding, concept in zip(embedding_list, concept_list):
+        for concept_name in concept['concept_name'].split(' '):
+            if not concept_name.startswith('<'):
+                continue
+            assert concept_name in embedding, 'check the config, the provide concept name is not in the lora model'
+            names = [f'<new{start_idx + layer}>' for layer in range(NUM_CROSS_ATTENTION_LAYERS)]
+            assert tokenizer.add_tokens(names) == NUM_CROSS_ATTENTION_LAYERS
+            ids = [tokenizer.convert_tokens_to_ids(n) for n in names]
+            text_encoder.resize_token_embeddings(len(tokenizer))
+            table = text_encoder.get_input_embeddings().weight.data
+            table[ids] = embedding[concept_name].to(table.device, table.dtype)
+            features[concept_name] = embedding[concept_name]
+            logging.info(f'concept {concept_name} is bind with token_id: [{min(ids)}, {max(ids)}]')
+            start_idx += NUM_CROSS_ATTENTION_LAYERS
+            new_concept_cfg[concept_name] = {'concept_token_ids': ids, 'concept_token_names': names}
+    return features, new_concept_cfg
+
+
+def parse_new_concepts(concept_cfg):
+    """reference :270-322 — split each checkpoint into embedding / text encoder / UNet cross-KV / UNet other."""
+    with open(concept_cfg, 'r') as f:
+        concept_list = json.load(f)
+    emb, te, kv, spatial = [], [], [], []
+    match = ['attn2.to_k.lora', 'attn2.to_v.lora']
+    for concept in concept_list:
+        model = torch.load(concept['lora_path'], map_location='cpu', weights_only=False)['params']
+        emb.append(model['new_concept_embedding'] if model.get('new_concept_embedding') else None)
+        te.append(model['text_encoder'] if model.get('text_encoder') else None)
+        if model.get('unet'):
+            a = {k: v for k, v in model['unet'].items() if any(x in k for x in match)}
+            b = {k: v for k, v in model['unet'].items() if all(x not in k for x in match)}
+            kv.append(a if a else None)
+            spatial.append(b if b else None)
+        else:
+            kv.append(None)
+            spatial.append(None)
+    return emb, te, kv, spatial, concept_list
+
+
+def _solve_layers(accs, original_state_dict, iters, tag):
+    out = {}
+    for i, (layer_name, acc) in enumerate(accs.items()):
+        W0 = original_state_dict[layer_name].to(torch.float32)
+        logging.info(f'[{i + 1}/{len(accs)}] optimizing {layer_name} ({tag}, n={acc.n})')
+        Wn, loss = lbfgs_on_gram(W0.reshape(W0.shape[0], -1), acc, iters)
+        logging.info('new_concept loss: %e' % loss)
+        out[layer_name] = Wn.reshape(W0.shape)
+    return out
+
+
+def merge_kv_in_cross_attention(concept_list, optimize_iters, new_concept_cfg, tokenizer, text_encoder, unet,
+                                unet_crosskv_list, device):
+    """reference :325-457 — targets are computed analytically: (W + alpha B A) x for the concept-token features."""
+    names = []
+    idx = -1
+    for prefix, block in (('down_blocks.', unet.down_blocks), ('mid_block.', unet.mid_block), ('up_blocks.', unet.up_blocks)):
+        for name, _ in block.named_parameters():
+            if 'attn2.to_k' in name:
+                idx += 1
+                names.append((idx, prefix + name))
+                names.append((idx, prefix + name.replace('to_k', 'to_v')))
+    logging.info(f'Unet have {len(names)} linear layer (related to text feature) need to optimize')
+    sd = unet.state_dict()
+    accs = {}
+    for concept, tuned in zip(concept_list, unet_crosskv_list):
+        prompts = bind_concept_prompt([TEMPLATE_SIMPLE.format(concept['concept_name']), concept['concept_name']],
+                                      new_concept_cfg)
+        n = len(prompts) // 16
+        layer_prompts = [tuple(prompts[j * 16 + i] for j in range(n)) for i in range(16)]
+        for layer_idx, layer_name in names:
+            W = sd[layer_name].float()
+            dn = layer_name.replace('to_k.weight', 'to_k.lora_down.weight').replace('to_v.weight', 'to_v.lora_down.weight')
+            up = dn.replace('lora_down', 'lora_up')
+            merged = W + concept['unet_alpha'] * tuned[up].to(device).float() @ tuned[dn].to(device).float()
+            feat = get_text_feature(list(layer_prompts[layer_idx]), tokenizer, text_encoder, device)
+            if layer_name not in accs:
+                accs[layer_name] = GramAccumulator(W.shape[1], W.shape[0], device)
+            accs[layer_name].add(feat, (merged @ feat.T).T, exact_fp32=True)
+    return _solve_layers(accs, sd, optimize_iters, 'cross-kv')
+
+
+class _Recorder:
+    """Streams (input, bias-free output) of named modules into Gram accumulators (reference get_hooker :150-167)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.accs = {}
+        self.enabled = False
+
+    def record(self, weight_name, module, x, y):
+        if not self.enabled:
+            return
+        if module.bias is not None:
+            b = module.bias[:, None, None] if y.dim() == 4 else module.bias
+            y = y - b.to(y.dtype)
+        if weight_name not in self.accs:
+            self.accs[weight_name] = GramAccumulator(module.weight.shape[1], module.weight.shape[0], self.device)
+        self.accs[weight_name].add(x, y)
+
+
+def merge_text_encoder(concept_list, optimize_iters, new_concept_cfg, tokenizer, text_encoder, text_encoder_list, device):
+    """reference :460-576."""
+    keys = set()
+    for lora in text_encoder_list:
+        keys |= {k.replace('.lora_down', '').replace('.lora_up', '') for k in lora.keys()}
+    layer_names = sorted(keys)
+    logging.info(f'text_encoder have {len(layer_names)} linear layer need to optimize')
+    rec = _Recorder(device)
+    mods = dict(text_encoder.named_modules())
+    handles = []
+    for wname in layer_names:
+        m = mods[wname.replace('.weight', '')]
+        handles.append(m.register_forward_hook(
+            lambda mod, fin, fout, wname=wname: rec.record(wname, mod, fin[0], fout)))
+    original = copy.copy(text_encoder.state_dict())
+    for concept, lora in zip(concept_list, text_encoder_list):
+        merged = merge_lora_into_weight(original, lora, layer_names, 'text_encoder', concept['text_encoder_alpha'], device)
+        text_encoder.load_state_dict(merged)
+        prompts = bind_concept_prompt([TEMPLATE_SIMPLE.format(concept['concept_name']), concept['concept_name']],
+                                      new_concept_cfg)
+        rec.enabled = True
+        get_text_feature(prompts, tokenizer, text_encoder, device)
+        rec.enabled = False
+    for h in handles:
+        h.remove()
+    text_encoder.load_state_dict(original)
+    return _solve_layers({k: rec.accs[k] for k in layer_names}, original, optimize_iters, 'text-encoder')
+
+
+@torch.no_grad()
+def decode_to_latents(concept_prompt, new_concept_cfg, tokenizer, text_encoder, unet, test_scheduler,
+                      num_inference_steps, device, record_nums, batch_size, recorder=None):
+    """reference :579-624 — 20-step DPM-Solver sample at 512x512, no CFG, recording on `record_nums` steps."""
+    prompts = bind_concept_prompt([concept_prompt], new_concept_cfg)
+    emb = get_text_feature(prompts, tokenizer, text_encoder, device, return_type='full_embedding').unsqueeze(0)
+    emb = emb.repeat((batch_size, 1, 1, 1))
+    latents = torch.randn((batch_size, unet.in_channels, 64, 64)).to(device, dtype=emb.dtype)
+    test_scheduler.set_timesteps(num_inference_steps)
+    latents = latents * test_scheduler.init_noise_sigma
+    ts = test_scheduler.timesteps
+    step = ts.size(0) // record_nums
+    record_ts = set(int(t) for t in ts[torch.arange(0, ts.size(0), step=step)[:record_nums]])
+    for t in ts:
+        if recorder is not None:
+            recorder.enabled = int(t) in record_ts
+        noise_pred = unet(test_scheduler.scale_model_input(latents, t), t, encoder_hidden_states=emb).sample
+        latents = test_scheduler.step(noise_pred, t, latents).prev_sample
+    if recorder is not None:
+        recorder.enabled = False
+    return latents, emb
+
+
+def merge_spatial_attention(concept_list, optimize_iters, new_concept_cfg, tokenizer, text_encoder, unet,
+                            unet_spatial_attn_list, test_scheduler, device):
+    """reference :627-747."""
+    keys = set()
+    for lora in unet_spatial_attn_list:
+        keys |= {k.replace('.lora_down', '').replace('.lora_up', '') for k in lora.keys()}
+    layer_names = sorted(keys)
+    logging.info(f'unet have {len(layer_names)} linear layer need to optimize')
+    rec = _Recorder(device)
+    mods = dict(unet.named_modules())
+    by_id, handles, tapped = {}, [], []
+    for wname in layer_names:
+        mname = wname.replace('.weight', '')
+        m = mods[mname]
+        parent = mods[mname.rsplit('.to_', 1)[0]] if '.to_' in mname else None
+        if parent is not None and parent.__class__.__name__ == 'Attention':
+            by_id[id(m)] = wname                     # fused projection: reported through the feature tap
+            if parent not in tapped:
+                tapped.append(parent)
+        else:
+            handles.append(m.register_forward_hook(
+                lambda mod, fin, fout, wname=wname: rec.record(wname, mod, fin[0], fout)))
+
+    def tap(linear, x, y):
+        wname = by_id.get(id(linear))
+        if wname is not None:
+            rec.record(wname, linear, x, y)
+
+    for a in tapped:
+        object.__setattr__(a, '_mos_tap', tap)
+    original = copy.copy(unet.state_dict())
+    revise_edlora_unet_attention_forward(unet)
+    for concept, lora in zip(concept_list, unet_spatial_attn_list):
+        merged = merge_lora_into_weight(original, lora, layer_names, 'unet', concept['unet_alpha'], device)
+        unet.load_state_dict(merged)
+        decode_to_latents(TEMPLATE_SIMPLE.format(concept['concept_name']), new_concept_cfg, tokenizer, text_encoder,
+                          unet, test_scheduler, num_inference_steps=20, device=device, record_nums=20, batch_size=1,
+                          recorder=rec)
+    for h in handles:
+        h.remove()
+    for a in tapped:
+        object.__setattr__(a, '_mos_tap', None)
+    unet.load_state_dict(original)
+    return _solve_layers({k: rec.accs[k] for k in layer_names}, original, optimize_iters, 'spatial')
+
+
+def compose_concepts(concept_cfg, optimize_textenc_iters, optimize_unet_iters, pretrained_model_path, save_path, suffix,
+                     device):
+    logging.info('------Step 1: load stable diffusion checkpoint------')
+    pipe, _, test_scheduler = init_stable_diffusion(pretrained_model_path, device)
+    tokenizer, text_encoder, unet, vae = pipe.tokenizer, pipe.text_encoder, pipe.unet, pipe.vae
+    for p in itertools.chain(text_encoder.parameters(), unet.parameters(), vae.parameters()):
+        p.requires_grad = False
+    logging.info('------Step 2: load new concepts checkpoints------')
+    emb_list, te_list, kv_list, spatial_list, concept_list = parse_new_concepts(concept_cfg)
+    new_concept_cfg = {}
+    if any(x is not None for x in emb_list):
+        logging.info('------Step 3: merge token embedding------')
+        _, new_concept_cfg = merge_new_concepts_(emb_list, concept_list, tokenizer, text_encoder)
+    if any(x is not None for x in te_list):
+        logging.info('------Step 4: merge text encoder------')
+        new_w = merge_text_encoder(concept_list, optimize_textenc_iters, new_concept_cfg, tokenizer, text_encoder,
+                                   te_list, device)
+        sd = text_encoder.state_dict()
+        sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
+        text_encoder.load_state_dict(sd)
+    if any(x is not None for x in kv_list):
+        logging.info('------Step 5: merge kv of cross-attention in unet------')
+        new_w = merge_kv_in_cross_attention(concept_list, optimize_textenc_iters, new_concept_cfg, tokenizer,
+                                            text_encoder, unet, kv_list, device)   # (sic) textenc iters, reference :787
+        sd = unet.state_dict()
+        sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
+        unet.load_state_dict(sd)
+    if any(x is not None for x in spatial_list):
+        logging.info('------Step 6: merge spatial attention (q in cross-attention, qkv in self-attention) in unet------')
+        new_w = merge_spatial_attention(concept_list, optimize_unet_iters, new_concept_cfg, tokenizer, text_encoder,
+                                        unet, spatial_list, test_scheduler, device)
+        sd = unet.state_dict()
+        sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
+        unet.load_state_dict(sd)
+    out = f'{save_path}/combined_model_{suffix}'
+    pipe.save_pretrained(out)
+    with open(os.path.join(out, 'new_concept_cfg.json'), 'w') as f:
+        json.dump(new_concept_cfg, f)
+    return pipe, new_concept_cfg
+
+
+def parse_args():
+    parser = argparse.ArgumentParser('', add_help=False)
+    parser.add_argument('--concept_cfg', help='json file for multi-concept', required=True, type=str)
+    parser.add_argument('--save_path', help='folder name to save optimized weights', required=True, type=str)
+    parser.add_argument('--suffix', help='suffix name', default='base', type=str)
+    parser.add_argument('--pretrained_models', required=True, type=str)
+    parser.add_argument('--optimize_unet_iters', default=50, type=int)
+    parser.add_argument('--optimize_textenc_iters', default=500, type=int)
+    return parser.parse_args()
+
+
+if __name__ == '__main__':
+    args = parse_args()
+    os.makedirs(args.save_path, exist_ok=True)
+    logging.basicConfig(level=logging.INFO, format='%(asctime)s %(levelname)s: %(message)s',
+                        handlers=[logging.StreamHandler(),
+                                  logging.FileHandler(f'{args.save_path}/combined_model_{args.suffix}.log')])
+    logging.info(args)
+    compose_concepts(args.concept_cfg, args.optimize_textenc_iters, args.optimize_unet_iters, args.pretrained_models,
+                     args.save_path, args.suffix, device='cuda')

@@ -43,6 +43,15 @@ typedef enum {
 int mos_version(void);
 const char* mos_last_error_string(void);
 
+/* Optional per-kernel timing (HIP events recorded on the launch stream around every kernel of this library).
+ * mos_profile_begin() clears and enables; mos_profile_end() disables, waits for the recorded events and
+ * returns the number of distinct (kernel, shape) records; mos_profile_get() reads record `idx`:
+ * total milliseconds, number of launches and the summed ALGORITHMIC flops / bytes of those launches. */
+int mos_profile_begin(void);
+int mos_profile_end(void);
+int mos_profile_get(int idx, char* name, int name_cap, double* total_ms, long long* calls,
+                    double* flops, double* bytes);
+
 /* ------------------------------------------------------------------------------------------
  * LoRA-augmented linear: replaces LoRALinearLayer.forward (mixofshow/models/edlora.py:244-246)
  *     y = orig(x) + alpha * lora_up(lora_down(x))

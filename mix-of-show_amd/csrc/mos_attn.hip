@@ -20,6 +20,8 @@
 //     and written in token-major (B, N, H*d) layout with explicit strides.
 //   * grid: blockIdx.x = head + H*(q_block + n_q_blocks*batch): blocks land on XCD (id % 8) = head,
 //     so all query blocks that re-read one head's K/V share one XCD's L2.
+#include <cstdio>
+#include <type_traits>
 #include "mos_common.h"
 
 namespace {
@@ -690,6 +692,20 @@ AttnArgs make_args(const void* q, const void* k, const void* v, void* o, float* 
     return a;
 }
 
+template <typename T>
+const char* tname() { return sizeof(T) == 2 && std::is_same<T, f16_t>::value ? "f16" : "bf16"; }
+
+struct AttnKey {
+    char s[96];
+    double flops, bytes;
+    AttnKey(const char* dt, const mos_attn_shape* sh, double gemms) {
+        snprintf(s, sizeof(s), "%s d%d B%d H%d Nq%d Nkv%d", dt, sh->d, sh->B, sh->H, sh->Nq, sh->Nkv);
+        // one "gemm" = 2*Nq*Nkv*d flops per head; forward has 2 (QK^T, PV), dq pass 3, dk/dv pass 4
+        flops = gemms * 2.0 * sh->B * sh->H * (double)sh->Nq * sh->Nkv * sh->d;
+        bytes = 2.0 * sh->B * sh->H * sh->d * (2.0 * sh->Nq + 2.0 * sh->Nkv);  // q,o + k,v at 2 B/element
+    }
+};
+
 template <typename T, int D>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* tok, int np,
                float* pcols, const mos_attn_shape* s, hipStream_t st) {
@@ -697,6 +713,8 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 4 * QW);
     const dim3 grid((unsigned)(a.H * a.nqb * a.B));
     const size_t lds = fwd_lds<D>(sizeof(T));
+    AttnKey key(tname<T>(), s, 2.0);
+    MosProfScope prof(st, np > 0 ? "attn_fwd_pcols" : "attn_fwd", key.s, key.flops, key.bytes);
     if (np > 0) {
         set_lds(&attn_fwd_kernel<T, D, QW, true>, lds);
         hipLaunchKernelGGL((attn_fwd_kernel<T, D, QW, true>), grid, dim3(256), lds, st, a);
@@ -714,6 +732,17 @@ int launch_region(const void* q, const void* k, const void* v, void* o, const mo
     const dim3 grid((unsigned)(a.H * a.nqb * a.B));
     const size_t lds = fwd_lds<D>(sizeof(T));
     set_lds(&region_attn_kernel<T, D>, lds);
+    // algorithmic work: every query attends to the context OR to its covering regions (box areas)
+    double cover = 0.0, area = 0.0;
+    for (int r = 0; r < reg->n_regions; ++r) {
+        const double bh = reg->box[r][2] - reg->box[r][0], bw = reg->box[r][3] - reg->box[r][1];
+        if (bh > 0 && bw > 0) area += bh * bw;
+    }
+    cover = area + (double)s->Nq;  // upper bound of (query, source) pairs: uncovered queries use the context
+    AttnKey key(tname<T>(), s, 2.0);
+    char rk[128];
+    snprintf(rk, sizeof(rk), "%s R%d", key.s, reg->n_regions);
+    MosProfScope prof(st, "region_attn", rk, key.flops * cover / (double)s->Nq, key.bytes);
     hipLaunchKernelGGL((region_attn_kernel<T, D>), grid, dim3(256), lds, st, a, *reg);
     return mos_check_launch("region_attn");
 }
@@ -744,6 +773,8 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     float* part = Dvec + ((nrows + 3) / 4) * 4;
     {
         const int64_t tot = nrows;
+        AttnKey key(tname<T>(), s, 0.0);
+        MosProfScope prof(st, "attn_bwd_prep", key.s, 2.0 * nrows * D, 4.0 * nrows * D);
         hipLaunchKernelGGL((attn_bwd_prep_kernel<T, D>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
                            (const T*)o, s->o_bs, s->o_rs, (const T*)dO, g->do_bs, g->do_rs, pcols, dpcols, np, Dvec,
                            s->B, s->H, s->Nq);
@@ -763,6 +794,8 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     {
         const dim3 grid((unsigned)(a.H * a.nqb * a.B));
         const size_t lds = dq_lds<D>(sizeof(T));
+        AttnKey key(tname<T>(), s, 3.0);
+        MosProfScope prof(st, "attn_bwd_dq", key.s, key.flops, key.bytes * 1.5);
         if (pc) {
             set_lds(&attn_bwd_dq_kernel<T, D, true>, lds);
             hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), grid, dim3(256), lds, st, a);
@@ -776,6 +809,8 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     {
         const dim3 grid((unsigned)(a.H * a.nkb * a.B), (unsigned)a.nsplit);
         const size_t lds = dkdv_lds<D>(sizeof(T));
+        AttnKey key(tname<T>(), s, 4.0);
+        MosProfScope prof(st, "attn_bwd_dkdv", key.s, key.flops, key.bytes * 1.5);
         if (pc) {
             set_lds(&attn_bwd_dkdv_kernel<T, D, true>, lds);
             hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true>), grid, dim3(256), lds, st, a);

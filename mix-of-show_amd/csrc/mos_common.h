@@ -92,3 +92,13 @@ int mos_check_launch(const char* what);
     do {                                                         \
         if (!(cond)) return mos_set_error(MOS_ERR_BAD_ARG, __VA_ARGS__); \
     } while (0)
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py roofline) ----------------
+// Usage at a launch site:  { MosProfScope p(stream, "kernel_name", "shape key", flops, bytes); launch...; }
+// Disabled (default) it costs one relaxed load. Defined in mos_api.hip.
+struct MosProfScope {
+    MosProfScope(hipStream_t st, const char* kernel, const char* key, double flops, double bytes);
+    ~MosProfScope();
+    int slot;
+    hipStream_t st;
+};

@@ -12,6 +12,8 @@
 //   D: lane l holds D[i = 4*(l>>4) + reg][j = l&15], reg = 0..3.
 // We feed A <- weight rows (n), B <- activation rows (m), so every lane ends up with 4
 // CONSECUTIVE output features of one token: an 8-byte store.
+#include <cstdio>
+#include <type_traits>
 #include "mos_common.h"
 
 namespace {
@@ -296,6 +298,11 @@ template <typename T>
 int launch_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, const void* t, const void* Bp,
                 const float* bias, void* Y, int64_t ldy, int M, int N, int K, hipStream_t st) {
     // BN=64 wastes no columns at N = 320 (5 tiles); BN=128 otherwise halves the X re-reads.
+    char key[96];
+    snprintf(key, sizeof(key), "%s M%d N%d K%d%s", sizeof(T) == 2 && std::is_same<T, f16_t>::value ? "f16" : "bf16", M, N, K,
+             t ? " +lora" : "");
+    MosProfScope prof(st, "gemm_nt", key, 2.0 * M * (double)N * (K + (t ? 16 : 0)),
+                      2.0 * ((double)M * K + (double)N * K + (double)M * N));
     const bool wide = (N % 128 == 0) && ((int64_t)((N + 127) / 128) * ((M + 127) / 128) >= 256);
     if (wide) {
         constexpr int BN = 128;
@@ -320,6 +327,9 @@ int launch_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, const vo
 template <typename T>
 int launch_skinny_nt(const void* X, int64_t ldx, const void* S, void* Tout, int M, int K, hipStream_t st) {
     dim3 grid((M + 255) / 256);
+    char key[64];
+    snprintf(key, sizeof(key), "M%d K%d", M, K);
+    MosProfScope prof(st, "lora_down(skinny_nt)", key, 2.0 * M * 16.0 * K, 2.0 * ((double)M * K + 16.0 * K + 16.0 * M));
     hipLaunchKernelGGL((skinny_nt_kernel<T>), grid, dim3(256), 0, st, (const T*)X, ldx, (const T*)S, (T*)Tout, M, K);
     return mos_check_launch("skinny_nt");
 }
@@ -340,6 +350,9 @@ int launch_skinny_tn(const void* P, const void* Z, int64_t ldz, float* out, floa
     const int rpc = tn_rows_per_chunk(M);
     const int nchunk = (M + rpc - 1) / rpc;
     dim3 grid(nchunk, (C + 63) / 64);
+    char key[64];
+    snprintf(key, sizeof(key), "M%d C%d", M, C);
+    MosProfScope prof(st, "lora_grad(skinny_tn)", key, 2.0 * M * 16.0 * C, 2.0 * ((double)M * C + 16.0 * M));
     hipLaunchKernelGGL((skinny_tn_kernel<T, NJ>), grid, dim3(256), 0, st, (const T*)P, (const T*)Z, ldz, partial, M, C,
                        rpc);
     int rc = mos_check_launch("skinny_tn");

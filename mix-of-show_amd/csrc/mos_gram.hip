@@ -10,6 +10,7 @@
 // Gram kernel: out[(Cout+Cin), Cin] = [Y | X]^T X.  The contraction index (sample n) is the slow
 // index of both operands, so 64-sample tiles are transposed into LDS ([column][n], packed pairs,
 // conflict-free ds_write_b32) and consumed as K-contiguous MFMA operands (32x32x16, ds_read_b128).
+#include <cstdio>
 #include "mos_common.h"
 
 namespace {
@@ -234,6 +235,9 @@ int mos_gram_accumulate(const void* X, int64_t ldx, const void* Y, int64_t ldy, 
     const int nYb = (Cout + GT - 1) / GT, nXb = (Cin + GT - 1) / GT;
     const int Rtot = (nYb + nXb) * GT;
     dim3 grid(nXb, nYb + nXb, nchunk);
+    char key[96];
+    snprintf(key, sizeof(key), "n%lld Cin%d Cout%d", (long long)n, Cin, Cout);
+    MosProfScope prof(st, "gram", key, 2.0 * (double)n * Cin * ((double)Cin + Cout), 2.0 * (double)n * ((double)Cin + Cout));
     if (dtype == MOS_F16)
         hipLaunchKernelGGL((gram_kernel<f16_t>), grid, dim3(256), 0, st, (const f16_t*)X, ldx, (const f16_t*)Y, ldy, n,
                            Cin, Cout, rpc, (float*)ws, c);
@@ -261,6 +265,9 @@ int mos_lsq_loss_grad_gram(const double* W, const double* G, const double* P, co
     hipStream_t st = (hipStream_t)stream;
     const double inv = 1.0 / n_times_cout;
     dim3 grid((Cin + 63) / 64, (Cout + 63) / 64);
+    char key[64];
+    snprintf(key, sizeof(key), "Cout%d Cin%d", Cout, Cin);
+    MosProfScope prof(st, "lsq_loss_grad", key, 2.0 * Cout * (double)Cin * Cin, 8.0 * (3.0 * Cout * Cin + (double)Cin * Cin));
     hipLaunchKernelGGL(lsq_grad_kernel, grid, dim3(256), 0, st, W, G, P, inv, Cout, Cin, grad, (double*)ws);
     int rc = mos_check_launch("lsq_grad");
     if (rc) return rc;

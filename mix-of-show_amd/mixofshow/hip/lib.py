@@ -74,6 +74,11 @@ _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_
 SIGNATURES = {
     'mos_version': (_i, []),
     'mos_last_error_string': (ctypes.c_char_p, []),
+    'mos_profile_begin': (_i, []),
+    'mos_profile_end': (_i, []),
+    'mos_profile_get': (_i, [_i, ctypes.c_char_p, _i, ctypes.POINTER(ctypes.c_double),
+                             ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double),
+                             ctypes.POINTER(ctypes.c_double)]),
     'mos_lora_pack': (_i, [ctypes.POINTER(LoraSites), _i, _vp, _vp, _vp, _vp, _vp]),
     'mos_lora_down': (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
     'mos_lora_linear_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),

@@ -106,7 +106,17 @@ def project(attn, name, linears, x, cd):
     b32 = attn._mos_cache.bias(name, [l.bias for l in linears])
     sites = _sites(*linears)
     assert sites is not None
-    return F_hip.lora_linear(x, W16, Wt16, b32, sites)
+    y = F_hip.lora_linear(x, W16, Wt16, b32, sites)
+    tap = getattr(attn, '_mos_tap', None)
+    if tap is not None:
+        # feature tap (gradient fusion): the fused GEMM bypasses nn.Linear.__call__, so forward hooks on
+        # to_q/to_k/to_v/to_out.0 would never fire — report (module, input, output) per projection instead
+        off = 0
+        for l in linears:
+            n = l.weight.shape[0]
+            tap(l, x, y[..., off:off + n])
+            off += n
+    return y
 
 
 def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_idx=None, region=None):
