@@ -35,6 +35,13 @@ FINETUNE_CFG = dict(
 TRAIN_OPT = dict(optim_g=dict(type='AdamW', lr=0.0, weight_decay=0.01, betas=[0.9, 0.999]), emb_norm_threshold=0.55)
 
 
+_T0 = time.time()
+
+
+def _log(msg):
+    print(f'[bench +{time.time() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
 def _sync_barrier(world):
     if world > 1:
         torch.distributed.barrier()
@@ -90,6 +97,7 @@ def cpu_baseline_train(trainer, size, budget_s=40.0):
     """Oracle path (plain torch fp32, full (B*H,N,77) maps, 3 launches per LoRA site) on the host cores, B=1."""
     from oracle import trainer_ref
     torch.set_num_threads(max(1, os.cpu_count() or 1))
+    _log('cpu_baseline: building the oracle twin on the host')
     twin = trainer_ref.make_reference_twin(trainer, device='cpu', dtype=torch.float32)
     b = synthetic_batch(1, size, 'cpu', 123)
     params = trainer_ref.twin_parameters(twin)
@@ -102,7 +110,8 @@ def cpu_baseline_train(trainer, size, budget_s=40.0):
         loss = trainer_ref.reference_forward(twin, b['images'], b['prompts'], b['masks'], b['img_masks'])
         loss.backward()
         times.append(time.time() - t0)
-        if time.time() - t_all > budget_s:
+        _log(f'cpu_baseline: step {i} took {times[-1]:.2f}s')
+        if time.time() - t_all + times[-1] > budget_s:   # bounded sample: stop before the next step would overrun
             break
     best = min(times[1:]) if len(times) > 1 else times[0]
     return dict(value=round(1.0 / best, 5), unit='images/s', cores=torch.get_num_threads(), kind='port',
@@ -114,7 +123,9 @@ def run_train(args, rank, world, device):
     from mixofshow.hip import profiler
     from mixofshow.pipelines.train_loop import TrainEngine
     B, size = args.batch, args.size
+    _log(f'building EDLoRATrainer (synthetic://{args.preset}) on {device}')
     trainer = build_trainer(args.preset, device)
+    _log('trainer ready')
     trainer.unet.train()
     trainer.text_encoder.train()
     engine = TrainEngine(trainer, dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g'])), total_iter=1e9,
@@ -122,12 +133,15 @@ def run_train(args, rank, world, device):
     batches = [synthetic_batch(B, size, device, 1000 * rank + i) for i in range(2)]
     for i in range(args.warmup):
         engine.step(batches[i % 2])
+        torch.cuda.synchronize()
+        _log(f'warmup step {i} done')
     _sync_barrier(world)
     t0 = time.perf_counter()
     for i in range(args.steps):
         engine.step(batches[i % 2])
     _sync_barrier(world)
     dt = _max_over_ranks(time.perf_counter() - t0, world, device)
+    _log(f'timed region: {args.steps} steps in {dt:.3f}s')
     # profiled pass (same workload, same process): per-kernel HIP-event timings of the library kernels
     recs = []
     with profiler.profile(recs):

@@ -97,7 +97,15 @@ def load_unet(path):
 def load_text_encoder(path):
     preset, seed = parse_synthetic(path)
     if preset is not None:
-        return _seeded(seed + 1, lambda: CLIPTextModel(**PRESETS[preset]['clip']))
+        def make():
+            m = CLIPTextModel(**PRESETS[preset]['clip'])
+            with torch.no_grad():
+                # real CLIP token embeddings have row norms ~0.4 (the emb_norm_threshold 0.55 of the YAMLs assumes
+                # that scale); nn.Embedding's N(0,1) init would give norms ~27 and freeze the concept rows at step 1
+                m.text_model.embeddings.token_embedding.weight.mul_(0.014)
+                m.text_model.embeddings.position_embedding.weight.mul_(0.014)
+            return m
+        return _seeded(seed + 1, make)
     m = CLIPTextModel()
     m.load_state_dict(remap_text_encoder_keys(_load_state(os.path.join(path, 'text_encoder'))))
     return m

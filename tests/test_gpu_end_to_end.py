@@ -46,28 +46,70 @@ def test_graft_smoke():
     g.smoke()
 
 
-@pytest.mark.parametrize('steps', [50])
-def test_edlora_pipeline_denoised_latents_vs_reference_path(steps):
+class _Fp32Layer:
+    """Yardstick: the oracle processor evaluated in fp32 on an fp32 copy of the layer (same fp16-valued weights and
+    inputs), output rounded once — i.e. the exact attention layer. Both the HIP path and the reference's fp16 path
+    are measured against it: the HIP path must be at least as close as the reference path is."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.copy = None
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, **kw):
+        if self.copy is None:
+            proc, attn.processor = attn.processor, None
+            self.copy = copy.deepcopy(attn).float()
+            attn.processor = proc
+        kw = dict(kw)
+        if 'region_list' in kw:
+            kw['region_list'] = [(r[0].float(), r[1]) for r in kw['region_list']]
+        ehs = encoder_hidden_states.float() if encoder_hidden_states is not None else None
+        return self.inner(self.copy, hidden_states.float(), encoder_hidden_states=ehs, **kw).to(hidden_states.dtype)
+
+
+def _three_way(name, run, install_ref, install_fp32):
+    out = run()
+    install_ref()
+    ref16 = run()
+    install_fp32()
+    truth = run()
+    scale = max(1.0, truth.float().abs().max().item())
+    e_hip = (out.float() - truth.float()).abs().max().item()
+    e_ref = (ref16.float() - truth.float()).abs().max().item()
+    e_pair = (out.float() - ref16.float()).abs().max().item()
+    print(f'[parity] {name}: |hip-exact|={e_hip:.3e} |ref_fp16-exact|={e_ref:.3e} |hip-ref_fp16|={e_pair:.3e} '
+          f'latents_absmax={scale:.3f} rel(hip-exact)={e_hip / scale:.3e} rel(ref-exact)={e_ref / scale:.3e}')
+    assert torch.isfinite(out).all()
+    # the HIP path must sit inside the reference path's own fp16 noise band around the exact result
+    assert e_hip <= max(1.5 * e_ref, 1e-3 * scale), f'{name}: hip error {e_hip:.3e} vs reference-path error {e_ref:.3e}'
+
+
+def test_edlora_pipeline_denoised_latents_vs_reference_path():
     from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline
     from oracle import edlora_ref as R
     pipe = EDLoRAPipeline.from_pretrained('synthetic://small?seed=0', torch_dtype=torch.float16).to(DEV)
     cfg = _concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>'])
     pipe.set_new_concept_cfg(cfg)
     latents = torch.randn((1, 4, 64, 64), generator=torch.manual_seed(1))     # PromptDataset recipe, index 1
-    kw = dict(prompt='a <potter1> <potter2> in the park', height=512, width=512, num_inference_steps=steps,
+    kw = dict(prompt='a <potter1> <potter2> in the park', height=512, width=512, num_inference_steps=50,
               guidance_scale=7.5, output_type='latent')
-    out = pipe(latents=latents.clone(), **kw).images
-    # same modules, oracle attention path
-    for m in pipe.unet.modules():
-        if m.__class__.__name__ == 'Attention':
-            m.set_processor(R.PlainAttnProcessorRef())
-    R.install_ref_processors(pipe.unet)
-    ref = pipe(latents=latents.clone(), **kw).images
-    _latent_report(f'edlora_sample_{steps}steps', out, ref)
+
+    def install_ref():
+        for m in pipe.unet.modules():
+            if m.__class__.__name__ == 'Attention':
+                m.set_processor(R.PlainAttnProcessorRef())
+        R.install_ref_processors(pipe.unet)
+
+    def install_fp32():
+        for m in pipe.unet.modules():
+            if m.__class__.__name__ == 'Attention':
+                m.set_processor(_Fp32Layer(m.processor))
+
+    _three_way('edlora_sample_50steps', lambda: pipe(latents=latents.clone(), **kw).images, install_ref, install_fp32)
 
 
 def test_regional_pipeline_denoised_latents_vs_reference_path():
-    from bench import REGION_PX, regional_prompt
+    from bench import regional_prompt
     from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionallyT2IAdapterPipeline
     from oracle import region_ref
     H, W = 512, 768
@@ -75,18 +117,21 @@ def test_regional_pipeline_denoised_latents_vs_reference_path():
     cfg = _concept_cfg(pipe.tokenizer, pipe.text_encoder,
                        ['<potter1>', '<potter2>', '<hermione1>', '<hermione2>', '<thanos1>', '<thanos2>'])
     pipe.set_new_concept_cfg(cfg)
-    prompt, neg = regional_prompt(H, W)
-    # add an overlapping 4th region so the count-normalisation path is exercised
-    prompt[0][1].append(('a castle', neg, [100 / H, 150 / W, 400 / H, 300 / W]))
     latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14))
-    kw = dict(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50, guidance_scale=7.5,
-              output_type='latent')
-    out = pipe(latents=latents.clone(), **kw).images
-    region_ref.install_region_processors_ref(pipe.unet)
-    prompt2, _ = regional_prompt(H, W)
-    prompt2[0][1].append(('a castle', neg, [100 / H, 150 / W, 400 / H, 300 / W]))
-    ref = pipe(latents=latents.clone(), **dict(kw, prompt=prompt2)).images
-    _latent_report('regional_sample_50steps', out, ref)
+
+    def run():
+        prompt, neg = regional_prompt(H, W)
+        # an overlapping 4th region exercises the count normalisation
+        prompt[0][1].append(('a castle', neg, [100 / H, 150 / W, 400 / H, 300 / W]))
+        return pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50, guidance_scale=7.5,
+                    latents=latents.clone(), output_type='latent').images
+
+    def install_fp32():
+        for m in pipe.unet.modules():
+            if m.__class__.__name__ == 'Attention':
+                m.set_processor(_Fp32Layer(m.processor))
+
+    _three_way('regional_sample_50steps', run, lambda: region_ref.install_region_processors_ref(pipe.unet), install_fp32)
 
 
 def test_training_steps_match_reference_path_and_engine_runs():
@@ -134,7 +179,7 @@ def test_training_steps_match_reference_path_and_engine_runs():
     rel = (num / den)**0.5
     print(f'[parity] parameters after 3 AdamW steps: rel_l2_diff={rel:.3e}')
     assert rel < 2e-3
-    assert engine.global_step == 3 and not bool(engine.stop_flag)
+    assert engine.global_step == 3 and not bool(engine.stop_flag)   # synthetic CLIP rows have real-CLIP-like norms
 
 
 def test_update_quasi_newton_vs_reference_golden(golden):
@@ -202,5 +247,5 @@ def test_fusion_reduces_layer_loss_on_real_features():
     Wr = fusion_ref.update_quasi_newton_ref(X.float(), Y.float(), W0.clone(), 50)
     lr = fusion_ref.lsq_loss_ref(X.double(), Y.double(), Wr.double()).item()
     print(f'[parity] spatial-layer LSQ: loss0={l0:.4e} hip(gram,fp64)={direct:.6e} gram_loss={loss:.6e} oracle(fp32 direct)={lr:.6e}')
-    assert abs(direct - loss) <= 1e-6 * direct + 1e-12
-    assert direct < 0.2 * l0 and direct <= lr * (1 + 5e-2)
+    # `loss` is the Gram-form value at the fp64 iterate; `direct` re-evaluates the fp32-rounded W the API returns
+    assert loss <= direct * (1 + 1e-6) and direct < 1e-3 * l0 and direct <= lr * (1 + 5e-2)
