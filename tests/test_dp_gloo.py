@@ -1,0 +1,86 @@
+"""Data-parallel path on CPU: 2 processes, gloo backend, HIP primitives emulated by the oracle (tests only).
+Checks that one all-reduce of the flat LoRA + concept-row bucket reproduces the single-process average of the
+per-rank gradients (what the reference's DDP computes) and that the ranks stay in lock-step after AdamW."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup_emulation():
+    sys.path.insert(0, ROOT)
+    import mos_path  # noqa: F401
+    import mixofshow.hip.ops as ops
+    from oracle import emu_ops
+    for name in emu_ops.EMULATED:
+        setattr(ops, name, getattr(emu_ops, name))
+
+
+def _make_engine():
+    from tests.test_host_cpu import _trainer
+    from mixofshow.pipelines.train_loop import TrainEngine
+    tr = _trainer()
+    opt = dict(optim_g=dict(type='AdamW', lr=0.0, weight_decay=0.01, betas=[0.9, 0.999]), emb_norm_threshold=0.55)
+    return tr, TrainEngine(tr, opt, total_iter=10, mixed_precision='no')
+
+
+def _rank_batch(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    masks = torch.zeros(1, 1, 16, 16)
+    masks[:, :, 4:12, 3:11] = 1
+    return dict(images=None, prompts=['a <potter1> <potter2> in the park'], masks=masks,
+                img_masks=torch.ones_like(masks), latents=torch.randn(1, 4, 16, 16, generator=g),
+                noise=torch.randn(1, 4, 16, 16, generator=g), timesteps=torch.randint(0, 1000, (1, ), generator=g))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    _setup_emulation()
+    from mixofshow.parallel import dp
+    dp.init_distributed(backend='gloo')
+    tr, engine = _make_engine()
+    # gradient of this rank's batch, reduced
+    engine.bucket.zero()
+    loss = tr(**_rank_batch(rank))
+    loss.backward()
+    local = engine.bucket.flat.clone()
+    engine.bucket.allreduce_mean()
+    reduced = engine.bucket.flat.clone()
+    # then one full engine step (forward, backward, all-reduce, AdamW, norm rule)
+    out = engine.step(_rank_batch(rank))
+    logged = dp.reduce_loss_dict(out)
+    params = torch.cat([p.detach().reshape(-1) for p in tr.trainable_parameters()])
+    torch.save(dict(local=local, reduced=reduced, params=params, loss=float(logged['loss']),
+                    nbytes=engine.bucket.nbytes), os.path.join(out_dir, f'rank{rank}.pt'))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_allreduce_matches_single_process_average(tmp_path):
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / 'rank0.pt')
+    r1 = torch.load(tmp_path / 'rank1.pt')
+    # bucket holds exactly concept rows + LoRA factors (tiny preset: 32x64 + 2*36 LoRA tensors), nothing else
+    assert r0['nbytes'] == r1['nbytes'] and r0['local'].numel() == r0['nbytes'] // 4
+    assert not torch.equal(r0['local'], r1['local'])                       # ranks saw different data
+    torch.testing.assert_close(r0['reduced'], r1['reduced'], rtol=0, atol=0)  # identical after the collective
+    torch.testing.assert_close(r0['reduced'], (r0['local'] + r1['local']) / 2, rtol=0, atol=1e-9)
+    torch.testing.assert_close(r0['params'], r1['params'], rtol=0, atol=0)    # lock-step after AdamW
+    assert abs(r0['loss'] - r1['loss']) < 1e-12                               # reduce_loss_dict averaged
+    # single-process reference: same two batches, gradients averaged by hand
+    _setup_emulation()
+    tr, engine = _make_engine()
+    grads = []
+    for rank in range(world):
+        engine.bucket.zero()
+        tr(**_rank_batch(rank)).backward()
+        grads.append(engine.bucket.flat.clone())
+    torch.testing.assert_close(r0['reduced'], (grads[0] + grads[1]) / 2, rtol=1e-5, atol=1e-8)
