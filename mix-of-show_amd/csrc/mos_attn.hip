@@ -43,6 +43,9 @@ struct HD {
     static constexpr int TR_TILE_ELEMS = DV * TS;
 };
 
+// dK/dV kernel: 4 staged tiles (Q, dO, Q^T, dO^T); double buffering fits the 160 KB LDS up to d = 80
+template <int D> struct DKDV_NBUF { static constexpr int value = D <= 80 ? 2 : 1; };
+
 struct AttnArgs {
     const void* q; const void* k; const void* v; void* o;
     float* lse; const int32_t* tok_idx; float* pcols; int n_pcols;
@@ -131,11 +134,71 @@ __device__ __forceinline__ typename MT<T>::v8 tr_afrag(const T* ldsT_row, int t,
 }
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
+// ---- split staging (issue global loads early, write LDS late: the loads fly under the MFMAs) --------
+// Loads are UNCONDITIONAL (addresses clamped into the tile) and the zero fill of out-of-range rows happens at
+// store time: a `cond ? load : 0` select makes hipcc branch around the load and wait vmcnt(0) right after it,
+// which serialises the prefetch behind the MFMAs it is supposed to overlap (cdna guide, ".s-level traps" (c)).
+template <typename T, int D>
+struct RowStage {
+    static constexpr int DCH = HD<D>::DCH, RS = HD<D>::RS;
+    static constexpr int N = (KV_TILE * DCH + 255) / 256;
+    u32x4 r[N];
+    int nv;
+    __device__ __forceinline__ void load(const T* g, int64_t rs, int nvalid, int tid) {
+        nv = nvalid;  // >= 1
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = min(tid + 256 * i, KV_TILE * DCH - 1);
+            const int row = c / DCH, cc = c - row * DCH;
+            r[i] = ld16(g + (int64_t)min(row, nvalid - 1) * rs + cc * 8);
+        }
+    }
+    __device__ __forceinline__ void store(T* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c / DCH, cc = c - row * DCH;
+            if (c < KV_TILE * DCH) st16(lds + row * RS + cc * 8, row < nv ? r[i] : u32x4{0, 0, 0, 0});
+        }
+    }
+};
+template <typename T, int D>
+struct TrStage {
+    static constexpr int DCH = HD<D>::DCH;
+    static constexpr int N = (32 * DCH + 255) / 256;
+    u32x4 r0[N], r1[N];
+    int nv;
+    __device__ __forceinline__ void load(const T* g, int64_t rs, int nvalid, int tid) {
+        nv = nvalid;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int it = min(tid + 256 * i, 32 * DCH - 1);
+            const int p = it & 31, cc = it >> 5;
+            r0[i] = ld16(g + (int64_t)min(2 * p, nvalid - 1) * rs + cc * 8);
+            r1[i] = ld16(g + (int64_t)min(2 * p + 1, nvalid - 1) * rs + cc * 8);
+        }
+    }
+    __device__ __forceinline__ void store(T* ldsT, int tid) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int it = tid + 256 * i;
+            const int p = it & 31, cc = it >> 5;
+            if (it < 32 * DCH) {
+                const uint32_t m0 = (2 * p < nv) ? 0xffffu : 0u, m1 = (2 * p + 1 < nv) ? 0xffff0000u : 0u;
+                uint32_t* dst = reinterpret_cast<uint32_t*>(ldsT + (cc * 8) * TS + 2 * p);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    dst[e * (TS / 2)] = (half_of(r0[i], e) & m0) | ((half_of(r1[i], e) << 16) & m1);
+            }
+        }
+    }
+};
+
 // ---- one attention pass of a wave's NQ x 32 queries over all keys of one source ----------------
 // Returns unnormalised O^T accumulators, running max m (raw score units) and PER-LANE partial sums l.
 template <typename T, int D, int NQ, bool PCOLS>
 __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vbase, int64_t v_rs, int Nkv,
-                                       float c /* scale*log2e */, T* Ks, T* Vt,
+                                       float c /* scale*log2e */, T* Ks_, T* Vt_,
                                        const typename MT<T>::v8 (&qf)[NQ][HD<D>::KS],
                                        f32x16 (&o)[NQ][HD<D>::DT], float (&m)[NQ], float (&l)[NQ],
                                        const int (&tok)[MOS_MAX_PCOLS], int n_pcols,
@@ -150,11 +213,25 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[iq][dt][r] = 0.f;
     }
-    for (int kv0 = 0; kv0 < Nkv; kv0 += KV_TILE) {
-        __syncthreads();  // all waves finished reading the previous tile
-        stage_rows<T, D>(Ks, kbase + (int64_t)kv0 * k_rs, k_rs, Nkv - kv0, tid);
-        stage_transposed<T, D>(Vt, vbase + (int64_t)kv0 * v_rs, v_rs, Nkv - kv0, tid);
-        __syncthreads();
+    // Double-buffered LDS tiles (Ks/Vt hold 2 tiles each) + register prefetch: the global loads of tile i+1 are
+    // issued before the MFMAs of tile i and written to the other buffer after them; ONE barrier per tile.
+    RowStage<T, D> kst;
+    TrStage<T, D> vst;
+    __syncthreads();  // earlier users of the LDS buffers (previous source / prologue zeroing) are done
+    kst.load(kbase, k_rs, Nkv, tid);
+    vst.load(vbase, v_rs, Nkv, tid);
+    kst.store(Ks_, tid);
+    vst.store(Vt_, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int kv0 = 0; kv0 < Nkv; kv0 += KV_TILE, cur ^= 1) {
+        const T* Ks = Ks_ + cur * HD<D>::ROW_TILE_ELEMS;
+        const T* Vt = Vt_ + cur * HD<D>::TR_TILE_ELEMS;
+        const bool more = kv0 + KV_TILE < Nkv;
+        if (more) {
+            kst.load(kbase + (int64_t)(kv0 + KV_TILE) * k_rs, k_rs, Nkv - kv0 - KV_TILE, tid);
+            vst.load(vbase + (int64_t)(kv0 + KV_TILE) * v_rs, v_rs, Nkv - kv0 - KV_TILE, tid);
+        }
 
         f32x16 s[NQ][2];
 #pragma unroll
@@ -212,10 +289,12 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
                     ls += p;
                 }
             l[iq] = l[iq] * alpha + ls;
+            if (__any(alpha != 1.0f)) {  // wave-uniform: once the running max has settled no lane rescales
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[iq][dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[iq][dt][r] *= alpha;
+            }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -233,6 +312,11 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
                     for (int iq = 0; iq < NQ; ++iq) o[iq][dt] = MT<T>::mfma32(a, pf[iq][t][s2], o[iq][dt]);
                 }
         }
+        if (more) {
+            kst.store(Ks_ + (cur ^ 1) * HD<D>::ROW_TILE_ELEMS, tid);
+            vst.store(Vt_ + (cur ^ 1) * HD<D>::TR_TILE_ELEMS, tid);
+        }
+        __syncthreads();  // tile i+1 visible; every wave is done reading tile i before it is overwritten next round
     }
 }
 
@@ -252,20 +336,20 @@ __device__ __forceinline__ void store_out_rows(T* orow, bool valid, const f32x16
 
 // ---- forward -----------------------------------------------------------------------------------
 template <typename T, int D, int QW, bool PCOLS>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_fwd_kernel(AttnArgs a) {
     typedef typename MT<T>::v8 v8;
     constexpr int NQ = QW / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Ks = reinterpret_cast<T*>(smem_raw);
-    T* Vt = Ks + HD<D>::ROW_TILE_ELEMS;
+    T* Vt = Ks + 2 * HD<D>::ROW_TILE_ELEMS;  // [2] K tiles, then [2] V^T tiles (double buffered)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int h = blockIdx.x % a.H;
     const int rest = blockIdx.x / a.H;
     const int qb = rest % a.nqb, b = rest / a.nqb;
     const int q0 = qb * (4 * QW) + wave * QW;
 
-    zero_row_pads<T, D>(Ks, tid);
-    zero_tr_pads<T, D>(Vt, tid);
+    zero_row_pads<T, D>(Ks, tid); zero_row_pads<T, D>(Ks + HD<D>::ROW_TILE_ELEMS, tid);
+    zero_tr_pads<T, D>(Vt, tid); zero_tr_pads<T, D>(Vt + HD<D>::TR_TILE_ELEMS, tid);
 
     const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
     const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * D;
@@ -321,15 +405,15 @@ __global__ __launch_bounds__(256) void region_attn_kernel(AttnArgs a, mos_region
     constexpr int DT = HD<D>::DT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* Ks = reinterpret_cast<T*>(smem_raw);
-    T* Vt = Ks + HD<D>::ROW_TILE_ELEMS;
+    T* Vt = Ks + 2 * HD<D>::ROW_TILE_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int h = blockIdx.x % a.H;
     const int rest = blockIdx.x / a.H;
     const int qb = rest % a.nqb, b = rest / a.nqb;
     const int qi = qb * 128 + wave * 32 + l31;
 
-    zero_row_pads<T, D>(Ks, tid);
-    zero_tr_pads<T, D>(Vt, tid);
+    zero_row_pads<T, D>(Ks, tid); zero_row_pads<T, D>(Ks + HD<D>::ROW_TILE_ELEMS, tid);
+    zero_tr_pads<T, D>(Vt, tid); zero_tr_pads<T, D>(Vt + HD<D>::TR_TILE_ELEMS, tid);
 
     const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
     T* op = (T*)a.o + (int64_t)b * a.o_bs + h * D;
@@ -407,13 +491,14 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, int64_t o_bs, int6
 // ---- backward dQ: one wave = 32 queries, loop over key tiles -----------------------------------------
 //   S^T = K Q^T ; P^T = exp(scale*S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - D) ; dQ^T += K^T dS^T
 template <typename T, int D, bool PCOLS>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Ks = reinterpret_cast<T*>(smem_raw);
-    T* Vs = Ks + HD<D>::ROW_TILE_ELEMS;
-    T* Kt = Vs + HD<D>::ROW_TILE_ELEMS;
+    constexpr int RT = HD<D>::ROW_TILE_ELEMS, TT = HD<D>::TR_TILE_ELEMS;
+    T* Ks_ = reinterpret_cast<T*>(smem_raw);   // double buffered: [2] K rows, [2] V rows, [2] K^T
+    T* Vs_ = Ks_ + 2 * RT;
+    T* Kt_ = Vs_ + 2 * RT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int h = blockIdx.x % a.H;
     const int rest = blockIdx.x / a.H;
@@ -422,9 +507,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     const bool qvalid = qi < a.Nq;
     const int qc = min(qi, a.Nq - 1);
 
-    zero_row_pads<T, D>(Ks, tid);
-    zero_row_pads<T, D>(Vs, tid);
-    zero_tr_pads<T, D>(Kt, tid);
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {
+        zero_row_pads<T, D>(Ks_ + bf * RT, tid);
+        zero_row_pads<T, D>(Vs_ + bf * RT, tid);
+        zero_tr_pads<T, D>(Kt_ + bf * TT, tid);
+    }
 
     const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * D;
     const T* vp = (const T*)a.v + (int64_t)b * a.v_bs + h * D;
@@ -451,12 +539,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-    for (int kv0 = 0; kv0 < a.Nkv; kv0 += KV_TILE) {
-        __syncthreads();
-        stage_rows<T, D>(Ks, kp + (int64_t)kv0 * a.k_rs, a.k_rs, a.Nkv - kv0, tid);
-        stage_rows<T, D>(Vs, vp + (int64_t)kv0 * a.v_rs, a.v_rs, a.Nkv - kv0, tid);
-        stage_transposed<T, D>(Kt, kp + (int64_t)kv0 * a.k_rs, a.k_rs, a.Nkv - kv0, tid);
-        __syncthreads();
+    RowStage<T, D> kst, vst;
+    TrStage<T, D> ktst;
+    __syncthreads();
+    kst.load(kp, a.k_rs, a.Nkv, tid);
+    vst.load(vp, a.v_rs, a.Nkv, tid);
+    ktst.load(kp, a.k_rs, a.Nkv, tid);
+    kst.store(Ks_, tid);
+    vst.store(Vs_, tid);
+    ktst.store(Kt_, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int kv0 = 0; kv0 < a.Nkv; kv0 += KV_TILE, cur ^= 1) {
+        const T* Ks = Ks_ + cur * RT;
+        const T* Vs = Vs_ + cur * RT;
+        const T* Kt = Kt_ + cur * TT;
+        const bool more = kv0 + KV_TILE < a.Nkv;
+        if (more) {  // prefetch the next key tile into registers; written to the other LDS buffer after the MFMAs
+            const int nx = kv0 + KV_TILE;
+            kst.load(kp + (int64_t)nx * a.k_rs, a.k_rs, a.Nkv - nx, tid);
+            vst.load(vp + (int64_t)nx * a.v_rs, a.v_rs, a.Nkv - nx, tid);
+            ktst.load(kp + (int64_t)nx * a.k_rs, a.k_rs, a.Nkv - nx, tid);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 s, dp;
@@ -490,6 +594,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
                 for (int s2 = 0; s2 < 2; ++s2) dq[dt] = MT<T>::mfma32(tr_afrag<T>(krow, t, s2, hh), dsf[s2], dq[dt]);
             }
         }
+        if (more) {
+            kst.store(Ks_ + (cur ^ 1) * RT, tid);
+            vst.store(Vs_ + (cur ^ 1) * RT, tid);
+            ktst.store(Kt_ + (cur ^ 1) * TT, tid);
+        }
+        __syncthreads();
     }
     T* dqp = (T*)a.dq + (int64_t)b * a.dq_bs + (int64_t)qi * a.dq_rs + h * D;
     store_out_rows<T, D>(dqp, qvalid, dq, a.scale, hh);
@@ -498,17 +608,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 // ---- backward dK/dV: one wave = 32 keys, loop over query tiles of this split ------------------------
 //   S = Q K^T ; P = exp(scale*S - lse) ; dV^T += dO^T P ; dP = dO V^T ; dS = P o (dP - D) ; dK^T += Q^T dS
 template <typename T, int D, bool PCOLS>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Qs = reinterpret_cast<T*>(smem_raw);
-    T* dOs = Qs + HD<D>::ROW_TILE_ELEMS;
-    T* Qt = dOs + HD<D>::ROW_TILE_ELEMS;
-    T* dOt = Qt + HD<D>::TR_TILE_ELEMS;
-    float* lse_s = reinterpret_cast<float*>(dOt + HD<D>::TR_TILE_ELEMS);  // [64] (already * log2e)
-    float* D_s = lse_s + KV_TILE;                                          // [64]
-    float* dpc_s = D_s + KV_TILE;                                          // [64][4]
+    constexpr int RT = HD<D>::ROW_TILE_ELEMS, TT = HD<D>::TR_TILE_ELEMS;
+    constexpr int NB = DKDV_NBUF<D>::value;    // 2 = double buffered (fits in 160 KB for d <= 80), 1 = single
+    constexpr int ST = KV_TILE * (2 + MOS_MAX_PCOLS);   // floats per stats buffer: lse[64], D[64], dpc[64][4]
+    T* Qs_ = reinterpret_cast<T*>(smem_raw);
+    T* dOs_ = Qs_ + NB * RT;
+    T* Qt_ = dOs_ + NB * RT;
+    T* dOt_ = Qt_ + NB * TT;
+    float* stat_ = reinterpret_cast<float*>(dOt_ + NB * TT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int h = blockIdx.x % a.H;
     const int rest = blockIdx.x / a.H;
@@ -518,10 +629,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
     const bool kvalid = kvi < a.Nkv;
     const int kc = min(kvi, a.Nkv - 1);
 
-    zero_row_pads<T, D>(Qs, tid);
-    zero_row_pads<T, D>(dOs, tid);
-    zero_tr_pads<T, D>(Qt, tid);
-    zero_tr_pads<T, D>(dOt, tid);
+#pragma unroll
+    for (int bf = 0; bf < NB; ++bf) {
+        zero_row_pads<T, D>(Qs_ + bf * RT, tid);
+        zero_row_pads<T, D>(dOs_ + bf * RT, tid);
+        zero_tr_pads<T, D>(Qt_ + bf * TT, tid);
+        zero_tr_pads<T, D>(dOt_ + bf * TT, tid);
+    }
 
     v8 kf[KS], vf[KS];
     load_row_frags<T, D>(kf, (const T*)a.k + (int64_t)b * a.k_bs + (int64_t)kc * a.k_rs + h * D, kvalid, hh);
@@ -545,25 +659,60 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
     const int qbeg = split * a.q_per_split;
     const int qend = min(qbeg + a.q_per_split, a.Nq);
 
-    for (int q0 = qbeg; q0 < qend; q0 += KV_TILE) {
-        __syncthreads();
+    RowStage<T, D> qst, dost;
+    TrStage<T, D> qtst, dotst;
+    float st_lse = 0.f, st_D = 0.f, st_dpc[MOS_MAX_PCOLS] = {0.f, 0.f, 0.f, 0.f};
+    int st_nv = 0;
+    auto load_tile = [&](int q0) {
         const int nv = qend - q0;
-        stage_rows<T, D>(Qs, qp + (int64_t)q0 * a.q_rs, a.q_rs, nv, tid);
-        stage_rows<T, D>(dOs, dop + (int64_t)q0 * a.do_rs, a.do_rs, nv, tid);
-        stage_transposed<T, D>(Qt, qp + (int64_t)q0 * a.q_rs, a.q_rs, nv, tid);
-        stage_transposed<T, D>(dOt, dop + (int64_t)q0 * a.do_rs, a.do_rs, nv, tid);
+        qst.load(qp + (int64_t)q0 * a.q_rs, a.q_rs, nv, tid);
+        dost.load(dop + (int64_t)q0 * a.do_rs, a.do_rs, nv, tid);
+        qtst.load(qp + (int64_t)q0 * a.q_rs, a.q_rs, nv, tid);
+        dotst.load(dop + (int64_t)q0 * a.do_rs, a.do_rs, nv, tid);
+        st_nv = nv;
+        const int64_t rr = rowbase + q0 + min(tid & (KV_TILE - 1), nv - 1);   // unconditional, clamped
+        st_lse = a.lse[rr];
+        st_D = a.Dvec[rr];
+        if constexpr (PCOLS) {
+#pragma unroll
+            for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
+                st_dpc[tt] = a.dpcols[rr * a.n_pcols + min(tt, a.n_pcols - 1)];
+        }
+    };
+    auto store_tile = [&](int bf) {
+        qst.store(Qs_ + bf * RT, tid);
+        dost.store(dOs_ + bf * RT, tid);
+        qtst.store(Qt_ + bf * TT, tid);
+        dotst.store(dOt_ + bf * TT, tid);
         if (tid < KV_TILE) {
-            const bool ok = tid < nv;
-            lse_s[tid] = ok ? a.lse[rowbase + q0 + tid] * LOG2E : 0.f;
-            D_s[tid] = ok ? a.Dvec[rowbase + q0 + tid] : 0.f;
+            float* sb = stat_ + bf * ST;
+            const bool ok = tid < st_nv;
+            sb[tid] = ok ? st_lse * LOG2E : 0.f;
+            sb[KV_TILE + tid] = ok ? st_D : 0.f;
             if constexpr (PCOLS) {
 #pragma unroll
                 for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
-                    dpc_s[tid * MOS_MAX_PCOLS + tt] =
-                        (ok && tt < a.n_pcols) ? a.dpcols[(rowbase + q0 + tid) * a.n_pcols + tt] : 0.f;
+                    sb[2 * KV_TILE + tid * MOS_MAX_PCOLS + tt] = (ok && tt < a.n_pcols) ? st_dpc[tt] : 0.f;
             }
         }
-        __syncthreads();
+    };
+    __syncthreads();
+    if (qbeg < qend) {
+        load_tile(qbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int q0 = qbeg; q0 < qend; q0 += KV_TILE) {
+        const T* Qs = Qs_ + cur * RT;
+        const T* dOs = dOs_ + cur * RT;
+        const T* Qt = Qt_ + cur * TT;
+        const T* dOt = dOt_ + cur * TT;
+        const float* lse_s = stat_ + cur * ST;
+        const float* D_s = lse_s + KV_TILE;
+        const float* dpc_s = D_s + KV_TILE;
+        const bool more = q0 + KV_TILE < qend;
+        if (more) load_tile(q0 + KV_TILE);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 s, dp;
@@ -607,6 +756,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
                 }
             }
         }
+        if constexpr (NB == 1) __syncthreads();   // single buffer: every wave is done reading before the overwrite
+        if (more) store_tile(NB == 2 ? (cur ^ 1) : 0);
+        __syncthreads();
+        if constexpr (NB == 2) cur ^= 1;
     }
     if (a.nsplit == 1) {
         T* dkp = (T*)a.dk + (int64_t)b * a.dk_bs + (int64_t)kvi * a.dk_rs + h * D;
@@ -659,10 +812,11 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part, int nspli
 // ---- host dispatch -----------------------------------------------------------------------------
 template <int D> constexpr int fwd_qw() { return D <= 80 ? 64 : 32; }
 
-template <int D> constexpr size_t fwd_lds(size_t es) { return (HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
-template <int D> constexpr size_t dq_lds(size_t es) { return (2 * HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
+template <int D> constexpr size_t fwd_lds(size_t es) { return 2 * (HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
+template <int D> constexpr size_t dq_lds(size_t es) { return 2 * (2 * HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
 template <int D> constexpr size_t dkdv_lds(size_t es) {
-    return (2 * HD<D>::ROW_TILE_ELEMS + 2 * HD<D>::TR_TILE_ELEMS) * es + (2 * KV_TILE + KV_TILE * MOS_MAX_PCOLS) * sizeof(float);
+    return DKDV_NBUF<D>::value * ((2 * HD<D>::ROW_TILE_ELEMS + 2 * HD<D>::TR_TILE_ELEMS) * es +
+                                  KV_TILE * (2 + MOS_MAX_PCOLS) * sizeof(float));
 }
 
 template <typename K>

@@ -1,0 +1,120 @@
+"""Micro-benchmark of the library kernels at the SD-1.5 shapes (HIP-event timing through mos_profile_*).
+
+  python tools/bench_kernels.py [--iters 20] [--only attn]     -> table + JSON lines on stdout
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mos_path  # noqa: E402,F401
+import torch  # noqa: E402
+
+from mixofshow.hip import ops, profiler  # noqa: E402
+
+
+def attn_case(B, H, Nq, Nkv, d, dtype, iters, bwd=True, pcols=False):
+    C = H * d
+    if Nq == Nkv:
+        buf = torch.randn(B, Nq, 3 * C, device='cuda', dtype=dtype)
+        q, k, v = buf[..., :C], buf[..., C:2 * C], buf[..., 2 * C:]
+    else:
+        q = torch.randn(B, Nq, C, device='cuda', dtype=dtype)
+        kv = torch.randn(B, Nkv, 2 * C, device='cuda', dtype=dtype)
+        k, v = kv[..., :C], kv[..., C:]
+    tok = torch.tensor([[3, 5]] * B, dtype=torch.int32, device='cuda') if pcols else None
+    scale = d**-0.5
+    o, lse, pc = ops.attn_fwd(q, k, v, H, scale, tok_idx=tok)
+    dO = torch.randn_like(o)
+    dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
+    dpc = torch.randn_like(pc) if pcols else None
+    for _ in range(iters):
+        ops.attn_fwd(q, k, v, H, scale, tok_idx=tok)
+        if bwd:
+            ops.attn_bwd(q, k, v, o, lse, dO, H, scale, dq, dk, dv, tok_idx=tok, pcols=pc, dpcols=dpc)
+
+
+def gemm_case(M, N, K, dtype, iters, lora=True):
+    x = torch.randn(M, K, device='cuda', dtype=dtype)
+    W = torch.randn(N, K, device='cuda', dtype=dtype) / math.sqrt(K)
+    Wt = W.t().contiguous()
+    downs = [torch.randn(4, K, device='cuda') * 0.05]
+    ups = [torch.randn(N, 4, device='cuda') * 0.05]
+    A16, A16T, Bp16, BpT = ops.lora_pack(downs, ups, [1.0], K, dtype, 'cuda')
+    dy = torch.randn(M, N, device='cuda', dtype=dtype)
+    for _ in range(iters):
+        t = ops.lora_down(x, A16)
+        ops.linear_fwd(x, W, t, Bp16)
+        ops.linear_bwd(dy, x, Wt, t, A16T, BpT)
+
+
+def region_case(fh, fw, d, dtype, iters):
+    B, H = 2, 8
+    C = H * d
+    q = torch.randn(B, fh * fw, C, device='cuda', dtype=dtype)
+    kv = torch.randn(4, B, 77, 2 * C, device='cuda', dtype=dtype)
+    px = [[2, 2, 512, 184], [7, 184, 512, 345], [1, 488, 512, 747]]
+    boxes = [(math.ceil(b[0] / 512 * fh), math.ceil(b[1] / 768 * fw), math.floor(b[2] / 512 * fh),
+              math.floor(b[3] / 768 * fw)) for b in px]
+    for _ in range(iters):
+        ops.region_attn_fwd(q, kv[..., :C], kv[..., C:], H, d**-0.5, boxes, fh, fw)
+
+
+def gram_case(n, cin, cout, dtype, iters):
+    X = torch.randn(n, cin, device='cuda', dtype=dtype)
+    Y = torch.randn(n, cout, device='cuda', dtype=dtype)
+    G = torch.zeros(cin, cin, dtype=torch.float64, device='cuda')
+    P = torch.zeros(cout, cin, dtype=torch.float64, device='cuda')
+    c = torch.zeros(1, dtype=torch.float64, device='cuda')
+    W = torch.randn(cout, cin, dtype=torch.float64, device='cuda')
+    for _ in range(iters):
+        ops.gram_accumulate(X, Y, G, P, c)
+        ops.lsq_loss_grad(W, G, P, c, float(n * cout))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--only', default='')
+    ap.add_argument('--dtype', default='f16')
+    args = ap.parse_args()
+    dt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
+    cases = []
+    if args.only in ('', 'attn'):
+        cases += [lambda: attn_case(4, 8, 4096, 4096, 40, dt, args.iters), lambda: attn_case(4, 8, 1024, 1024, 80, dt, args.iters),
+                  lambda: attn_case(4, 8, 256, 256, 160, dt, args.iters), lambda: attn_case(4, 8, 64, 64, 160, dt, args.iters),
+                  lambda: attn_case(4, 8, 4096, 77, 40, dt, args.iters, pcols=True),
+                  lambda: attn_case(4, 8, 1024, 77, 80, dt, args.iters, pcols=True),
+                  lambda: attn_case(4, 8, 256, 77, 160, dt, args.iters, pcols=True),
+                  lambda: attn_case(2, 8, 6144, 6144, 40, dt, args.iters, bwd=False),
+                  lambda: attn_case(2, 8, 1536, 1536, 80, dt, args.iters, bwd=False)]
+    if args.only in ('', 'gemm'):
+        cases += [lambda: gemm_case(16384, 960, 320, dt, args.iters), lambda: gemm_case(16384, 320, 320, dt, args.iters),
+                  lambda: gemm_case(4096, 1920, 640, dt, args.iters), lambda: gemm_case(1024, 3840, 1280, dt, args.iters),
+                  lambda: gemm_case(4928, 768, 768, dt, args.iters), lambda: gemm_case(308, 640, 768, dt, args.iters)]
+    if args.only in ('', 'region'):
+        cases += [lambda: region_case(64, 96, 40, dt, args.iters), lambda: region_case(32, 48, 80, dt, args.iters),
+                  lambda: region_case(16, 24, 160, dt, args.iters)]
+    if args.only in ('', 'gram'):
+        cases += [lambda: gram_case(81920, 320, 320, dt, 5), lambda: gram_case(20480, 1280, 1280, dt, 5)]
+    for c in cases:   # warm-up (module load, allocator)
+        pass
+    recs = []
+    attn_case(1, 8, 256, 256, 40, dt, 2)
+    torch.cuda.synchronize()
+    with profiler.profile(recs):
+        for c in cases:
+            c()
+        torch.cuda.synchronize()
+    recs.sort(key=lambda r: r['name'])
+    print(f"{'kernel':72s} {'calls':>6s} {'avg us':>10s} {'TFLOP/s':>9s} {'GB/s':>9s}")
+    for r in recs:
+        s = r['avg_us'] * 1e-6
+        print(f"{r['name']:72s} {r['calls']:6d} {r['avg_us']:10.1f} {r['flops'] / s / 1e12:9.1f} {r['bytes'] / s / 1e9:9.0f}")
+    print('JSON ' + json.dumps(recs))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,23 @@
+#!/usr/bin/env bash
+# PMC passes over the kernel micro-benchmark (rocprofv3, counters only + kernel trace, one pass per counter group —
+# see /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots"). Writes a per-kernel summary to gpurun_out/.
+#   bash tools/pmc_collect.sh attn   (or gemm / region / gram)
+set -u
+WHAT="${1:-attn}"
+ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+export TMPDIR=/tmp
+OUT="$ROOT/gpurun_out"
+mkdir -p "$OUT"
+cd /tmp
+pass() {   # name, counters...
+  local name="$1"; shift
+  rm -rf "/tmp/pmc_$name"
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "/tmp/pmc_$name" -o p -- \
+      python "$ROOT/tools/bench_kernels.py" --only "$WHAT" --iters 3 > "/tmp/pmc_$name.log" 2>&1 || tail -5 "/tmp/pmc_$name.log"
+}
+pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS
+pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+python "$ROOT/tools/pmc_summary.py" /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_fetch /tmp/pmc_write > "$OUT/pmc_${WHAT}.txt" 2>&1
+tail -60 "$OUT/pmc_${WHAT}.txt"

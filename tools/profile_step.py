@@ -1,0 +1,65 @@
+"""Steady-state breakdown of one training step (or one regional UNet call) with torch.profiler: which kernels the
+step spends its GPU time in, how many launches it makes, and GPU-busy time vs wall time (launch-bound or not).
+
+  python tools/profile_step.py --mode train   > gpurun_out/step_breakdown_train.txt
+  python tools/profile_step.py --mode regional
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mos_path  # noqa: E402,F401
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', default='train')
+    ap.add_argument('--precision', default='fp16')
+    ap.add_argument('--rows', type=int, default=45)
+    args = ap.parse_args()
+    dev = torch.device('cuda', 0)
+    if args.mode == 'train':
+        from mixofshow.pipelines.train_loop import TrainEngine
+        tr = bench.build_trainer('sd15', dev)
+        tr.unet.train(); tr.text_encoder.train()
+        eng = TrainEngine(tr, dict(bench.TRAIN_OPT, optim_g=dict(bench.TRAIN_OPT['optim_g'])), 1e9, args.precision)
+        b = bench.synthetic_batch(4, 512, dev, 0)
+        fn = lambda: eng.step(b)  # noqa: E731
+    else:
+        pipe = bench.build_regional_pipe('sd15', dev)
+        prompt, neg = bench.regional_prompt(512, 768)
+        lat = torch.randn((1, 4, 64, 96), generator=torch.manual_seed(14))
+        fn = lambda: pipe(prompt=prompt, negative_prompt=[neg], height=512, width=768, num_inference_steps=5,  # noqa: E731
+                          guidance_scale=7.5, latents=lat.clone(), output_type='latent')
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    ka = prof.key_averages()
+    dev_attr = 'self_device_time_total' if hasattr(ka[0], 'self_device_time_total') else 'self_cuda_time_total'
+    rows = [(getattr(k, dev_attr), k.count, k.key) for k in ka if getattr(k, dev_attr) > 0]
+    rows.sort(reverse=True)
+    busy = sum(r[0] for r in rows)
+    launches = sum(r[1] for r in rows)
+    print(f'mode={args.mode} wall per call = {wall * 1e3:.2f} ms ; GPU busy (sum of kernel time) = {busy / 1e3:.2f} ms ; '
+          f'kernel launches = {launches}')
+    for t, c, k in rows[:args.rows]:
+        print(f'{t / 1e3:9.3f} ms {100 * t / busy:5.1f}%  x{c:<5d} {k[:130]}')
+
+
+if __name__ == '__main__':
+    main()
