@@ -96,6 +96,8 @@ int mos_lora_linear_fwd(const void* x, int64_t ldx, const void* W, int64_t ldw,
  *   dx[M,K]   = dy[M,N] . Wt[K,N]^T + dt . A16T[K,16]^T   (Wt = W^T, cached by the caller)
  *   dA16[16,K] (fp32) = dt^T . x
  *   dBpT[16,N] (fp32) = t^T . dy               (caller scales by alpha and slices per site)
+ * lora_cols: number of packed rank columns in use (n_sites * rank <= 16); the factor-gradient reduction only
+ *            computes that many rows (rounded up to 4), the remaining rows of dA16/dBpT are zero.
  * ws: fp32 workspace of mos_lora_bwd_workspace_bytes(M,N,K) bytes.
  * dx may be NULL (skip), dA16/dBpT may be NULL (no LoRA / frozen LoRA). */
 int64_t mos_lora_bwd_workspace_bytes(int M, int N, int K);
@@ -103,7 +105,7 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
                         const void* Wt, int64_t ldwt, const void* t,
                         const void* A16T, const void* BpT,
                         void* dt, void* dx, int64_t lddx, float* dA16, float* dBpT,
-                        void* ws, int M, int N, int K, int dtype, void* stream);
+                        void* ws, int M, int N, int K, int lora_cols, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused attention core: softmax(scale * Q K^T) V with online softmax, no materialised P.

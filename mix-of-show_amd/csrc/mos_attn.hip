@@ -572,12 +572,17 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(Att
                 s = MT<T>::mfma32(as_v8<T>(ld16(Ks + off)), qf[ks], s);
                 dp = MT<T>::mfma32(as_v8<T>(ld16(Vs + off)), dof[ks], dp);
             }
+            if (kv0 + KV_TILE > a.Nkv) {  // ragged last tile only (wave-uniform): keys past Nkv get probability 0
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + 32 * t + acc_row(r, hh) >= a.Nkv) s[r] = NEG_BIG;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kvi = kv0 + 32 * t + acc_row(r, hh);
-                const float p = (kvi < a.Nkv) ? __builtin_amdgcn_exp2f(s[r] * c - lse2) : 0.f;
+                const float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
                 float g = dp[r];
                 if constexpr (PCOLS) {
+                    const int kvi = kv0 + 32 * t + acc_row(r, hh);
 #pragma unroll
                     for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
                         if (kvi == tok[tt]) g += dpc[tt];

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 }
 
 // t[M,16] = X[M,K] . S[16,K]^T  — lora_down of all fused sites in one pass over X (HBM-bound).
-// One wave = 64 tokens (4 MFMA column tiles); A <- S rows (j), B <- X rows (m).
+// One wave = 16 tokens (one MFMA column tile): many small waves keep every CU busy at M = 5k..16k; the K loop is
+// unrolled x4 with all loads issued unconditionally up front (a `cond ? load : 0` select would serialise them).
 template <typename T>
 __global__ __launch_bounds__(256) void skinny_nt_kernel(const T* __restrict__ X, int64_t ldx,
                                                         const T* __restrict__ S, T* __restrict__ Tout,
@@ -164,30 +165,32 @@ __global__ __launch_bounds__(256) void skinny_nt_kernel(const T* __restrict__ X,
     typedef typename MT<T>::v8 v8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int mbase = (blockIdx.x * 4 + wave) * 64;
+    const int mbase = (blockIdx.x * 4 + wave) * 16;
     if (mbase >= M) return;
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const T* xrow[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xrow[i] = X + (int64_t)min(mbase + i * 16 + l15, M - 1) * ldx + lg * 8;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const T* xrow = X + (int64_t)min(mbase + l15, M - 1) * ldx + lg * 8;
     const T* srow = S + (int64_t)l15 * K + lg * 8;
-    for (int k = 0; k < K; k += 32) {
-        const bool ok = (k + lg * 8) < K;  // K % 8 == 0; tail chunks contribute zeros
-        const v8 a = ok ? as_v8<T>(ld16(srow + k)) : as_v8<T>(u32x4{0, 0, 0, 0});
-        v8 b[4];
+    int k = 0;
+    for (; k + 128 <= K; k += 128) {
+        u32x4 a[4], b[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) b[i] = ok ? as_v8<T>(ld16(xrow[i] + k)) : as_v8<T>(u32x4{0, 0, 0, 0});
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = MT<T>::mfma16(a, b[i], acc[i]);
+        for (int u = 0; u < 4; ++u) { a[u] = ld16(srow + k + 32 * u); b[u] = ld16(xrow + k + 32 * u); }
+        acc0 = MT<T>::mfma16(as_v8<T>(a[0]), as_v8<T>(b[0]), acc0);
+        acc1 = MT<T>::mfma16(as_v8<T>(a[1]), as_v8<T>(b[1]), acc1);
+        acc0 = MT<T>::mfma16(as_v8<T>(a[2]), as_v8<T>(b[2]), acc0);
+        acc1 = MT<T>::mfma16(as_v8<T>(a[3]), as_v8<T>(b[3]), acc1);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = mbase + i * 16 + l15;
-        if (m < M)
-            st8(Tout + (int64_t)m * MOS_LORA_PAD + lg * 4, pack4<T>(acc[i][0], acc[i][1], acc[i][2], acc[i][3]));
+    for (; k < K; k += 32) {  // tail (K % 8 == 0): chunks past K contribute zeros
+        const int kk = min(k + lg * 8, K - 8) - lg * 8;
+        const bool ok = (k + lg * 8) < K;
+        u32x4 a = ld16(srow + kk), b = ld16(xrow + kk);
+        if (!ok) a = u32x4{0, 0, 0, 0};
+        acc0 = MT<T>::mfma16(as_v8<T>(a), as_v8<T>(b), acc0);
     }
+    const int m = mbase + l15;
+    if (m < M)
+        st8(Tout + (int64_t)m * MOS_LORA_PAD + lg * 4,
+            pack4<T>(acc0[0] + acc1[0], acc0[1] + acc1[1], acc0[2] + acc1[2], acc0[3] + acc1[3]));
 }
 
 // partial[chunk][j][c] = sum_{m in chunk} P[m][j] * Z[m][c]   (j < NJ) — LoRA factor gradients.
@@ -326,7 +329,7 @@ int launch_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, const vo
 
 template <typename T>
 int launch_skinny_nt(const void* X, int64_t ldx, const void* S, void* Tout, int M, int K, hipStream_t st) {
-    dim3 grid((M + 255) / 256);
+    dim3 grid((M + 63) / 64);
     char key[64];
     snprintf(key, sizeof(key), "M%d K%d", M, K);
     MosProfScope prof(st, "lora_down(skinny_nt)", key, 2.0 * M * 16.0 * K, 2.0 * ((double)M * K + 16.0 * K + 16.0 * M));
@@ -334,25 +337,26 @@ int launch_skinny_nt(const void* X, int64_t ldx, const void* S, void* Tout, int 
     return mos_check_launch("skinny_nt");
 }
 
-inline int tn_rows_per_chunk(int M) {
-    int nchunk = M / 512;
+inline int tn_rows_per_chunk(int M, int C) {
+    const int colblocks = (C + 63) / 64;
+    int nchunk = (512 + colblocks - 1) / colblocks;   // aim at >= ~512 workgroups
+    const int maxchunk = (M + 63) / 64;
+    if (nchunk > maxchunk) nchunk = maxchunk;
     if (nchunk < 1) nchunk = 1;
-    if (nchunk > 64) nchunk = 64;
     int rpc = (M + nchunk - 1) / nchunk;
     rpc = (rpc + 31) / 32 * 32;
     return rpc;
 }
 
-template <typename T>
-int launch_skinny_tn(const void* P, const void* Z, int64_t ldz, float* out, float* partial, int M, int C,
-                     hipStream_t st) {
-    constexpr int NJ = MOS_LORA_PAD;  // all 16 packed columns (zeros cost nothing measurable: HBM-bound)
-    const int rpc = tn_rows_per_chunk(M);
+template <typename T, int NJ>
+int launch_skinny_tn_nj(const void* P, const void* Z, int64_t ldz, float* out, float* partial, int M, int C,
+                        hipStream_t st) {
+    const int rpc = tn_rows_per_chunk(M, C);
     const int nchunk = (M + rpc - 1) / rpc;
     dim3 grid(nchunk, (C + 63) / 64);
     char key[64];
-    snprintf(key, sizeof(key), "M%d C%d", M, C);
-    MosProfScope prof(st, "lora_grad(skinny_tn)", key, 2.0 * M * 16.0 * C, 2.0 * ((double)M * C + 16.0 * M));
+    snprintf(key, sizeof(key), "M%d C%d r%d", M, C, NJ);
+    MosProfScope prof(st, "lora_grad(skinny_tn)", key, 2.0 * M * (double)NJ * C, 2.0 * ((double)M * C + 16.0 * M));
     hipLaunchKernelGGL((skinny_tn_kernel<T, NJ>), grid, dim3(256), 0, st, (const T*)P, (const T*)Z, ldz, partial, M, C,
                        rpc);
     int rc = mos_check_launch("skinny_tn");
@@ -360,6 +364,16 @@ int launch_skinny_tn(const void* P, const void* Z, int64_t ldz, float* out, floa
     const int tot = MOS_LORA_PAD * C;
     hipLaunchKernelGGL(skinny_tn_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, partial, out, nchunk, NJ, C);
     return mos_check_launch("skinny_tn_reduce");
+}
+
+// cols = number of packed LoRA columns in use (n_sites * rank); rounded up to a multiple of 4
+template <typename T>
+int launch_skinny_tn(const void* P, const void* Z, int64_t ldz, float* out, float* partial, int M, int C, int cols,
+                     hipStream_t st) {
+    if (cols <= 4) return launch_skinny_tn_nj<T, 4>(P, Z, ldz, out, partial, M, C, st);
+    if (cols <= 8) return launch_skinny_tn_nj<T, 8>(P, Z, ldz, out, partial, M, C, st);
+    if (cols <= 12) return launch_skinny_tn_nj<T, 12>(P, Z, ldz, out, partial, M, C, st);
+    return launch_skinny_tn_nj<T, 16>(P, Z, ldz, out, partial, M, C, st);
 }
 
 }  // namespace
@@ -407,15 +421,19 @@ int mos_lora_linear_fwd(const void* x, int64_t ldx, const void* W, int64_t ldw, 
 }
 
 int64_t mos_lora_bwd_workspace_bytes(int M, int N, int K) {
-    const int rpc = tn_rows_per_chunk(M);
-    const int nchunk = (M + rpc - 1) / rpc;
-    const int C = N > K ? N : K;
-    return (int64_t)nchunk * MOS_LORA_PAD * C * sizeof(float);
+    int64_t best = 0;
+    for (int C : {N, K}) {
+        const int rpc = tn_rows_per_chunk(M, C);
+        const int64_t nchunk = (M + rpc - 1) / rpc;
+        const int64_t b = nchunk * MOS_LORA_PAD * C * (int64_t)sizeof(float);
+        if (b > best) best = b;
+    }
+    return best;
 }
 
 int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
                         const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
-                        float* dA16, float* dBpT, void* ws, int M, int N, int K, int dtype, void* stream) {
+                        float* dA16, float* dBpT, void* ws, int M, int N, int K, int lora_cols, int dtype, void* stream) {
     MOS_REQUIRE(dy, "mos_lora_linear_bwd: NULL dy");
     MOS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && lddy % 8 == 0,
                 "mos_lora_linear_bwd: M=%d N=%d K=%d lddy=%lld", M, N, K, (long long)lddy);
@@ -437,13 +455,13 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
     }
     if (lora && dA16) {  // dA16[16,K] = dt^T . x
         MOS_REQUIRE(ldx % 8 == 0, "mos_lora_linear_bwd: ldx %% 8");
-        rc = h ? launch_skinny_tn<f16_t>(dt, x, ldx, dA16, (float*)ws, M, K, st)
-               : launch_skinny_tn<bf16_t>(dt, x, ldx, dA16, (float*)ws, M, K, st);
+        rc = h ? launch_skinny_tn<f16_t>(dt, x, ldx, dA16, (float*)ws, M, K, lora_cols, st)
+               : launch_skinny_tn<bf16_t>(dt, x, ldx, dA16, (float*)ws, M, K, lora_cols, st);
         if (rc) return rc;
     }
     if (lora && dBpT) {  // dBpT[16,N] = t^T . dy
-        rc = h ? launch_skinny_tn<f16_t>(t, dy, lddy, dBpT, (float*)ws, M, N, st)
-               : launch_skinny_tn<bf16_t>(t, dy, lddy, dBpT, (float*)ws, M, N, st);
+        rc = h ? launch_skinny_tn<f16_t>(t, dy, lddy, dBpT, (float*)ws, M, N, lora_cols, st)
+               : launch_skinny_tn<bf16_t>(t, dy, lddy, dBpT, (float*)ws, M, N, lora_cols, st);
         if (rc) return rc;
     }
     return MOS_OK;

@@ -113,7 +113,8 @@ class _LoRALinear(torch.autograd.Function):
         need_lora = ctx.n_sites > 0 and any(ctx.needs_input_grad[5:])
         if need_dx and Wt16 is None:
             raise RuntimeError('mixofshow.hip: backward to the input needs the transposed weight (Wt16)')
-        dx, dA16, dBpT = ops.linear_bwd(dy2, x2, Wt16, t, A16T, BpT, need_dx=need_dx, need_lora=need_lora)
+        dx, dA16, dBpT = ops.linear_bwd(dy2, x2, Wt16, t, A16T, BpT, need_dx=need_dx, need_lora=need_lora,
+                                        lora_cols=max(1, ctx.n_sites * ctx.rank))
         grads = []
         if ctx.n_sites:
             r = ctx.rank

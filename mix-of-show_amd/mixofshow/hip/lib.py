@@ -84,7 +84,7 @@ SIGNATURES = {
     'mos_lora_linear_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     'mos_lora_bwd_workspace_bytes': (_i64, [_i, _i, _i]),
     'mos_lora_linear_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
-                                 _i, _i, _i, _i, _vp]),
+                                 _i, _i, _i, _i, _i, _vp]),
     'mos_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
     'mos_attn_bwd_workspace_bytes': (_i64, [ctypes.POINTER(AttnShape)]),
     'mos_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -106,7 +106,7 @@ def linear_fwd(x, W, t=None, Bp16=None, bias=None, out=None):
     return y
 
 
-def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True):
+def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True, lora_cols=16):
     """Backward of linear_fwd. Returns (dx | None, dA16 (16,K) fp32 | None, dBpT (16,N) fp32 | None)."""
     _dev(dy, x, Wt, t, A16T, BpT)
     M, N = dy.shape
@@ -124,7 +124,7 @@ def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True):
     _lib.check(L.mos_lora_linear_bwd(_p(dy), _rows(dy), _p(x), _rows(x) if x is not None else 0,
                                      _p(Wt), _rows(Wt) if Wt is not None else 0, _p(t), _p(A16T), _p(BpT),
                                      _p(dt), _p(dx), _rows(dx) if dx is not None else 0, _p(dA16), _p(dBpT), _p(ws),
-                                     M, N, K, _dt(dy), _stream()), 'mos_lora_linear_bwd')
+                                     M, N, K, int(lora_cols), _dt(dy), _stream()), 'mos_lora_linear_bwd')
     return dx, dA16, dBpT
 
 

@@ -48,7 +48,20 @@ class CLIPAttention(nn.Module):
 
     def forward(self, x):
         b, s, c = x.shape
-        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        if all(getattr(m, '_mos_lora', None) is not None for m in (self.q_proj, self.k_proj, self.v_proj)):
+            # all three projections carry ED-LoRA branches (where: CLIPAttention): one fused [Wq;Wk;Wv] GEMM with
+            # the three rank-r updates appended to the contraction instead of 3 x (GEMM + down + up) launches
+            from mixofshow.hip import functional as F_hip
+            from mixofshow.models.attention import project
+            if getattr(self, '_mos_cache', None) is None:
+                object.__setattr__(self, '_mos_cache', F_hip.WeightCache())
+            cd = F_hip.compute_dtype_for(x)
+            qkv = project(self, 'qkv', [self.q_proj, self.k_proj, self.v_proj], x if x.dtype == cd else x.to(cd), cd)
+            if not (torch.is_autocast_enabled('cuda') or x.dtype == cd):
+                qkv = qkv.to(x.dtype)
+            q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+        else:
+            q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
         shape = (b, s, self.num_heads, self.head_dim)
         q, k, v = (t.view(shape).transpose(1, 2) for t in (q, k, v))
         o = F.scaled_dot_product_attention(q, k, v, is_causal=True)

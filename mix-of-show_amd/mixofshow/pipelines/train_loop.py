@@ -15,7 +15,7 @@ from mixofshow.parallel import dp
 
 class TrainEngine:
 
-    def __init__(self, trainer, train_opt, total_iter, mixed_precision='fp16', grad_accum=1):
+    def __init__(self, trainer, train_opt, total_iter, mixed_precision='fp16', grad_accum=1, frozen_weights_half=True):
         self.trainer = trainer
         self.total_iter = total_iter
         self.grad_accum = grad_accum
@@ -30,11 +30,28 @@ class TrainEngine:
         self.mixed_precision = mixed_precision
         self.amp_dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(mixed_precision)
         self.scaler = torch.amp.GradScaler('cuda', enabled=(mixed_precision == 'fp16' and dev.type == 'cuda'))
+        if self.amp_dtype is not None and frozen_weights_half and dev.type == 'cuda':
+            self._store_frozen_weights_in_half(trainer, self.amp_dtype)
         self.threshold = float(train_opt.get('emb_norm_threshold', 5.5e-1))
         self.stop_flag = torch.zeros((), dtype=torch.bool, device=dev)          # stop_emb_update, on device
         self.frozen_rows = trainer.concept_embedding.detach().clone()
         self.global_step = 0
         self._micro = 0
+
+    @staticmethod
+    @torch.no_grad()
+    def _store_frozen_weights_in_half(trainer, dtype):
+        """Frozen Conv/Linear weights are only ever consumed through autocast, which rounds the fp32 tensor to
+        half on EVERY use (~700 cast kernels and ~5 GB of traffic per step for SD-1.5). Rounding once and keeping
+        the half tensor gives bit-identical operands. Trainable tensors (LoRA factors, concept rows) and everything
+        autocast runs in fp32 (norm affine parameters, embeddings) keep their fp32 masters."""
+        import torch.nn as nn
+        for root in (trainer.vae, trainer.text_encoder, trainer.unet):
+            for m in root.modules():
+                if isinstance(m, (nn.Linear, nn.Conv2d)):
+                    for p in (m.weight, m.bias):
+                        if p is not None and not p.requires_grad and p.dtype == torch.float32:
+                            p.data = p.data.to(dtype)
 
     def lr_factor(self, step):
         # diffusers get_scheduler('linear', warmup 0): lr * max(0, (T - step) / T)  (train_edlora.py:85-90)

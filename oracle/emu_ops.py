@@ -45,7 +45,7 @@ def linear_fwd(x, W, t=None, Bp16=None, bias=None, out=None):
     return y
 
 
-def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True):
+def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True, lora_cols=16):
     dyf = dy.float()
     lora = BpT is not None
     dt = (dyf @ BpT.float().t()).to(dy.dtype) if lora else None

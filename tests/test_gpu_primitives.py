@@ -91,7 +91,7 @@ def test_lora_linear_fwd_bwd(ops, emu, dtype, M, N, K, sites):
     # backward
     dy = torch.randn(M, N, generator=g).to(dev, dtype)
     Wt = W.t().contiguous()
-    dx, dA, dB = ops.linear_bwd(dy, x, Wt, t_ref, A16T, BpT)
+    dx, dA, dB = ops.linear_bwd(dy, x, Wt, t_ref, A16T, BpT, lora_cols=4 * len(sites))
     dx_r, dA_r, dB_r = emu.linear_bwd(dy, x, Wt, t_ref, A16T, BpT)
     _check('linear_bwd.dx', dx, dx_r, dtype)
     # LoRA factor grads are fp32 sums over M tokens of half-precision products

@@ -47,7 +47,7 @@ def gemm_case(M, N, K, dtype, iters, lora=True):
     for _ in range(iters):
         t = ops.lora_down(x, A16)
         ops.linear_fwd(x, W, t, Bp16)
-        ops.linear_bwd(dy, x, Wt, t, A16T, BpT)
+        ops.linear_bwd(dy, x, Wt, t, A16T, BpT, lora_cols=4)
 
 
 def region_case(fh, fw, d, dtype, iters):
