@@ -151,7 +151,7 @@ def run_train(args, rank, world, device):
     trainer.unet.train()
     trainer.text_encoder.train()
     engine = TrainEngine(trainer, dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g'])), total_iter=1e9,
-                         mixed_precision=args.precision)
+                         mixed_precision=args.precision, channels_last=args.channels_last)
     batches = [synthetic_batch(B, size, device, 1000 * rank + i) for i in range(2)]
     for i in range(args.warmup):
         engine.step(batches[i % 2])
@@ -263,6 +263,7 @@ def main():
     ap.add_argument('--preset', default='sd15')
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--channels-last', type=int, default=0)
     args = ap.parse_args()
     from mixofshow.parallel import dp
     rank, world, local = dp.init_distributed()

@@ -204,6 +204,20 @@ int mos_lsq_loss_grad_gram(const double* W, const double* G, const double* P, co
                            double n_times_cout, int Cout, int Cin, double* loss, double* grad,
                            void* ws, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused GroupNorm (+ SiLU) on half-precision NCHW activations — a CALLER of the hot path (SURVEY.md
+ * §8(f) item 1: the ResnetBlock2D / Transformer2DModel / VAE norm->activation pairs that diffusers runs
+ * as fp32 group_norm + silu under autocast). x, y, dy, dx: (B, C, HW) contiguous in `dtype`;
+ * gamma/beta fp32 (frozen: no affine gradients); stats (B*G, 2) fp32 = mean, rstd (saved for backward);
+ * HW must be a multiple of 8; ws: mos_groupnorm_workspace_bytes() bytes.
+ * ------------------------------------------------------------------------------------------ */
+int64_t mos_groupnorm_workspace_bytes(int B, int C, int HW, int G);
+int mos_groupnorm_silu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                           void* ws, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
+int mos_groupnorm_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta,
+                           const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu,
+                           int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

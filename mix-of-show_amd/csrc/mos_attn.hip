@@ -336,7 +336,7 @@ __device__ __forceinline__ void store_out_rows(T* orow, bool valid, const f32x16
 
 // ---- forward -----------------------------------------------------------------------------------
 template <typename T, int D, int QW, bool PCOLS>
-__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) void attn_fwd_kernel(AttnArgs a) {
     typedef typename MT<T>::v8 v8;
     constexpr int NQ = QW / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -869,11 +869,27 @@ template <typename T, int D>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* tok, int np,
                float* pcols, const mos_attn_shape* s, hipStream_t st) {
     constexpr int QW = fwd_qw<D>();
-    AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 4 * QW);
-    const dim3 grid((unsigned)(a.H * a.nqb * a.B));
     const size_t lds = fwd_lds<D>(sizeof(T));
     AttnKey key(tname<T>(), s, 2.0);
     MosProfScope prof(st, np > 0 ? "attn_fwd_pcols" : "attn_fwd", key.s, key.flops, key.bytes);
+    // 64 queries per wave halve the LDS operand traffic, but with few workgroups (small batch at inference, short
+    // sequences) they leave CUs idle / unbalanced: fall back to 32 queries per wave when the 256-query grid would
+    // not give every CU at least two workgroups.
+    const int64_t wg_big = (int64_t)s->H * s->B * ((s->Nq + 4 * QW - 1) / (4 * QW));
+    if (QW == 64 && wg_big < 512) {
+        AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 128);
+        const dim3 grid((unsigned)(a.H * a.nqb * a.B));
+        if (np > 0) {
+            set_lds(&attn_fwd_kernel<T, D, 32, true>, lds);
+            hipLaunchKernelGGL((attn_fwd_kernel<T, D, 32, true>), grid, dim3(256), lds, st, a);
+        } else {
+            set_lds(&attn_fwd_kernel<T, D, 32, false>, lds);
+            hipLaunchKernelGGL((attn_fwd_kernel<T, D, 32, false>), grid, dim3(256), lds, st, a);
+        }
+        return mos_check_launch("attn_fwd");
+    }
+    AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 4 * QW);
+    const dim3 grid((unsigned)(a.H * a.nqb * a.B));
     if (np > 0) {
         set_lds(&attn_fwd_kernel<T, D, QW, true>, lds);
         hipLaunchKernelGGL((attn_fwd_kernel<T, D, QW, true>), grid, dim3(256), lds, st, a);

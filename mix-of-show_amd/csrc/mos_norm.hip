@@ -1,0 +1,276 @@
+// mos_norm.hip — fused GroupNorm (+ SiLU) forward / backward on half-precision NCHW activations (gfx950).
+//
+// Not one of the attention-path kernels of SURVEY.md §8(a); it is the first item of §8(f) "next": the ResnetBlock2D /
+// Transformer2DModel / VAE GroupNorm->SiLU pairs that CALL the attention path. Under autocast the reference stack runs
+// GroupNorm in fp32 (cast in, fp32 normalise, fp32 SiLU, cast out at the next conv): 4-6 elementwise passes over
+// activations as large as (4,128,512,512). Here: statistics in fp32/fp64 from the half tensor, one fused
+// normalise+affine+SiLU pass writing half — 2 reads + 1 write of the half tensor. HBM-bound by construction.
+// gamma/beta are frozen in ED-LoRA training (no affine gradients are produced).
+#include <cstdio>
+#include <type_traits>
+#include "mos_common.h"
+
+namespace {
+
+constexpr int GN_SLICE = 16384;   // elements per workgroup slice (256 threads x 8 elements x 8 iterations)
+constexpr int GN_MAX_SPLIT = 64;
+
+struct GnArgs {
+    const void* x; const void* dy; void* out;      // fwd: x -> out ; bwd: (x, dy) -> out (= dx)
+    const float* gamma; const float* beta;
+    float* stats;                                  // [B*G][2] = mean, rstd
+    float* partial;                                // [B*G][nsplit][2]
+    int B, C, HW, G, cpg, nsplit;
+    int64_t group_elems;
+    float eps;
+};
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+
+__device__ __forceinline__ void block_reduce2(float& a, float& b, float* red /*[8]*/) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave * 2] = a; red[wave * 2 + 1] = b; }
+    __syncthreads();
+    a = red[0] + red[2] + red[4] + red[6];
+    b = red[1] + red[3] + red[5] + red[7];
+}
+
+// slice [e0, e1) of group bg, in units of elements; every slice boundary is a multiple of 8
+__device__ __forceinline__ void slice_range(const GnArgs& a, int64_t& e0, int64_t& e1) {
+    const int64_t per = ((a.group_elems / 8 + a.nsplit - 1) / a.nsplit) * 8;
+    e0 = (int64_t)blockIdx.y * per;
+    e1 = min(e0 + per, a.group_elems);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnArgs a) {
+    typedef typename MT<T>::v8 v8;
+    __shared__ float red[8];
+    const int bg = blockIdx.x;
+    int64_t e0, e1;
+    slice_range(a, e0, e1);
+    const T* xg = (const T*)a.x + (int64_t)bg * a.group_elems;
+    float s = 0.f, ss = 0.f;
+    for (int64_t e = e0 + (int64_t)threadIdx.x * 8; e < e1; e += 256 * 8) {
+        const v8 v = as_v8<T>(ld16(xg + e));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float f = (float)v[i]; s += f; ss += f * f; }
+    }
+    block_reduce2(s, ss, red);
+    if (threadIdx.x == 0) {
+        float* p = a.partial + ((int64_t)bg * a.nsplit + blockIdx.y) * 2;
+        p[0] = s; p[1] = ss;
+    }
+}
+
+// mean / rstd of group bg from the slice partials (combined in double: E[x^2]-mean^2 is cancellation-prone in fp32)
+__device__ __forceinline__ void group_stats(const GnArgs& a, int bg, float& mean, float& rstd) {
+    double s = 0.0, ss = 0.0;
+    for (int i = 0; i < a.nsplit; ++i) {
+        s += (double)a.partial[((int64_t)bg * a.nsplit + i) * 2];
+        ss += (double)a.partial[((int64_t)bg * a.nsplit + i) * 2 + 1];
+    }
+    const double n = (double)a.group_elems;
+    const double m = s / n;
+    double var = ss / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+}
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
+    typedef typename MT<T>::v8 v8;
+    const int bg = blockIdx.x;
+    const int g = bg % a.G;
+    float mean, rstd;
+    group_stats(a, bg, mean, rstd);
+    if (blockIdx.y == 0 && threadIdx.x == 0 && a.stats != nullptr) { a.stats[bg * 2] = mean; a.stats[bg * 2 + 1] = rstd; }
+    int64_t e0, e1;
+    slice_range(a, e0, e1);
+    const T* xg = (const T*)a.x + (int64_t)bg * a.group_elems;
+    T* yg = (T*)a.out + (int64_t)bg * a.group_elems;
+    for (int64_t e = e0 + (int64_t)threadIdx.x * 8; e < e1; e += 256 * 8) {
+        const int c = g * a.cpg + (int)(e / a.HW);        // HW % 8 == 0: the 8 elements share one channel
+        const float ga = a.gamma[c] * rstd, be = a.beta[c] - mean * a.gamma[c] * rstd;
+        const v8 v = as_v8<T>(ld16(xg + e));
+        v8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float z = (float)v[i] * ga + be;
+            if (SILU) z = silu_f(z);
+            o[i] = (T)z;
+        }
+        st16(yg + e, from_v8<T>(o));
+    }
+}
+
+// backward pass 1: per group sum(g) and sum(g * xhat), g = dL/dz * gamma, z = xhat*gamma + beta
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(GnArgs a) {
+    typedef typename MT<T>::v8 v8;
+    __shared__ float red[8];
+    const int bg = blockIdx.x;
+    const int g = bg % a.G;
+    const float mean = a.stats[bg * 2], rstd = a.stats[bg * 2 + 1];
+    int64_t e0, e1;
+    slice_range(a, e0, e1);
+    const T* xg = (const T*)a.x + (int64_t)bg * a.group_elems;
+    const T* dg = (const T*)a.dy + (int64_t)bg * a.group_elems;
+    float sg = 0.f, sgx = 0.f;
+    for (int64_t e = e0 + (int64_t)threadIdx.x * 8; e < e1; e += 256 * 8) {
+        const int c = g * a.cpg + (int)(e / a.HW);
+        const float gam = a.gamma[c], bet = a.beta[c];
+        const v8 v = as_v8<T>(ld16(xg + e)), d = as_v8<T>(ld16(dg + e));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = ((float)v[i] - mean) * rstd;
+            float dz = (float)d[i];
+            if (SILU) {
+                const float z = xh * gam + bet;
+                const float sig = 1.f / (1.f + __expf(-z));
+                dz *= sig * (1.f + z * (1.f - sig));
+            }
+            const float gg = dz * gam;
+            sg += gg; sgx += gg * xh;
+        }
+    }
+    block_reduce2(sg, sgx, red);
+    if (threadIdx.x == 0) {
+        float* p = a.partial + ((int64_t)bg * a.nsplit + blockIdx.y) * 2;
+        p[0] = sg; p[1] = sgx;
+    }
+}
+
+// backward pass 2: dx = rstd * (g - mean(g) - xhat * mean(g*xhat))
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnArgs a) {
+    typedef typename MT<T>::v8 v8;
+    const int bg = blockIdx.x;
+    const int g = bg % a.G;
+    const float mean = a.stats[bg * 2], rstd = a.stats[bg * 2 + 1];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = 0; i < a.nsplit; ++i) {
+        s0 += (double)a.partial[((int64_t)bg * a.nsplit + i) * 2];
+        s1 += (double)a.partial[((int64_t)bg * a.nsplit + i) * 2 + 1];
+    }
+    const float mg = (float)(s0 / (double)a.group_elems), mgx = (float)(s1 / (double)a.group_elems);
+    int64_t e0, e1;
+    slice_range(a, e0, e1);
+    const T* xg = (const T*)a.x + (int64_t)bg * a.group_elems;
+    const T* dg = (const T*)a.dy + (int64_t)bg * a.group_elems;
+    T* og = (T*)a.out + (int64_t)bg * a.group_elems;
+    for (int64_t e = e0 + (int64_t)threadIdx.x * 8; e < e1; e += 256 * 8) {
+        const int c = g * a.cpg + (int)(e / a.HW);
+        const float gam = a.gamma[c], bet = a.beta[c];
+        const v8 v = as_v8<T>(ld16(xg + e)), d = as_v8<T>(ld16(dg + e));
+        v8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = ((float)v[i] - mean) * rstd;
+            float dz = (float)d[i];
+            if (SILU) {
+                const float z = xh * gam + bet;
+                const float sig = 1.f / (1.f + __expf(-z));
+                dz *= sig * (1.f + z * (1.f - sig));
+            }
+            o[i] = (T)(rstd * (dz * gam - mg - xh * mgx));
+        }
+        st16(og + e, from_v8<T>(o));
+    }
+}
+
+int gn_nsplit(int64_t group_elems) {
+    int64_t n = (group_elems + GN_SLICE - 1) / GN_SLICE;
+    if (n < 1) n = 1;
+    if (n > GN_MAX_SPLIT) n = GN_MAX_SPLIT;
+    return (int)n;
+}
+
+int gn_check(const void* x, const void* out, const float* gamma, const float* beta, void* ws, int B, int C, int HW, int G,
+             const char* who) {
+    if (!x || !out || !gamma || !beta || !ws) return mos_set_error(MOS_ERR_BAD_ARG, "%s: NULL argument", who);
+    if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G != 0 || HW % 8 != 0)
+        return mos_set_error(MOS_ERR_BAD_ARG, "%s: B=%d C=%d HW=%d G=%d (need C %% G == 0, HW %% 8 == 0)", who, B, C, HW, G);
+    return MOS_OK;
+}
+
+GnArgs gn_args(const void* x, const void* dy, void* out, const float* gamma, const float* beta, float* stats, void* ws,
+               int B, int C, int HW, int G, float eps) {
+    GnArgs a;
+    a.x = x; a.dy = dy; a.out = out; a.gamma = gamma; a.beta = beta; a.stats = stats; a.partial = (float*)ws;
+    a.B = B; a.C = C; a.HW = HW; a.G = G; a.cpg = C / G; a.group_elems = (int64_t)(C / G) * HW;
+    a.nsplit = gn_nsplit(a.group_elems); a.eps = eps;
+    return a;
+}
+
+template <typename T>
+int gn_fwd(GnArgs a, int silu, hipStream_t st) {
+    const dim3 grid(a.B * a.G, a.nsplit);
+    char key[96];
+    snprintf(key, sizeof(key), "B%d C%d HW%d%s", a.B, a.C, a.HW, silu ? " +silu" : "");
+    const double n = (double)a.B * a.C * a.HW;
+    {
+        MosProfScope prof(st, "groupnorm_stats", key, 3.0 * n, 2.0 * n);
+        hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 0, st, a);
+    }
+    int rc = mos_check_launch("gn_stats");
+    if (rc) return rc;
+    MosProfScope prof(st, "groupnorm_apply", key, 8.0 * n, 4.0 * n);
+    if (silu) hipLaunchKernelGGL((gn_apply_kernel<T, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gn_apply_kernel<T, false>), grid, dim3(256), 0, st, a);
+    return mos_check_launch("gn_apply");
+}
+
+template <typename T>
+int gn_bwd(GnArgs a, int silu, hipStream_t st) {
+    const dim3 grid(a.B * a.G, a.nsplit);
+    char key[96];
+    snprintf(key, sizeof(key), "B%d C%d HW%d%s", a.B, a.C, a.HW, silu ? " +silu" : "");
+    const double n = (double)a.B * a.C * a.HW;
+    {
+        MosProfScope prof(st, "groupnorm_bwd_stats", key, 12.0 * n, 4.0 * n);
+        if (silu) hipLaunchKernelGGL((gn_bwd_stats_kernel<T, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gn_bwd_stats_kernel<T, false>), grid, dim3(256), 0, st, a);
+    }
+    int rc = mos_check_launch("gn_bwd_stats");
+    if (rc) return rc;
+    MosProfScope prof(st, "groupnorm_bwd_apply", key, 14.0 * n, 6.0 * n);
+    if (silu) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, false>), grid, dim3(256), 0, st, a);
+    return mos_check_launch("gn_bwd_apply");
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t mos_groupnorm_workspace_bytes(int B, int C, int HW, int G) {
+    if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G) return 0;
+    return (int64_t)B * G * gn_nsplit((int64_t)(C / G) * HW) * 2 * (int64_t)sizeof(float);
+}
+
+int mos_groupnorm_silu_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, void* ws, int B,
+                           int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
+    int rc = gn_check(x, y, gamma, beta, ws, B, C, HW, G, "mos_groupnorm_silu_fwd");
+    if (rc) return rc;
+    GnArgs a = gn_args(x, nullptr, y, gamma, beta, stats, ws, B, C, HW, G, eps);
+    if (dtype == MOS_F16) return gn_fwd<f16_t>(a, silu, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return gn_fwd<bf16_t>(a, silu, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_fwd: dtype %d", dtype);
+}
+
+int mos_groupnorm_silu_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,
+                           void* dx, void* ws, int B, int C, int HW, int G, int silu, int dtype, void* stream) {
+    int rc = gn_check(x, dx, gamma, beta, ws, B, C, HW, G, "mos_groupnorm_silu_bwd");
+    if (rc) return rc;
+    MOS_REQUIRE(dy && stats, "mos_groupnorm_silu_bwd: NULL dy / stats");
+    GnArgs a = gn_args(x, dy, dx, gamma, beta, const_cast<float*>(stats), ws, B, C, HW, G, 0.f);
+    if (dtype == MOS_F16) return gn_bwd<f16_t>(a, silu, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return gn_bwd<bf16_t>(a, silu, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_bwd: dtype %d", dtype);
+}
+
+}  // extern "C"

@@ -219,3 +219,37 @@ def attention(q, k, v, heads, scale, tok_idx=None):
     _check_half(q, k, v)
     o, pcols = _Attention.apply('sep', heads, scale, tok_idx, q, k, v)
     return o, (pcols if tok_idx is not None else None)
+
+
+class _GroupNormSiLU(torch.autograd.Function):
+    """Fused GroupNorm (+ SiLU) on half NCHW activations; affine parameters are treated as frozen constants."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        xc = x if x.is_contiguous() else x.contiguous()
+        y, stats = ops.groupnorm_silu_fwd(xc, gamma, beta, groups, eps, silu)
+        ctx.save_for_backward(xc, gamma, beta, stats)
+        ctx.groups, ctx.silu = groups, silu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        if dy.dtype != x.dtype or not dy.is_contiguous():
+            dy = dy.to(x.dtype).contiguous()
+        return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
+
+
+def group_norm_act(norm, x, silu):
+    """`silu(norm(x))` (or `norm(x)`) for an nn.GroupNorm `norm`.
+
+    HIP path: half-precision device tensors with frozen affine parameters and HW % 8 == 0 — one fused kernel pair
+    instead of autocast's cast / fp32 group_norm / fp32 silu / cast chain. Anything else (CPU oracle runs, fp32
+    inference, trainable norms) takes the plain torch ops: this is plumbing around the hot path, not part of it."""
+    hw = x.numel() // max(1, x.shape[0] * x.shape[1])
+    use_hip = (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and hw % 8 == 0
+               and not norm.weight.requires_grad and not norm.bias.requires_grad and norm.weight.dtype == torch.float32)
+    if use_hip:
+        return _GroupNormSiLU.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, bool(silu))
+    y = norm(x)
+    return torch.nn.functional.silu(y) if silu else y

@@ -95,6 +95,9 @@ SIGNATURES = {
                                        _i, _vp]),
     'mos_gram_workspace_bytes': (_i64, [_i64, _i, _i]),
     'mos_gram_accumulate': (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'mos_groupnorm_workspace_bytes': (_i64, [_i, _i, _i, _i]),
+    'mos_groupnorm_silu_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    'mos_groupnorm_silu_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_lsq_workspace_bytes': (_i64, [_i, _i]),
     'mos_lsq_loss_grad_gram': (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),
 }

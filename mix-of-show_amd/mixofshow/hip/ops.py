@@ -245,3 +245,32 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
     _lib.check(L.mos_lsq_loss_grad_gram(_p(W), _p(G), _p(P), _p(c), float(n_times_cout), Cout, Cin, _p(loss), _p(grad),
                                         _p(ws), _stream()), 'mos_lsq_loss_grad_gram')
     return loss, grad
+
+
+# ------------------------------------------------------------------------------------------------
+# fused GroupNorm (+ SiLU) — caller-side plumbing kernel
+# ------------------------------------------------------------------------------------------------
+def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
+    """x (B, C, *spatial) contiguous half; gamma/beta fp32. Returns (y like x, stats (B*G, 2) fp32)."""
+    _dev(x, gamma, beta)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    stats = torch.empty((B * groups, 2), dtype=torch.float32, device=x.device)
+    L = _lib.load()
+    ws = torch.empty((L.mos_groupnorm_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(L.mos_groupnorm_silu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, C, HW, groups,
+                                        float(eps), int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_fwd')
+    return y, stats
+
+
+def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu):
+    _dev(dy, x, gamma, beta, stats)
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    dx = torch.empty_like(x)
+    L = _lib.load()
+    ws = torch.empty((L.mos_groupnorm_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
+    _lib.check(L.mos_groupnorm_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, C, HW, groups,
+                                        int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_bwd')
+    return dx

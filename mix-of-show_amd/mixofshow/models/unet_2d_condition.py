@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from mixofshow.hip.functional import group_norm_act
 from mixofshow.models.attention import Attention
 
 
@@ -59,10 +60,10 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(self.nonlinearity(self.norm1(x)))
+        h = self.conv1(group_norm_act(self.norm1, x, True))          # fused GroupNorm+SiLU on the HIP device
         if self.time_emb_proj is not None and temb is not None:
             h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
-        h = self.conv2(self.dropout(self.nonlinearity(self.norm2(h))))
+        h = self.conv2(self.dropout(group_norm_act(self.norm2, h, True)))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h
@@ -145,11 +146,13 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, encoder_hidden_states=None, cross_attention_kwargs=None):
         b, c, h, w = x.shape
         residual = x
-        x = self.proj_in(self.norm(x))
+        x = self.proj_in(group_norm_act(self.norm, x, False))
         x = x.permute(0, 2, 3, 1).reshape(b, h * w, -1)
         for blk in self.transformer_blocks:
             x = blk(x, encoder_hidden_states=encoder_hidden_states, cross_attention_kwargs=cross_attention_kwargs)
-        x = x.reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous()
+        # (b, hw, c) -> NCHW view with channels-last strides: free when the UNet runs in channels_last memory format
+        # (the token-major layout of the attention path IS NHWC); the 1x1 conv accepts either layout
+        x = x.reshape(b, h, w, -1).permute(0, 3, 1, 2)
         return self.proj_out(x) + residual
 
 
@@ -352,7 +355,7 @@ class UNet2DConditionModel(nn.Module):
                 sample = blk(sample, take, emb, encoder_hidden_states, cross_attention_kwargs)
             else:
                 sample = blk(sample, take, emb)
-        sample = self.conv_out(self.conv_act(self.conv_norm_out(sample)))
+        sample = self.conv_out(group_norm_act(self.conv_norm_out, sample, True))
         return UNetOutput(sample=sample) if return_dict else (sample, )
 
     def _run(self, blk, sample, emb, ehs, cak, extra):

@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from mixofshow.hip.functional import group_norm_act
 from mixofshow.models.unet_2d_condition import Downsample2D, ResnetBlock2D, Upsample2D
 
 
@@ -23,7 +24,7 @@ class VaeAttention(nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
-        y = self.group_norm(x).view(b, c, h * w).transpose(1, 2)
+        y = group_norm_act(self.group_norm, x, False).view(b, c, h * w).transpose(1, 2)
         q, k, v = self.to_q(y), self.to_k(y), self.to_v(y)
         o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
         o = self.to_out[0](o)
@@ -86,7 +87,7 @@ class Encoder(nn.Module):
         x = self.conv_in(x)
         for b in self.down_blocks:
             x = b(x)
-        return self.conv_out(self.conv_act(self.conv_norm_out(self.mid_block(x))))
+        return self.conv_out(group_norm_act(self.conv_norm_out, self.mid_block(x), True))
 
 
 class Decoder(nn.Module):
@@ -109,7 +110,7 @@ class Decoder(nn.Module):
         x = self.mid_block(self.conv_in(z))
         for b in self.up_blocks:
             x = b(x)
-        return self.conv_out(self.conv_act(self.conv_norm_out(x)))
+        return self.conv_out(group_norm_act(self.conv_norm_out, x, True))
 
 
 class DiagonalGaussianDistribution:

@@ -15,7 +15,8 @@ from mixofshow.parallel import dp
 
 class TrainEngine:
 
-    def __init__(self, trainer, train_opt, total_iter, mixed_precision='fp16', grad_accum=1, frozen_weights_half=True):
+    def __init__(self, trainer, train_opt, total_iter, mixed_precision='fp16', grad_accum=1, frozen_weights_half=True,
+                 channels_last=False):
         self.trainer = trainer
         self.total_iter = total_iter
         self.grad_accum = grad_accum
@@ -32,6 +33,11 @@ class TrainEngine:
         self.scaler = torch.amp.GradScaler('cuda', enabled=(mixed_precision == 'fp16' and dev.type == 'cuda'))
         if self.amp_dtype is not None and frozen_weights_half and dev.type == 'cuda':
             self._store_frozen_weights_in_half(trainer, self.amp_dtype)
+        self.channels_last = bool(channels_last) and dev.type == 'cuda'
+        if self.channels_last:
+            # NHWC is the native layout of the token-major attention path and of MIOpen's fp16 implicit-GEMM convs
+            trainer.unet.to(memory_format=torch.channels_last)
+            trainer.vae.to(memory_format=torch.channels_last)
         self.threshold = float(train_opt.get('emb_norm_threshold', 5.5e-1))
         self.stop_flag = torch.zeros((), dtype=torch.bool, device=dev)          # stop_emb_update, on device
         self.frozen_rows = trainer.concept_embedding.detach().clone()
@@ -65,8 +71,11 @@ class TrainEngine:
         masks = batch['masks'] if 'masks' in batch else batch['img_masks']
         extra = {k: batch[k] for k in ('noise', 'timesteps', 'latents') if k in batch}
         dev_type = tr.concept_embedding.device.type
+        images = batch['images']
+        if self.channels_last and images is not None:
+            images = images.contiguous(memory_format=torch.channels_last)
         with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-            loss = tr(batch['images'], batch['prompts'], masks, batch['img_masks'], **extra)
+            loss = tr(images, batch['prompts'], masks, batch['img_masks'], **extra)
         self.scaler.scale(loss / self.grad_accum).backward()
         self._micro += 1
         out = {'loss': loss.detach()}

@@ -8,7 +8,7 @@ Emulations compute in fp32 from the (possibly half) inputs and round the result 
 import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
-            'gram_accumulate', 'lsq_loss_grad')
+            'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd')
 PAD = 16
 
 
@@ -132,3 +132,39 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
     R = W @ G - P
     loss = ((R * W).sum() - (P * W).sum() + c.reshape(())) / n_times_cout
     return loss, 2.0 * R / n_times_cout
+
+
+def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
+    import torch.nn.functional as F
+    cd = torch.float64 if x.dtype == torch.float64 else torch.float32
+    xf = x.to(cd)
+    B, C = x.shape[0], x.shape[1]
+    g = xf.reshape(B, groups, -1)
+    mean = g.mean(-1)
+    var = g.var(-1, unbiased=False)
+    y = F.group_norm(xf, groups, gamma.to(cd), beta.to(cd), eps)
+    if silu:
+        y = F.silu(y)
+    stats = torch.stack([mean.reshape(-1), torch.rsqrt(var + eps).reshape(-1)], 1).contiguous()
+    return y.to(x.dtype), stats
+
+
+def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu):
+    """Closed-form GroupNorm(+SiLU) input gradient from the saved (mean, rstd); checked against autograd in
+    tests/test_host_cpu.py."""
+    B, C = x.shape[0], x.shape[1]
+    shape = [1, C] + [1] * (x.dim() - 2)
+    mean = stats[:, 0].reshape(B, groups, 1)
+    rstd = stats[:, 1].reshape(B, groups, 1)
+    cd = torch.float64 if x.dtype == torch.float64 else torch.float32
+    gamma, beta = gamma.to(cd), beta.to(cd)
+    xh = ((x.to(cd).reshape(B, groups, -1) - mean.to(cd)) * rstd.to(cd)).reshape(x.shape)
+    dz = dy.to(cd)
+    if silu:
+        z = xh * gamma.reshape(shape) + beta.reshape(shape)
+        sig = torch.sigmoid(z)
+        dz = dz * sig * (1 + z * (1 - sig))
+    g = (dz * gamma.reshape(shape)).reshape(B, groups, -1)
+    xg = xh.reshape(B, groups, -1)
+    dx = rstd * (g - g.mean(-1, keepdim=True) - xg * (g * xg).mean(-1, keepdim=True))
+    return dx.reshape(x.shape).to(x.dtype)

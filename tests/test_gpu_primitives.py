@@ -239,3 +239,26 @@ def test_errors_are_loud(ops):
     from mixofshow.hip.lib import MosHipError
     with pytest.raises(MosHipError, match='head dim'):
         ops.attn_fwd(q, q, q, 8, 1.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('silu', [True, False])
+@pytest.mark.parametrize('B,C,H,W,G', [(4, 320, 64, 64, 32), (2, 1280, 8, 8, 32), (2, 128, 256, 256, 32),
+                                       (2, 2560, 16, 16, 32), (1, 640, 32, 48, 32)])
+def test_groupnorm_silu(ops, emu, dtype, silu, B, C, H, W, G):
+    """Fused GroupNorm(+SiLU) vs torch fp32 group_norm/silu on the same half inputs (forward and input gradient)."""
+    g = torch.Generator(device='cpu').manual_seed(8)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to('cuda', dtype)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    y, stats = ops.groupnorm_silu_fwd(x, gamma, beta, G, 1e-5, silu)
+    y_ref, stats_ref = emu.groupnorm_silu_fwd(x, gamma, beta, G, 1e-5, silu)
+    _check(f'groupnorm.y[{B}x{C}x{H}x{W}]', y, y_ref, dtype, ulps=2.0)
+    _check('groupnorm.stats', stats, stats_ref, torch.float16, ulps=0.05)
+    dy = torch.randn(B, C, H, W, generator=g).to('cuda', dtype)
+    dx = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats_ref, G, silu)
+    xf = x.float().requires_grad_(True)
+    out = torch.nn.functional.group_norm(xf, G, gamma, beta, 1e-5)
+    out = torch.nn.functional.silu(out) if silu else out
+    (dx_ref, ) = torch.autograd.grad(out, xf, dy.float())
+    _check('groupnorm.dx', dx, dx_ref, dtype, ulps=3.0)

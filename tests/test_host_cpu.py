@@ -275,3 +275,21 @@ def test_region_processor_host_logic(emulated_hip, golden):
     torch.testing.assert_close(ys.float(), g['y_self'], rtol=3e-2, atol=4e-3)
     with pytest.raises(KeyError):
         proc(attn, g['hs'].half(), encoder_hidden_states=g['ctx'].half())
+
+
+@pytest.mark.parametrize('silu', [True, False])
+def test_groupnorm_closed_form_backward_matches_autograd(silu):
+    """The closed-form GroupNorm(+SiLU) input gradient the HIP kernel implements (oracle/emu_ops.py) == autograd."""
+    from oracle import emu_ops
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 6, 8, dtype=torch.float64)
+    gamma, beta = torch.rand(16, dtype=torch.float64) + 0.5, torch.randn(16, dtype=torch.float64)
+    dy = torch.randn_like(x)
+    y, stats = emu_ops.groupnorm_silu_fwd(x, gamma, beta, 4, 1e-5, silu)
+    xr = x.clone().requires_grad_(True)
+    out = torch.nn.functional.group_norm(xr, 4, gamma, beta, 1e-5)
+    out = torch.nn.functional.silu(out) if silu else out
+    torch.testing.assert_close(y.double(), out.detach(), rtol=1e-5, atol=1e-6)
+    (ref, ) = torch.autograd.grad(out, xr, dy)
+    got = emu_ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats.double(), 4, silu)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
