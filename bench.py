@@ -153,6 +153,17 @@ def run_train(args, rank, world, device):
     engine = TrainEngine(trainer, dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g'])), total_iter=1e9,
                          mixed_precision=args.precision, channels_last=args.channels_last)
     batches = [synthetic_batch(B, size, device, 1000 * rank + i) for i in range(2)]
+    graphed = False
+    if args.graph:
+        try:
+            engine.enable_graph(batches[0])
+            graphed = True
+            _log('forward+backward captured in a hipGraph')
+        except Exception as e:  # capture is an optimisation of launch overhead only; eager runs the same kernels
+            engine._graph = None
+            torch.cuda.synchronize()
+            import traceback
+            _log(f'hipGraph capture failed ({type(e).__name__}); running eager\n' + traceback.format_exc())
     for i in range(args.warmup):
         engine.step(batches[i % 2])
         torch.cuda.synchronize()
@@ -166,10 +177,12 @@ def run_train(args, rank, world, device):
     _log(f'timed region: {args.steps} steps in {dt:.3f}s')
     # profiled pass (same workload, same process): per-kernel HIP-event timings of the library kernels
     recs = []
+    saved_graph, engine._graph = getattr(engine, '_graph', None), None   # events are recorded at launch: eager pass
     with profiler.profile(recs):
         for i in range(2):
             engine.step(batches[i % 2])
         torch.cuda.synchronize()
+    engine._graph = saved_graph
     result = dict(
         metric='edlora_train_images_per_sec_512_sd15', value=round(B * world * args.steps / dt, 4), unit='images/s',
         n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
@@ -178,7 +191,8 @@ def run_train(args, rank, world, device):
         config=dict(workload='BASELINE.json configs[1]: single-concept ED-LoRA tune, SD-1.5 UNet/CLIP/VAE '
                              f'(random init), {size}x{size}, LoRA rank 4 on Attention+CLIPAttention, attn_reg on, '
                              f'batch {B}/GPU', global_batch=B * world, per_gpu_batch=B, image_size=size,
-                    parallelism=f'dp{world}', grad_bucket_bytes=engine.bucket.nbytes, preset=args.preset),
+                    parallelism=f'dp{world}', grad_bucket_bytes=engine.bucket.nbytes, preset=args.preset,
+                    hipgraph=graphed),
         roofline=roofline_from_profile(recs) if recs else None,
         kernels=[dict(name=r['name'], calls_per_step=r['calls'] / 2, avg_us=round(r['avg_us'], 2),
                       ms_per_step=round(r['total_ms'] / 2, 3),
@@ -264,6 +278,7 @@ def main():
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--channels-last', type=int, default=0)
+    ap.add_argument('--graph', type=int, default=1, help='capture fwd+bwd of the train step in a hipGraph')
     args = ap.parse_args()
     from mixofshow.parallel import dp
     rank, world, local = dp.init_distributed()

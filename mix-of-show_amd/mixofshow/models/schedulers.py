@@ -27,7 +27,11 @@ class DDPMScheduler:
         self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
 
     def _coeffs(self, timesteps, like):
-        acp = self.alphas_cumprod.to(device=like.device, dtype=like.dtype)
+        key = (like.device, like.dtype)                  # table resident per device: no H2D copy inside a step
+        cache = self.__dict__.setdefault('_acp_cache', {})
+        acp = cache.get(key)
+        if acp is None:
+            acp = cache[key] = self.alphas_cumprod.to(device=like.device, dtype=like.dtype)
         a = acp[timesteps]**0.5
         s = (1 - acp[timesteps])**0.5
         while a.dim() < like.dim():

@@ -25,7 +25,12 @@ class TrainEngine:
         assert optim_type == 'AdamW', 'only support AdamW now'
         groups = trainer.get_params_to_optimize()
         dev = trainer.concept_embedding.device
-        self.optimizer = torch.optim.AdamW(groups, **optim_cfg, foreach=True)
+        # fused multi-tensor AdamW on the device (one kernel per group instead of ~10 foreach kernels over 105 small
+        # tensors); it also takes GradScaler's grad_scale / found_inf on the device, so the fp16 step has no host sync
+        if dev.type == 'cuda':
+            self.optimizer = torch.optim.AdamW(groups, **optim_cfg, fused=True)
+        else:
+            self.optimizer = torch.optim.AdamW(groups, **optim_cfg, foreach=True)
         self.base_lrs = [g['lr'] for g in self.optimizer.param_groups]
         self.bucket = dp.FlatGradBucket(trainer.trainable_parameters())
         self.mixed_precision = mixed_precision
@@ -59,12 +64,87 @@ class TrainEngine:
                         if p is not None and not p.requires_grad and p.dtype == torch.float32:
                             p.data = p.data.to(dtype)
 
+    # ---- hipGraph mode ------------------------------------------------------------------------------------
+    def enable_graph(self, example_batch, warmup=2):
+        """Capture forward + backward of one micro-batch (about 4.5 k kernel launches for SD-1.5) in a hipGraph and
+        replay it every step. Inputs live in static device buffers; the host only tokenises, copies and replays.
+        The all-reduce, the optimiser update, GradScaler bookkeeping and the embedding-norm rule stay eager (a
+        handful of launches). Shapes (batch, image size, tokens per prompt) are fixed by `example_batch`."""
+        assert self.grad_accum == 1, 'graph mode captures exactly one micro-batch per optimiser step'
+        import os
+        if os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') != '0':
+            raise RuntimeError('TrainEngine.enable_graph needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment '
+                               'before the HIP runtime starts (mos_path.py sets it): the ROCm 7.2 packet-capture '
+                               'graph path faults when eager launches interleave with replays of this graph')
+        tr = self.trainer
+        dev = tr.concept_embedding.device
+        st = {}
+        for k in ('images', 'masks', 'img_masks', 'noise', 'timesteps', 'latents'):
+            v = example_batch.get(k)
+            if torch.is_tensor(v):
+                v = v.to(dev)
+                if k == 'images' and self.channels_last:
+                    v = v.contiguous(memory_format=torch.channels_last)
+                st[k] = v.clone()
+        B = (st.get('images', st.get('latents'))).shape[0]
+        ids, pos = tr.tokenize(example_batch['prompts'], B)
+        st['ids'] = ids.to(dev)
+        st['pos'] = pos.to(dev) if pos is not None else None
+        self._static = st
+        self._token_cache = {}
+
+        def fwd_bwd():
+            self.bucket.zero()
+            with torch.autocast(dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                loss = tr(st.get('images'), None, st.get('masks', st['img_masks']), st['img_masks'],
+                          noise=st.get('noise'), timesteps=st.get('timesteps'), latents=st.get('latents'),
+                          text_input_ids=st['ids'], token_positions=st['pos'])
+            self.scaler.scale(loss).backward()
+            return loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_loss = fwd_bwd()
+        return self
+
+    def _graph_step(self, batch):
+        tr, st = self.trainer, self._static
+        for k in ('images', 'masks', 'img_masks', 'noise', 'timesteps', 'latents'):
+            if k in st and torch.is_tensor(batch.get(k)):
+                v = batch[k]
+                # an async copy out of pageable host memory may run after the host tensor is gone: only device or
+                # pinned sources are copied without blocking
+                st[k].copy_(v, non_blocking=(v.is_cuda or v.is_pinned()))
+        # token ids of a caption set are a pure function of the strings: keep them on the device (a concept's
+        # training set is a handful of captions), so a steady-state step has no host->device traffic at all
+        key = tuple(batch['prompts'])
+        ent = self._token_cache.get(key)
+        if ent is None:
+            ids, pos = tr.tokenize(batch['prompts'], st['ids'].shape[0] // (16 if tr.enable_edlora else 1))
+            dev = st['ids'].device
+            ent = (ids.to(dev), pos.to(dev) if pos is not None else None)     # blocking uploads
+            if len(self._token_cache) < 4096:
+                self._token_cache[key] = ent
+        st['ids'].copy_(ent[0])
+        if ent[1] is not None:
+            st['pos'].copy_(ent[1])
+        self._graph.replay()
+        return self._finish_step(self._static_loss)
+
     def lr_factor(self, step):
         # diffusers get_scheduler('linear', warmup 0): lr * max(0, (T - step) / T)  (train_edlora.py:85-90)
         return max(0.0, float(self.total_iter - step) / float(max(1.0, self.total_iter)))
 
     def step(self, batch):
         """One micro-batch; performs the optimiser update every `grad_accum` calls. Returns a dict of device scalars."""
+        if getattr(self, '_graph', None) is not None:
+            return self._graph_step(batch)
         tr = self.trainer
         if self._micro == 0:
             self.bucket.zero()
@@ -78,10 +158,14 @@ class TrainEngine:
             loss = tr(images, batch['prompts'], masks, batch['img_masks'], **extra)
         self.scaler.scale(loss / self.grad_accum).backward()
         self._micro += 1
-        out = {'loss': loss.detach()}
         if self._micro < self.grad_accum:
-            return out
+            return {'loss': loss.detach()}
         self._micro = 0
+        return self._finish_step(loss.detach())
+
+    def _finish_step(self, loss):
+        tr = self.trainer
+        out = {'loss': loss}
         self.bucket.allreduce_mean()                      # RCCL all-reduce of LoRA + concept-row grads only
         for g, base in zip(self.optimizer.param_groups, self.base_lrs):
             g['lr'] = base * self.lr_factor(self.global_step)

@@ -186,7 +186,20 @@ class EDLoRATrainer(nn.Module):
             f'each prompt must contain the same number (1..4) of concept tokens, got {[len(p) for p in pos]}'
         return torch.tensor(pos, dtype=torch.int32)
 
-    def forward(self, images, prompts, masks, img_masks, noise=None, timesteps=None, latents=None):
+    def tokenize(self, prompts, batch):
+        """Host side of the text path: 16-way concept binding + tokenisation (+ positions of the concept tokens in
+        the first prompt of each sample). Returns CPU tensors (ids (B*16, 77) int64, positions (B, T) int32 | None)."""
+        if self.enable_edlora:
+            prompts = bind_concept_prompt(prompts, new_concept_cfg=self.new_concept_cfg)
+        ids = self.tokenizer(prompts, padding='max_length', max_length=self.tokenizer.model_max_length,
+                             truncation=True, return_tensors='pt').input_ids
+        pos = self._concept_positions(ids, batch) if self.attn_reg_weight is not None else None
+        return ids, pos
+
+    def forward(self, images, prompts, masks, img_masks, noise=None, timesteps=None, latents=None,
+                text_input_ids=None, token_positions=None):
+        """`text_input_ids` / `token_positions` (device tensors from `tokenize`) bypass the host tokeniser: this is
+        what makes the step capturable in a hipGraph (TrainEngine.enable_graph)."""
         if latents is None:
             latents = self.vae.encode(images).latent_dist.sample() * 0.18215
         bsz = latents.shape[0]
@@ -199,17 +212,16 @@ class EDLoRATrainer(nn.Module):
         timesteps = timesteps.long()
         noisy_latents = self.scheduler.add_noise(latents, noise.to(latents.dtype), timesteps)
 
-        if self.enable_edlora:
-            prompts = bind_concept_prompt(prompts, new_concept_cfg=self.new_concept_cfg)
-        ids_cpu = self.tokenizer(prompts, padding='max_length', max_length=self.tokenizer.model_max_length,
-                                 truncation=True, return_tensors='pt').input_ids
-        text_input_ids = ids_cpu.to(latents.device)
+        if text_input_ids is None:
+            ids_cpu, pos_cpu = self.tokenize(prompts, bsz)
+            text_input_ids = ids_cpu.to(latents.device)
+            token_positions = pos_cpu.to(latents.device) if pos_cpu is not None else None
         encoder_hidden_states = self.text_encoder(text_input_ids)[0]
         if self.enable_edlora:
             encoder_hidden_states = encoder_hidden_states.reshape(bsz, -1, *encoder_hidden_states.shape[1:])
 
         if self.attn_reg_weight is not None:
-            self.controller.set_token_positions(self._concept_positions(ids_cpu, bsz).to(latents.device))
+            self.controller.set_token_positions(token_positions)
         model_pred = self.unet(noisy_latents, timesteps, encoder_hidden_states).sample
 
         if self.scheduler.config.prediction_type == 'epsilon':

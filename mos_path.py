@@ -10,3 +10,11 @@ if PKG_DIR not in sys.path:
     sys.path.insert(0, PKG_DIR)
 if REPO_ROOT not in sys.path:
     sys.path.insert(0, REPO_ROOT)
+
+# hipGraph replays of the captured training step (TrainEngine.enable_graph): the ROCm 7.2 runtime's "graph packet
+# capture" fast path (pre-baked AQL packets + a per-graph kernel-argument pool) faults with
+# HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION once ordinary launches are interleaved with replays of a ~4.6 k-node
+# graph (reproduced deterministically on MI355X at the 9th optimiser step). Node-by-node graph
+# launch is unaffected and costs nothing here (the step stays GPU-bound), so it is selected before the HIP runtime
+# initialises. Every entry point imports this module before torch touches the device.
+os.environ.setdefault('DEBUG_CLR_GRAPH_PACKET_CAPTURE', '0')

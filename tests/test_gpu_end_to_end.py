@@ -182,6 +182,51 @@ def test_training_steps_match_reference_path_and_engine_runs():
     assert engine.global_step == 3 and not bool(engine.stop_flag)   # synthetic CLIP rows have real-CLIP-like norms
 
 
+def test_hipgraph_step_equals_eager_step():
+    """TrainEngine.enable_graph replays the same kernels: 3 steps with given latents/noise/timesteps must give the
+    eager engine's losses and parameters (same seeds, two trainers)."""
+    from bench import TRAIN_OPT, build_trainer, synthetic_batch
+    from mixofshow.pipelines.train_loop import TrainEngine
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for step in range(3):
+        b = synthetic_batch(B, 256, 'cpu', 70 + step)
+        b.update(latents=torch.randn(B, 4, 32, 32, generator=g), noise=torch.randn(B, 4, 32, 32, generator=g),
+                 timesteps=torch.randint(0, 1000, (B, ), generator=g))
+        b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+        b['images'] = None
+        batches.append(b)
+    results = []
+    for graphed in (False, False, True):
+        tr = build_trainer('small', torch.device(DEV))
+        torch.manual_seed(1)
+        with torch.no_grad():
+            for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+                l.lora_up.weight.normal_(0, 0.02)
+        engine = TrainEngine(tr, dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g'])), total_iter=100,
+                             mixed_precision='fp16')
+        if graphed:
+            engine.enable_graph(batches[0])
+            assert engine._graph is not None
+        losses = [engine.step(b)['loss'].item() for b in batches]
+        results.append((losses, [p.detach().float().clone() for p in tr.trainable_parameters()]))
+    (le, pe), (le2, pe2), (lg, pg) = results
+
+    def rel(pa, pb):
+        num = sum((a - b).pow(2).sum().item() for a, b in zip(pa, pb))
+        return (num / sum(a.pow(2).sum().item() for a in pa)) ** 0.5
+
+    # run-to-run spread of the eager step itself (MIOpen's backward-weight kernels use atomics; Adam's first steps
+    # turn a sign flip of a noise-level gradient into a full +-lr move) is the yardstick for "same kernels"
+    spread = rel(pe, pe2)
+    print(f'[parity] eager losses {le} / {le2}, graph losses {lg}; param rel diff eager-eager {spread:.3e}, '
+          f'graph-eager {rel(pe, pg):.3e}')
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-4 * abs(a)
+    assert rel(pe, pg) <= max(2.0 * spread, 1e-6)
+
+
 def test_update_quasi_newton_vs_reference_golden(golden):
     """The Gram-form fp64 L-BFGS (HIP) against the iterates the REAL reference code produced (fp32, direct form)."""
     from mixofshow.utils.lsq import update_quasi_newton

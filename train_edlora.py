@@ -21,7 +21,7 @@ from mixofshow.utils.options import dict2str, load_options
 
 
 def _to_device(batch, device):
-    return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    return {k: (v.to(device, non_blocking=v.is_pinned()) if torch.is_tensor(v) else v) for k, v in batch.items()}
 
 
 def train(root_path, args):
@@ -70,8 +70,14 @@ def train(root_path, args):
     trainer.unet.train()
     trainer.text_encoder.train()
     t0 = time.time()
+    use_graph = bool(opt['train'].get('hipgraph', False)) and device.type == 'cuda' and accum == 1
     while engine.global_step < total_iter:
-        out = engine.step(_to_device(next(it), device))
+        batch = _to_device(next(it), device)
+        if use_graph and getattr(engine, '_graph', None) is None:
+            engine.enable_graph(batch)       # fixed batch shape: the loader drops ragged tails in this mode
+            if rank == 0:
+                logger.info('forward+backward captured in a hipGraph')
+        out = engine.step(batch)
         if 'Norm_mean' not in out:
             continue
         step = engine.global_step
