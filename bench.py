@@ -240,7 +240,8 @@ def run_regional(args, rank, world, device):
 
     def sample():
         return pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50,
-                    guidance_scale=7.5, latents=latents.clone(), output_type='latent').images
+                    guidance_scale=7.5, latents=latents.clone(), output_type='latent',
+                    hipgraph=(args.graph >= 2)).images
 
     for _ in range(args.warmup):
         sample()
@@ -250,7 +251,9 @@ def run_regional(args, rank, world, device):
         out = sample()
     _sync_barrier(world)
     dt = _max_over_ranks(time.perf_counter() - t0, world, device)
+    graphed = bool(getattr(pipe, 'last_call_graphed', False))
     recs = []
+    args.graph = 0                                   # HIP events are recorded at launch: profiled pass runs eagerly
     with profiler.profile(recs):
         sample()
         torch.cuda.synchronize()
@@ -259,7 +262,8 @@ def run_regional(args, rank, world, device):
                 higher_is_better=False, scaling='weak', vs_baseline=None, dtype='fp16', data='synthetic',
                 config=dict(workload='BASELINE.json configs[4]: 3-region (potter/hermione/thanos) 512x768, 50 '
                                      'DPM-Solver++(2M) steps, CFG 7.5, batch 1, SD-1.5 random init, no adapter',
-                            replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all())),
+                            replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all()),
+                            hipgraph=graphed),
                 roofline=roofline_from_profile(recs) if recs else None,
                 kernels=[dict(name=r['name'], calls=r['calls'], avg_us=round(r['avg_us'], 2),
                               total_ms=round(r['total_ms'], 3)) for r in recs[:12]],
@@ -278,7 +282,8 @@ def main():
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--channels-last', type=int, default=0)
-    ap.add_argument('--graph', type=int, default=1, help='capture fwd+bwd of the train step in a hipGraph')
+    ap.add_argument('--graph', type=int, default=1, help='train: capture fwd+bwd of the step in a hipGraph (default 1); regional: 2 = replay the UNet call '
+                         'from a hipGraph (the loop is GPU-bound, no gain measured)')
     args = ap.parse_args()
     from mixofshow.parallel import dp
     rank, world, local = dp.init_distributed()

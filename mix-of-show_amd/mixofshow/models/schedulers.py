@@ -75,6 +75,7 @@ class DPMSolverMultistepScheduler:
         self.num_inference_steps = len(self._ts_list)
         self.model_outputs = [None] * self.config.solver_order
         self.lower_order_nums = 0
+        self._step_index = 0
 
     def scale_model_input(self, sample, timestep=None):
         return sample
@@ -88,8 +89,15 @@ class DPMSolverMultistepScheduler:
         raise ValueError(self.config.prediction_type)
 
     def step(self, model_output, timestep, sample, **kwargs):
-        t = int(timestep)
-        idx = self._ts_list.index(t)
+        if torch.is_tensor(timestep) and timestep.is_cuda:
+            # the loop hands over `self.timesteps[i]` in order: count the steps instead of reading the value back
+            # (a device->host read here would drain the queue once per denoising step)
+            idx = self._step_index
+            t = self._ts_list[idx]
+        else:
+            t = int(timestep)
+            idx = self._ts_list.index(t)
+        self._step_index = idx + 1
         last = idx == len(self._ts_list) - 1
         prev_t = 0 if last else self._ts_list[idx + 1]
         few = len(self._ts_list) < 15

@@ -200,7 +200,7 @@ class EDLoRAPipeline(StableDiffusionPipeline):
     def __call__(self, prompt=None, height=None, width=None, num_inference_steps=50, guidance_scale=7.5,
                  negative_prompt=None, num_images_per_prompt=1, eta=0.0, generator=None, latents=None,
                  prompt_embeds=None, negative_prompt_embeds=None, output_type='pil', return_dict=True, callback=None,
-                 callback_steps=1, cross_attention_kwargs=None):
+                 callback_steps=1, cross_attention_kwargs=None, hipgraph=None):
         height = height or self.unet.config.sample_size * self.vae_scale_factor
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps, negative_prompt, prompt_embeds, negative_prompt_embeds)
@@ -215,11 +215,26 @@ class EDLoRAPipeline(StableDiffusionPipeline):
         timesteps = self.scheduler.timesteps
         latents = self.prepare_latents(batch_size * num_images_per_prompt, self.unet.in_channels, height, width,
                                        prompt_embeds.dtype, device, generator, latents)
+
+        def unet_call(x, t):
+            return self.unet(x, t, encoder_hidden_states=prompt_embeds,
+                             cross_attention_kwargs=cross_attention_kwargs).sample
+
+        # `hipgraph=True` (opt-in; not with an attention-recording controller, which keeps Python-side state per
+        # call): step 0 is eager, the UNet call is captured at step 1 and replayed afterwards.
+        from mixofshow.utils import hipgraph as hipgraph_util
+        hipgraph = (bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
+                    and not hasattr(self, 'controller'))
+        graphed = None
+        self.last_call_graphed = False
         for i, t in enumerate(timesteps):
             model_in = torch.cat([latents] * 2) if do_cfg else latents
             model_in = self.scheduler.scale_model_input(model_in, t)
-            noise_pred = self.unet(model_in, t, encoder_hidden_states=prompt_embeds,
-                                   cross_attention_kwargs=cross_attention_kwargs).sample
+            if hipgraph and i == 1:
+                graphed = hipgraph_util.try_capture(unet_call, model_in, t)
+                hipgraph = graphed is not None
+                self.last_call_graphed = hipgraph
+            noise_pred = graphed(model_in, t) if graphed is not None else unet_call(model_in, t)
             if do_cfg:
                 uncond, text = noise_pred.chunk(2)
                 noise_pred = uncond + guidance_scale * (text - uncond)

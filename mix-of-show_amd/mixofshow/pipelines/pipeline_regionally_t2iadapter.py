@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from mixofshow.hip import functional as F_hip
 from mixofshow.models.attention import _check_plain, fused_attention_layer, project
 from mixofshow.pipelines.pipeline_edlora import StableDiffusionPipeline, bind_concept_prompt
+from mixofshow.utils import hipgraph as hipgraph_util
 
 
 def region_feature_boxes(region_fracs, feat_h, feat_w):
@@ -243,7 +244,7 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
                  region_sketch_adaptor_weight='', height=None, width=None, num_inference_steps=50, guidance_scale=7.5,
                  negative_prompt=None, num_images_per_prompt=1, eta=0.0, generator=None, latents=None,
                  prompt_embeds=None, negative_prompt_embeds=None, output_type='pil', return_dict=True, callback=None,
-                 callback_steps=1, cross_attention_kwargs=None, adapter_states=None):
+                 callback_steps=1, cross_attention_kwargs=None, adapter_states=None, hipgraph=None):
         device = self._execution_device
         self.check_inputs(prompt, height, width, callback_steps, negative_prompt, prompt_embeds, negative_prompt_embeds)
         batch_size = 1 if isinstance(prompt, str) else (len(prompt) if isinstance(prompt, list) else prompt_embeds.shape[0])
@@ -270,12 +271,26 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
         if adapter_states is not None and do_cfg:
             adapter_states = [torch.cat([s] * 2, dim=0) if s.shape[0] == batch_size else s for s in adapter_states]
         cak = {'region_list': region_list, 'height': height, 'width': width}
+
+        def unet_call(x, t):
+            residuals = [s.clone() for s in adapter_states] if adapter_states is not None else None
+            return self.unet(x, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak,
+                             down_block_additional_residuals=residuals).sample
+
+        # `hipgraph=True` (opt-in): step 0 runs eagerly (it fills the per-layer source K/V caches), the UNet call is
+        # captured at step 1 and replayed from then on. Off by default: at 512x768 with a CFG pair the loop is
+        # GPU-bound once the scheduler no longer reads the timestep back, so replay gains nothing.
+        hipgraph = bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
+        graphed = None
+        self.last_call_graphed = False
         for i, t in enumerate(timesteps):
             model_in = torch.cat([latents] * 2) if do_cfg else latents
             model_in = self.scheduler.scale_model_input(model_in, t)
-            residuals = [s.clone() for s in adapter_states] if adapter_states is not None else None
-            noise_pred = self.unet(model_in, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak,
-                                   down_block_additional_residuals=residuals).sample
+            if hipgraph and i == 1:
+                graphed = hipgraph_util.try_capture(unet_call, model_in, t)
+                hipgraph = graphed is not None
+                self.last_call_graphed = hipgraph
+            noise_pred = graphed(model_in, t) if graphed is not None else unet_call(model_in, t)
             if do_cfg:
                 uncond, text = noise_pred.chunk(2)
                 noise_pred = uncond + guidance_scale * (text - uncond)

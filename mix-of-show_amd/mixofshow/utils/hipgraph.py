@@ -1,0 +1,50 @@
+"""hipGraph replay of a fixed-shape device computation (the UNet call of a sampling loop).
+
+A 50-step sample issues the same ~1.6 k kernel launches 50 times with only the latents and the timestep changing.
+`GraphedCall` captures `fn(*tensors)` once (inputs copied into static buffers) and replays it; the host then spends
+one launch per denoising step instead of ~1.6 k, and the GPU never waits for the Python dispatcher.
+The capture needs node-by-node graph launch on ROCm 7.2 (see mos_path.py).
+"""
+import os
+import warnings
+
+import torch
+
+
+def graphs_usable(device):
+    return (torch.device(device).type == 'cuda' and torch.cuda.is_available()
+            and os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0')
+
+
+class GraphedCall:
+    """`fn` must be free of host<->device synchronisation and allocate only through torch. Everything `fn` reads
+    besides `example_inputs` (weights, prompt embeddings, cached K/V, adapter features) is baked in by address and must
+    stay alive and unchanged in place for the lifetime of this object."""
+
+    def __init__(self, fn, *example_inputs):
+        self.static_in = [x.clone() for x in example_inputs]
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = fn(*self.static_in)
+
+    def __call__(self, *inputs):
+        for s, x in zip(self.static_in, inputs):
+            s.copy_(x)
+        self.graph.replay()
+        return self.static_out
+
+
+def try_capture(fn, *example_inputs):
+    """GraphedCall or None (with a warning): capture is an optimisation of launch overhead, the eager path computes
+    the same kernels."""
+    prev = torch.cuda.current_stream()
+    try:
+        return GraphedCall(fn, *example_inputs)
+    except Exception:  # noqa: BLE001
+        import traceback
+        # torch.cuda.graph.__exit__ does not restore the stream when ending an invalidated capture raises: put the
+        # caller's stream back and retire the poisoned capture stream before going on eagerly
+        torch.cuda.set_stream(prev)
+        torch.cuda.graph.default_capture_stream = None
+        warnings.warn('hipGraph capture failed; continuing eagerly\n' + traceback.format_exc())
+        return None
