@@ -24,12 +24,36 @@
 #include <type_traits>
 #include "mos_common.h"
 
+// tuning knobs of the backward kernels (tools/build_variant.sh overrides them for experiments)
+#ifndef MOS_DQ_OCC
+#define MOS_DQ_OCC 2
+#endif
+#ifndef MOS_DQ_NW
+#define MOS_DQ_NW 4
+#endif
+#ifndef MOS_STAGGER
+#define MOS_STAGGER 0   // 1: odd wave slots run at priority 1; 2: odd wave slots start ~half a tile late
+#endif
+#ifndef MOS_DKDV_LDS_PAD
+#define MOS_DKDV_LDS_PAD 0   // experiment: extra dynamic LDS per block (forces one block per CU)
+#endif
+#ifndef MOS_DKDV_NW
+#define MOS_DKDV_NW 4
+#endif
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
 constexpr int KV_TILE = 64;
-constexpr int TS = KV_TILE + 4;  // transposed-tile row stride (68 el = 136 B = 8*17: b64 reads conflict-free)
+// transposed-tile row stride: 72 el = 144 B = 16*9 -> every row is 16-byte aligned and the 16 lanes of a
+// ds_read_b128 lane group (consecutive rows) land on 16 distinct 16-byte bank slots (9 is odd): conflict-free
+constexpr int TS = KV_TILE + 8;
+// Column order inside a transposed tile: within each group of 16 tokens, bits 2 and 3 of the token index are
+// swapped, i.e. tokens are stored [0-3, 8-11, 4-7, 12-15]. A lane half h needs tokens {4h..4h+3, 8+4h..8+4h+3} of
+// the group (the rows its S^T accumulator registers hold, see the header comment): with this order they are 8
+// CONTIGUOUS elements, one ds_read_b128 (256 B/clk) instead of a ds_read2_b64 (128 B/clk).
+__device__ __forceinline__ constexpr int tr_col(int c) { return (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1); }
 
 template <int D>
 struct HD {
@@ -63,50 +87,24 @@ struct AttnBwdArgs {
     float scale;
 };
 
-// ---- LDS staging -----------------------------------------------------------------------------
-// Row-major tile [64][RS]: rows = tokens, 16-byte chunks; rows >= nvalid are zero-filled.
-template <typename T, int D>
-__device__ __forceinline__ void stage_rows(T* lds, const T* g, int64_t rs, int nvalid, int tid) {
-    constexpr int DCH = HD<D>::DCH, RS = HD<D>::RS;
-#pragma unroll
-    for (int c = tid; c < KV_TILE * DCH; c += 256) {
-        const int row = c / DCH, cc = c - row * DCH;
-        const u32x4 v = (row < nvalid) ? ld16(g + (int64_t)row * rs + cc * 8) : u32x4{0, 0, 0, 0};
-        st16(lds + row * RS + cc * 8, v);
-    }
-}
-// Transposed tile [DV][TS]: element (d, token). Two token rows are loaded per item and packed so the
-// store is one conflict-free ds_write_b32 per (d, token pair).
-template <typename T, int D>
-__device__ __forceinline__ void stage_transposed(T* ldsT, const T* g, int64_t rs, int nvalid, int tid) {
-    constexpr int DCH = HD<D>::DCH;
-#pragma unroll
-    for (int it = tid; it < 32 * DCH; it += 256) {
-        const int p = it & 31, cc = it >> 5;
-        const int r0 = 2 * p, r1 = 2 * p + 1;
-        const u32x4 v0 = (r0 < nvalid) ? ld16(g + (int64_t)r0 * rs + cc * 8) : u32x4{0, 0, 0, 0};
-        const u32x4 v1 = (r1 < nvalid) ? ld16(g + (int64_t)r1 * rs + cc * 8) : u32x4{0, 0, 0, 0};
-        uint32_t* dst = reinterpret_cast<uint32_t*>(ldsT + (cc * 8) * TS + 2 * p);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) dst[i * (TS / 2)] = half_of(v0, i) | (half_of(v1, i) << 16);
-    }
-}
-template <typename T, int D>
+// ---- LDS tiles ----------------------------------------------------------------------------------
+// Row-major tile [64][RS]: rows = tokens. Transposed tile [DV][TS]: element (d, token), columns in tr_col order.
+template <typename T, int D, int NT = 256>
 __device__ __forceinline__ void zero_row_pads(T* lds, int tid) {  // columns [D, DK) of a row-major tile
     constexpr int DK = HD<D>::DK, RS = HD<D>::RS;
     if constexpr (DK > D) {
-        for (int c = tid; c < KV_TILE * ((DK - D) / 8); c += 256) {
+        for (int c = tid; c < KV_TILE * ((DK - D) / 8); c += NT) {
             const int row = c / ((DK - D) / 8), cc = c % ((DK - D) / 8);
             st16(lds + row * RS + D + cc * 8, u32x4{0, 0, 0, 0});
         }
     }
 }
-template <typename T, int D>
+template <typename T, int D, int NT = 256>
 __device__ __forceinline__ void zero_tr_pads(T* ldsT, int tid) {  // rows [D, DV) of a transposed tile
     constexpr int DV = HD<D>::DV;
     if constexpr (DV > D) {
         uint32_t* p = reinterpret_cast<uint32_t*>(ldsT + D * TS);
-        for (int c = tid; c < (DV - D) * TS / 2; c += 256) p[c] = 0u;
+        for (int c = tid; c < (DV - D) * TS / 2; c += NT) p[c] = 0u;
     }
 }
 // B-operand fragments of a register-resident row (query / dO / key / value row of this lane).
@@ -128,67 +126,127 @@ __device__ __forceinline__ typename MT<T>::v8 acc_to_bfrag(const f32x16& x, int 
 // A operand of a transposed tile for contraction step (t, s2): rows = 32*dt + (l&31).
 template <typename T>
 __device__ __forceinline__ typename MT<T>::v8 tr_afrag(const T* ldsT_row, int t, int s2, int hh) {
-    const T* p = ldsT_row + 32 * t + 16 * s2 + 4 * hh;
-    const u32x2 lo = ld8(p), hi = ld8(p + 8);
-    return as_v8<T>(u32x4{lo[0], lo[1], hi[0], hi[1]});
+    return as_v8<T>(ld16(ldsT_row + 32 * t + 16 * s2 + 8 * hh));
 }
 __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // ---- split staging (issue global loads early, write LDS late: the loads fly under the MFMAs) --------
-// Loads are UNCONDITIONAL (addresses clamped into the tile) and the zero fill of out-of-range rows happens at
-// store time: a `cond ? load : 0` select makes hipcc branch around the load and wait vmcnt(0) right after it,
-// which serialises the prefetch behind the MFMAs it is supposed to overlap (cdna guide, ".s-level traps" (c)).
+// Tiles are fetched with BUFFER loads through a descriptor that covers exactly the valid rows of one (batch, head)
+// slice: rows past the end of the sequence read as zeros in hardware, so the ragged last tile needs no clamped
+// addresses, no selects and no masks, and the per-tile address arithmetic is one 32-bit add per load (a wave
+// issues about one instruction per 4 cycles, so this bookkeeping is paid in MFMA issue slots). A plain
+// `cond ? load : 0` would also make hipcc branch around the load and wait vmcnt(0) right after it, serialising
+// the prefetch behind the MFMAs it is supposed to overlap (cdna guide, ".s-level traps" (c)).
+// Two workgroups share a CU (two waves per SIMD) and run the same MFMA-run / VALU-run program: started together
+// and arbitrated round-robin they stay in lockstep, both asking for the MFMA pipe, then both for the VALU, and
+// the pipes never overlap. Breaking the symmetry between the two wave slots of a SIMD lets one wave's MFMA run
+// cover the other's exp/convert phase.
+__device__ __forceinline__ void desync_wave_slots() {
+#if MOS_STAGGER
+    const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) ;   // HW_ID[3:0] = wave slot within the SIMD
+#if MOS_STAGGER == 1
+    if (slot & 1) __builtin_amdgcn_s_setprio(1);
+#else
+    if (slot & 1) { __builtin_amdgcn_s_sleep(16); }   // 16 x 64 clk
+#endif
+#endif
+}
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// descriptor of `bytes` valid bytes at p; p and bytes are wave-uniform (made provably so: cdna guide T20)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0,
+                                             (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// bytes of a token-major slice: n rows of D contiguous elements, row stride rs elements (other heads in between)
 template <typename T, int D>
+__device__ __forceinline__ uint32_t slice_bytes(int n, int64_t rs) {
+    return (uint32_t)(((int64_t)(n - 1) * rs + D) * (int64_t)sizeof(T));
+}
+__device__ __forceinline__ u32x4 ldbuf16(rsrc_t src, int byte_off) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, byte_off, 0, 0));
+}
+
+template <typename T, int D, int NT = 256>
 struct RowStage {
     static constexpr int DCH = HD<D>::DCH, RS = HD<D>::RS;
-    static constexpr int N = (KV_TILE * DCH + 255) / 256;
+    static constexpr int N = (KV_TILE * DCH + NT - 1) / NT;
     u32x4 r[N];
-    int nv;
-    __device__ __forceinline__ void load(const T* g, int64_t rs, int nvalid, int tid) {
-        nv = nvalid;  // >= 1
+    int voff[N];   // byte offset of chunk i inside a tile: (row * rs + 8 * cc) * sizeof(T)
+    __device__ __forceinline__ void init(int64_t rs, int tid) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int c = min(tid + 256 * i, KV_TILE * DCH - 1);
+            const int c = min(tid + NT * i, KV_TILE * DCH - 1);
             const int row = c / DCH, cc = c - row * DCH;
-            r[i] = ld16(g + (int64_t)min(row, nvalid - 1) * rs + cc * 8);
+            voff[i] = (row * (int)rs + cc * 8) * (int)sizeof(T);
         }
+    }
+    __device__ __forceinline__ void load(rsrc_t src, int tile_byte_off) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) r[i] = ldbuf16(src, voff[i] + tile_byte_off);
     }
     __device__ __forceinline__ void store(T* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int c = tid + 256 * i;
+            const int c = tid + NT * i;
             const int row = c / DCH, cc = c - row * DCH;
-            if (c < KV_TILE * DCH) st16(lds + row * RS + cc * 8, row < nv ? r[i] : u32x4{0, 0, 0, 0});
+            if (N * NT <= KV_TILE * DCH || c < KV_TILE * DCH) st16(lds + row * RS + cc * 8, r[i]);
         }
     }
 };
-template <typename T, int D>
+template <typename T, int D, int NT = 256>
 struct TrStage {
     static constexpr int DCH = HD<D>::DCH;
-    static constexpr int N = (32 * DCH + 255) / 256;
+    static constexpr int N = (32 * DCH + NT - 1) / NT;
     u32x4 r0[N], r1[N];
-    int nv;
-    __device__ __forceinline__ void load(const T* g, int64_t rs, int nvalid, int tid) {
-        nv = nvalid;
+    int voff[N];   // byte offset of (row 2p, chunk cc); row 2p+1 is + row_bytes
+    int row_bytes;
+    __device__ __forceinline__ void init(int64_t rs, int tid) {
+        row_bytes = (int)rs * (int)sizeof(T);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int it = min(tid + 256 * i, 32 * DCH - 1);
+            const int it = min(tid + NT * i, 32 * DCH - 1);
             const int p = it & 31, cc = it >> 5;
-            r0[i] = ld16(g + (int64_t)min(2 * p, nvalid - 1) * rs + cc * 8);
-            r1[i] = ld16(g + (int64_t)min(2 * p + 1, nvalid - 1) * rs + cc * 8);
+            voff[i] = (2 * p * (int)rs + cc * 8) * (int)sizeof(T);
+        }
+    }
+    __device__ __forceinline__ void load(rsrc_t src, int tile_byte_off) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            r0[i] = ldbuf16(src, voff[i] + tile_byte_off);
+            r1[i] = ldbuf16(src, voff[i] + tile_byte_off + row_bytes);
+        }
+    }
+    // the row-major image [64][RS] of the same tile from the same registers (kernels that need both images of a
+    // tensor fetch it once)
+    __device__ __forceinline__ void store_rows(T* lds, int tid) const {
+        constexpr int RS = HD<D>::RS;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int it = tid + NT * i;
+            const int p = it & 31, cc = it >> 5;
+            if (N * NT <= 32 * DCH || it < 32 * DCH) {
+                st16(lds + (2 * p) * RS + cc * 8, r0[i]);
+                st16(lds + (2 * p + 1) * RS + cc * 8, r1[i]);
+            }
         }
     }
     __device__ __forceinline__ void store(T* ldsT, int tid) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int it = tid + 256 * i;
+            const int it = tid + NT * i;
             const int p = it & 31, cc = it >> 5;
-            if (it < 32 * DCH) {
-                const uint32_t m0 = (2 * p < nv) ? 0xffffu : 0u, m1 = (2 * p + 1 < nv) ? 0xffff0000u : 0u;
-                uint32_t* dst = reinterpret_cast<uint32_t*>(ldsT + (cc * 8) * TS + 2 * p);
+            if (N * NT <= 32 * DCH || it < 32 * DCH) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(ldsT + (cc * 8) * TS + tr_col(2 * p));
+                // word e of the packed pair = {row 2p+1 elem e (high half), row 2p elem e (low half)}:
+                // v_perm_b32 byte selectors over {src0 = r1 word (bytes 4..7), src1 = r0 word (bytes 0..3)}
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    dst[e * (TS / 2)] = (half_of(r0[i], e) & m0) | ((half_of(r1[i], e) << 16) & m1);
+                for (int w = 0; w < 4; ++w) {
+                    dst[(2 * w) * (TS / 2)] = __builtin_amdgcn_perm(r1[i][w], r0[i][w], 0x05040100u);
+                    dst[(2 * w + 1) * (TS / 2)] = __builtin_amdgcn_perm(r1[i][w], r0[i][w], 0x07060302u);
+                }
             }
         }
     }
@@ -217,20 +275,26 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
     // issued before the MFMAs of tile i and written to the other buffer after them; ONE barrier per tile.
     RowStage<T, D> kst;
     TrStage<T, D> vst;
+    kst.init(k_rs, tid);
+    vst.init(v_rs, tid);
+    const rsrc_t ksrc = make_rsrc(kbase, slice_bytes<T, D>(Nkv, k_rs));
+    const rsrc_t vsrc = make_rsrc(vbase, slice_bytes<T, D>(Nkv, v_rs));
+    const int k_tile_bytes = KV_TILE * (int)k_rs * (int)sizeof(T), v_tile_bytes = KV_TILE * (int)v_rs * (int)sizeof(T);
     __syncthreads();  // earlier users of the LDS buffers (previous source / prologue zeroing) are done
-    kst.load(kbase, k_rs, Nkv, tid);
-    vst.load(vbase, v_rs, Nkv, tid);
+    kst.load(ksrc, 0);
+    vst.load(vsrc, 0);
     kst.store(Ks_, tid);
     vst.store(Vt_, tid);
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the dK/dV kernel
     int cur = 0;
     for (int kv0 = 0; kv0 < Nkv; kv0 += KV_TILE, cur ^= 1) {
         const T* Ks = Ks_ + cur * HD<D>::ROW_TILE_ELEMS;
         const T* Vt = Vt_ + cur * HD<D>::TR_TILE_ELEMS;
         const bool more = kv0 + KV_TILE < Nkv;
         if (more) {
-            kst.load(kbase + (int64_t)(kv0 + KV_TILE) * k_rs, k_rs, Nkv - kv0 - KV_TILE, tid);
-            vst.load(vbase + (int64_t)(kv0 + KV_TILE) * v_rs, v_rs, Nkv - kv0 - KV_TILE, tid);
+            kst.load(ksrc, (kv0 / KV_TILE + 1) * k_tile_bytes);
+            vst.load(vsrc, (kv0 / KV_TILE + 1) * v_tile_bytes);
         }
 
         f32x16 s[NQ][2];
@@ -490,8 +554,14 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, int64_t o_bs, int6
 
 // ---- backward dQ: one wave = 32 queries, loop over key tiles -----------------------------------------
 //   S^T = K Q^T ; P^T = exp(scale*S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - D) ; dQ^T += K^T dS^T
-template <typename T, int D, bool PCOLS>
-__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+// NW waves per block share each staged K / V / K^T tile. NW = 8 (512 threads, two blocks per CU = 4 waves per
+// SIMD): a wave's MFMA -> exp/VALU -> MFMA phases are serialised by data dependence, so the pipes only overlap across
+// waves; the kernels need < 128 VGPRs at d = 40, and the per-tile staging cost is shared by twice as many rows.
+template <typename T, int D, bool PCOLS, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MOS_DQ_OCC : D <= 80 ? 2 : 1))) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+    constexpr int NT = 64 * NW;
+    desync_wave_slots();
+    constexpr bool PIN = D <= 80 && NW == 4;   // explicit fragment prefetch where the registers allow it
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -503,15 +573,15 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(Att
     const int h = blockIdx.x % a.H;
     const int rest = blockIdx.x / a.H;
     const int qb = rest % a.nqb, b = rest / a.nqb;
-    const int qi = qb * 128 + wave * 32 + l31;
+    const int qi = qb * (32 * NW) + wave * 32 + l31;
     const bool qvalid = qi < a.Nq;
     const int qc = min(qi, a.Nq - 1);
 
 #pragma unroll
     for (int bf = 0; bf < 2; ++bf) {
-        zero_row_pads<T, D>(Ks_ + bf * RT, tid);
-        zero_row_pads<T, D>(Vs_ + bf * RT, tid);
-        zero_tr_pads<T, D>(Kt_ + bf * TT, tid);
+        zero_row_pads<T, D, NT>(Ks_ + bf * RT, tid);
+        zero_row_pads<T, D, NT>(Vs_ + bf * RT, tid);
+        zero_tr_pads<T, D, NT>(Kt_ + bf * TT, tid);
     }
 
     const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * D;
@@ -539,16 +609,21 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
 
-    RowStage<T, D> kst, vst;
-    TrStage<T, D> ktst;
+    RowStage<T, D, NT> vst;
+    TrStage<T, D, NT> ktst;      // K: one fetch, both LDS images
+    vst.init(a.v_rs, tid);
+    ktst.init(a.k_rs, tid);
+    const rsrc_t ksrc = make_rsrc(kp, slice_bytes<T, D>(a.Nkv, a.k_rs));
+    const rsrc_t vsrc = make_rsrc(vp, slice_bytes<T, D>(a.Nkv, a.v_rs));
+    const int k_tile_bytes = KV_TILE * (int)a.k_rs * (int)sizeof(T), v_tile_bytes = KV_TILE * (int)a.v_rs * (int)sizeof(T);
     __syncthreads();
-    kst.load(kp, a.k_rs, a.Nkv, tid);
-    vst.load(vp, a.v_rs, a.Nkv, tid);
-    ktst.load(kp, a.k_rs, a.Nkv, tid);
-    kst.store(Ks_, tid);
+    vst.load(vsrc, 0);
+    ktst.load(ksrc, 0);
+    ktst.store_rows(Ks_, tid);
     vst.store(Vs_, tid);
     ktst.store(Kt_, tid);
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the dK/dV kernel
     int cur = 0;
     for (int kv0 = 0; kv0 < a.Nkv; kv0 += KV_TILE, cur ^= 1) {
         const T* Ks = Ks_ + cur * RT;
@@ -556,21 +631,36 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(Att
         const T* Kt = Kt_ + cur * TT;
         const bool more = kv0 + KV_TILE < a.Nkv;
         if (more) {  // prefetch the next key tile into registers; written to the other LDS buffer after the MFMAs
-            const int nx = kv0 + KV_TILE;
-            kst.load(kp + (int64_t)nx * a.k_rs, a.k_rs, a.Nkv - nx, tid);
-            vst.load(vp + (int64_t)nx * a.v_rs, a.v_rs, a.Nkv - nx, tid);
-            ktst.load(kp + (int64_t)nx * a.k_rs, a.k_rs, a.Nkv - nx, tid);
+            const int nt = kv0 / KV_TILE + 1;
+            vst.load(vsrc, nt * v_tile_bytes);
+            ktst.load(ksrc, nt * k_tile_bytes);
         }
+        // fragment reads one stage ahead of their MFMAs, pinned with scheduling fences (see the dK/dV kernel)
+        v8 ak[KS], av[KS];
+        auto read_rows = [&](int t) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (32 * t + l31) * RS + ks * 16 + hh * 8;
+                ak[ks] = as_v8<T>(ld16(Ks + off));
+                av[ks] = as_v8<T>(ld16(Vs + off));
+            }
+        };
+        read_rows(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            v8 tk[DT][2];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) tk[dt][s2] = tr_afrag<T>(Kt + (32 * dt + l31) * TS, t, s2, hh);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int off = (32 * t + l31) * RS + ks * 16 + hh * 8;
-                s = MT<T>::mfma32(as_v8<T>(ld16(Ks + off)), qf[ks], s);
-                dp = MT<T>::mfma32(as_v8<T>(ld16(Vs + off)), dof[ks], dp);
+                s = MT<T>::mfma32(ak[ks], qf[ks], s);
+                dp = MT<T>::mfma32(av[ks], dof[ks], dp);
             }
             if (kv0 + KV_TILE > a.Nkv) {  // ragged last tile only (wave-uniform): keys past Nkv get probability 0
 #pragma unroll
@@ -592,15 +682,15 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(Att
             v8 dsf[2];
             dsf[0] = acc_to_bfrag<T>(s, 0);
             dsf[1] = acc_to_bfrag<T>(s, 1);
+            if (t == 0) read_rows(1);
+            if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const T* krow = Kt + (32 * dt + l31) * TS;
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) dq[dt] = MT<T>::mfma32(tr_afrag<T>(krow, t, s2, hh), dsf[s2], dq[dt]);
-            }
+                for (int s2 = 0; s2 < 2; ++s2) dq[dt] = MT<T>::mfma32(tk[dt][s2], dsf[s2], dq[dt]);
         }
         if (more) {
-            kst.store(Ks_ + (cur ^ 1) * RT, tid);
+            ktst.store_rows(Ks_ + (cur ^ 1) * RT, tid);
             vst.store(Vs_ + (cur ^ 1) * RT, tid);
             ktst.store(Kt_ + (cur ^ 1) * TT, tid);
         }
@@ -612,8 +702,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void attn_bwd_dq_kernel(Att
 
 // ---- backward dK/dV: one wave = 32 keys, loop over query tiles of this split ------------------------
 //   S = Q K^T ; P = exp(scale*S - lse) ; dV^T += dO^T P ; dP = dO V^T ; dS = P o (dP - D) ; dK^T += Q^T dS
-template <typename T, int D, bool PCOLS>
-__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
+template <typename T, int D, bool PCOLS, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 : 1))) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
+    constexpr int NT = 64 * NW;
+    desync_wave_slots();
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -630,16 +722,16 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     const int rest = blockIdx.x / a.H;
     const int kb = rest % a.nkb, b = rest / a.nkb;
     const int split = blockIdx.y;
-    const int kvi = kb * 128 + wave * 32 + l31;
+    const int kvi = kb * (32 * NW) + wave * 32 + l31;
     const bool kvalid = kvi < a.Nkv;
     const int kc = min(kvi, a.Nkv - 1);
 
 #pragma unroll
     for (int bf = 0; bf < NB; ++bf) {
-        zero_row_pads<T, D>(Qs_ + bf * RT, tid);
-        zero_row_pads<T, D>(dOs_ + bf * RT, tid);
-        zero_tr_pads<T, D>(Qt_ + bf * TT, tid);
-        zero_tr_pads<T, D>(dOt_ + bf * TT, tid);
+        zero_row_pads<T, D, NT>(Qs_ + bf * RT, tid);
+        zero_row_pads<T, D, NT>(dOs_ + bf * RT, tid);
+        zero_tr_pads<T, D, NT>(Qt_ + bf * TT, tid);
+        zero_tr_pads<T, D, NT>(dOt_ + bf * TT, tid);
     }
 
     v8 kf[KS], vf[KS];
@@ -664,16 +756,19 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
     const int qbeg = split * a.q_per_split;
     const int qend = min(qbeg + a.q_per_split, a.Nq);
 
-    RowStage<T, D> qst, dost;
-    TrStage<T, D> qtst, dotst;
+    TrStage<T, D, NT> qtst, dotst;   // one fetch per tensor, both LDS images
+    qtst.init(a.q_rs, tid);
+    dotst.init(a.do_rs, tid);
     float st_lse = 0.f, st_D = 0.f, st_dpc[MOS_MAX_PCOLS] = {0.f, 0.f, 0.f, 0.f};
     int st_nv = 0;
+    // rows in [qend, tile end) are always >= Nq (splits are whole tiles), i.e. outside the descriptors: zeros
+    const rsrc_t qsrc = make_rsrc(qp, slice_bytes<T, D>(a.Nq, a.q_rs));
+    const rsrc_t dosrc = make_rsrc(dop, slice_bytes<T, D>(a.Nq, a.do_rs));
+    const int q_row_bytes = (int)a.q_rs * (int)sizeof(T), do_row_bytes = (int)a.do_rs * (int)sizeof(T);
     auto load_tile = [&](int q0) {
         const int nv = qend - q0;
-        qst.load(qp + (int64_t)q0 * a.q_rs, a.q_rs, nv, tid);
-        dost.load(dop + (int64_t)q0 * a.do_rs, a.do_rs, nv, tid);
-        qtst.load(qp + (int64_t)q0 * a.q_rs, a.q_rs, nv, tid);
-        dotst.load(dop + (int64_t)q0 * a.do_rs, a.do_rs, nv, tid);
+        qtst.load(qsrc, q0 * q_row_bytes);
+        dotst.load(dosrc, q0 * do_row_bytes);
         st_nv = nv;
         const int64_t rr = rowbase + q0 + min(tid & (KV_TILE - 1), nv - 1);   // unconditional, clamped
         st_lse = a.lse[rr];
@@ -685,8 +780,8 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
         }
     };
     auto store_tile = [&](int bf) {
-        qst.store(Qs_ + bf * RT, tid);
-        dost.store(dOs_ + bf * RT, tid);
+        qtst.store_rows(Qs_ + bf * RT, tid);
+        dotst.store_rows(dOs_ + bf * RT, tid);
         qtst.store(Qt_ + bf * TT, tid);
         dotst.store(dOt_ + bf * TT, tid);
         if (tid < KV_TILE) {
@@ -707,6 +802,11 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
         store_tile(0);
     }
     __syncthreads();
+    // nothing may be pending on the vector-memory counter when the loop is entered: with the K/V (Q/dO) fragment
+    // loads of the prologue still "in flight" on some path, hipcc's waitcnt pass guards their first use INSIDE the loop
+    // with vmcnt(N), and because that counter retires in order, the wait also covers the tile prefetch issued just
+    // before it -- a full memory round trip in front of the first MFMAs of every tile
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (expcnt / lgkmcnt untouched)
     int cur = 0;
     for (int q0 = qbeg; q0 < qend; q0 += KV_TILE) {
         const T* Qs = Qs_ + cur * RT;
@@ -718,48 +818,75 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void attn_bwd_dkdv_kernel(A
         const float* dpc_s = D_s + KV_TILE;
         const bool more = q0 + KV_TILE < qend;
         if (more) load_tile(q0 + KV_TILE);
+        // Fragment reads are issued one stage ahead of their MFMAs and pinned there with scheduling fences: left
+        // alone, hipcc sinks each ds_read next to its consumer (`ds_read; s_waitcnt lgkmcnt(0); v_mfma`), which puts
+        // one LDS round trip in front of nearly every MFMA.
+        v8 aq[KS], ado[KS];
+        f32x4 l4[4], d4[4];
+        auto read_rows = [&](int t) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (32 * t + l31) * RS + ks * 16 + hh * 8;
+                aq[ks] = as_v8<T>(ld16(Qs + off));
+                ado[ks] = as_v8<T>(ld16(dOs + off));
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int ql = 32 * t + 8 * r4 + 4 * hh;
+                l4[r4] = *reinterpret_cast<const f32x4*>(lse_s + ql);
+                d4[r4] = *reinterpret_cast<const f32x4*>(D_s + ql);
+            }
+        };
+        read_rows(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            // transposed fragments of this half: consumed after the softmax, in flight during S / dP / exp
+            v8 tdo[DT][2], tq[DT][2];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    tdo[dt][s2] = tr_afrag<T>(dOt + (32 * dt + l31) * TS, t, s2, hh);
+                    tq[dt][s2] = tr_afrag<T>(Qt + (32 * dt + l31) * TS, t, s2, hh);
+                }
+            if constexpr (D <= 80) __builtin_amdgcn_sched_barrier(0);   // d = 160: the fragments would spill
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const int off = (32 * t + l31) * RS + ks * 16 + hh * 8;
-                s = MT<T>::mfma32(as_v8<T>(ld16(Qs + off)), kf[ks], s);
-                dp = MT<T>::mfma32(as_v8<T>(ld16(dOs + off)), vf[ks], dp);
+                s = MT<T>::mfma32(aq[ks], kf[ks], s);
+                dp = MT<T>::mfma32(ado[ks], vf[ks], dp);
             }
             // accumulator rows are query-local indices 32t + acc_row(r, hh); column = this lane's key
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
-                const int ql = 32 * t + 8 * r4 + 4 * hh;
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + ql);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(D_s + ql);
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
                     const int r = 4 * r4 + rr;
-                    const float p = kvalid ? __builtin_amdgcn_exp2f(s[r] * c - l4[rr]) : 0.f;
+                    // keys past Nkv (lanes of the last key block) need no masking: each lane's key is one column of
+                    // dK^T / dV^T, columns never mix, and the store skips invalid keys
+                    const float p = __builtin_amdgcn_exp2f(s[r] * c - l4[r4][rr]);
                     float g = dp[r];
                     if constexpr (PCOLS) {
-                        if (mytok >= 0) g += dpc_s[(ql + rr) * MOS_MAX_PCOLS + mytok];
+                        if (mytok >= 0) g += dpc_s[(32 * t + 8 * r4 + 4 * hh + rr) * MOS_MAX_PCOLS + mytok];
                     }
                     s[r] = p;
-                    dp[r] = p * (g - d4[rr]);
+                    dp[r] = p * (g - d4[r4][rr]);
                 }
             }
             v8 pf[2], dsf[2];
             pf[0] = acc_to_bfrag<T>(s, 0); pf[1] = acc_to_bfrag<T>(s, 1);
             dsf[0] = acc_to_bfrag<T>(dp, 0); dsf[1] = acc_to_bfrag<T>(dp, 1);
+            if (t == 0) read_rows(1);   // next half's row fragments fly under the 8 MFMAs below
+            if constexpr (D <= 80) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const T* dorow = dOt + (32 * dt + l31) * TS;
-                const T* qrow = Qt + (32 * dt + l31) * TS;
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    dvT[dt] = MT<T>::mfma32(tr_afrag<T>(dorow, t, s2, hh), pf[s2], dvT[dt]);
-                    dkT[dt] = MT<T>::mfma32(tr_afrag<T>(qrow, t, s2, hh), dsf[s2], dkT[dt]);
+                    dvT[dt] = MT<T>::mfma32(tdo[dt][s2], pf[s2], dvT[dt]);
+                    dkT[dt] = MT<T>::mfma32(tq[dt][s2], dsf[s2], dkT[dt]);
                 }
-            }
         }
         if constexpr (NB == 1) __syncthreads();   // single buffer: every wave is done reading before the overwrite
         if (more) store_tile(NB == 2 ? (cur ^ 1) : 0);
@@ -922,10 +1049,17 @@ int launch_region(const void* q, const void* k, const void* v, void* o, const mo
     return mos_check_launch("region_attn");
 }
 
-struct BwdPlan { int nkb, nsplit, q_per_split; };
+constexpr int DQ_NW = MOS_DQ_NW, DKDV_NW = MOS_DKDV_NW;   // waves per block of the wide d = 40 variants
+struct BwdPlan { int nw_q, nw_k, nqb, nkb, nsplit, q_per_split; };
+// waves per block of the backward kernels: 8 where the register budget allows four waves per SIMD (d = 40) and the
+// grid still holds >= 512 blocks of 256 rows; 4 otherwise
 BwdPlan plan_bwd(const mos_attn_shape* s) {
     BwdPlan p;
-    p.nkb = (s->Nkv + 127) / 128;
+    const int64_t bh = (int64_t)s->B * s->H;
+    p.nw_q = (s->d == 40 && bh * ((s->Nq + 32 * DQ_NW - 1) / (32 * DQ_NW)) >= 512) ? DQ_NW : 4;
+    p.nw_k = (s->d == 40 && bh * ((s->Nkv + 32 * DKDV_NW - 1) / (32 * DKDV_NW)) >= 512) ? DKDV_NW : 4;
+    p.nqb = (s->Nq + 32 * p.nw_q - 1) / (32 * p.nw_q);
+    p.nkb = (s->Nkv + 32 * p.nw_k - 1) / (32 * p.nw_k);
     const int64_t base = (int64_t)p.nkb * s->B * s->H;
     const int qtiles = (s->Nq + KV_TILE - 1) / KV_TILE;
     int ns = (int)((512 + base - 1) / base);
@@ -960,7 +1094,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     a.q = q; a.k = k; a.v = v; a.dO = dO; a.lse = lse; a.Dvec = Dvec; a.tok_idx = tok; a.dpcols = dpcols;
     a.n_pcols = (dpcols != nullptr) ? np : 0;
     a.dq = dq; a.dk = dk; a.dv = dv; a.part = part;
-    a.B = s->B; a.H = s->H; a.Nq = s->Nq; a.Nkv = s->Nkv; a.nqb = (s->Nq + 127) / 128; a.nkb = p.nkb;
+    a.B = s->B; a.H = s->H; a.Nq = s->Nq; a.Nkv = s->Nkv; a.nqb = p.nqb; a.nkb = p.nkb;
     a.nsplit = p.nsplit; a.q_per_split = p.q_per_split;
     a.q_bs = s->q_bs; a.q_rs = s->q_rs; a.k_bs = s->k_bs; a.k_rs = s->k_rs; a.v_bs = s->v_bs; a.v_rs = s->v_rs;
     a.do_bs = g->do_bs; a.do_rs = g->do_rs; a.dq_bs = g->dq_bs; a.dq_rs = g->dq_rs;
@@ -971,27 +1105,45 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         const size_t lds = dq_lds<D>(sizeof(T));
         AttnKey key(tname<T>(), s, 3.0);
         MosProfScope prof(st, "attn_bwd_dq", key.s, key.flops, key.bytes * 1.5);
-        if (pc) {
-            set_lds(&attn_bwd_dq_kernel<T, D, true>, lds);
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true>), grid, dim3(256), lds, st, a);
+        constexpr int NWMAX = (D == 40) ? DQ_NW : 4;
+        if (p.nw_q > 4 && NWMAX > 4) {
+            if (pc) {
+                set_lds(&attn_bwd_dq_kernel<T, D, true, NWMAX>, lds);
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true, NWMAX>), grid, dim3(64 * NWMAX), lds, st, a);
+            } else {
+                set_lds(&attn_bwd_dq_kernel<T, D, false, NWMAX>, lds);
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false, NWMAX>), grid, dim3(64 * NWMAX), lds, st, a);
+            }
+        } else if (pc) {
+            set_lds(&attn_bwd_dq_kernel<T, D, true, 4>, lds);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true, 4>), grid, dim3(256), lds, st, a);
         } else {
-            set_lds(&attn_bwd_dq_kernel<T, D, false>, lds);
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false>), grid, dim3(256), lds, st, a);
+            set_lds(&attn_bwd_dq_kernel<T, D, false, 4>, lds);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false, 4>), grid, dim3(256), lds, st, a);
         }
         int rc = mos_check_launch("attn_bwd_dq");
         if (rc) return rc;
     }
     {
         const dim3 grid((unsigned)(a.H * a.nkb * a.B), (unsigned)a.nsplit);
-        const size_t lds = dkdv_lds<D>(sizeof(T));
+        const size_t lds = dkdv_lds<D>(sizeof(T)) + MOS_DKDV_LDS_PAD;
         AttnKey key(tname<T>(), s, 4.0);
         MosProfScope prof(st, "attn_bwd_dkdv", key.s, key.flops, key.bytes * 1.5);
-        if (pc) {
-            set_lds(&attn_bwd_dkdv_kernel<T, D, true>, lds);
-            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true>), grid, dim3(256), lds, st, a);
+        constexpr int NWMAX = (D == 40) ? DKDV_NW : 4;
+        if (p.nw_k > 4 && NWMAX > 4) {
+            if (pc) {
+                set_lds(&attn_bwd_dkdv_kernel<T, D, true, NWMAX>, lds);
+                hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true, NWMAX>), grid, dim3(64 * NWMAX), lds, st, a);
+            } else {
+                set_lds(&attn_bwd_dkdv_kernel<T, D, false, NWMAX>, lds);
+                hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, false, NWMAX>), grid, dim3(64 * NWMAX), lds, st, a);
+            }
+        } else if (pc) {
+            set_lds(&attn_bwd_dkdv_kernel<T, D, true, 4>, lds);
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true, 4>), grid, dim3(256), lds, st, a);
         } else {
-            set_lds(&attn_bwd_dkdv_kernel<T, D, false>, lds);
-            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, false>), grid, dim3(256), lds, st, a);
+            set_lds(&attn_bwd_dkdv_kernel<T, D, false, 4>, lds);
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, false, 4>), grid, dim3(256), lds, st, a);
         }
         int rc = mos_check_launch("attn_bwd_dkdv");
         if (rc) return rc;

@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'libmos_hip.so'))
+# MOS_HIP_LIB: alternative build of the same C-ABI (kernel tuning experiments); default = the in-tree library
+LIB_PATH = os.environ.get('MOS_HIP_LIB') or os.path.normpath(os.path.join(_HERE, '..', '..', 'libmos_hip.so'))
 
 MOS_F16 = 0
 MOS_BF16 = 1

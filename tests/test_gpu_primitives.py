@@ -123,6 +123,10 @@ ATTN_CASES = [
     (2, 8, 1024, 77, 80),
     (2, 8, 256, 77, 160),
     (1, 8, 70, 77, 40),       # ragged queries
+    (4, 8, 4096, 4096, 40),   # the bench shape (level-0 self attention, batch 4)
+    (8, 8, 2000, 777, 40),    # large grid, ragged query and key tails, several key blocks
+    (8, 8, 2048, 77, 40),     # batch 8 with exported probability columns
+    (2, 8, 512, 600, 40),     # exported probability columns spread over several key blocks (keys 5, 70 / 599, 0)
 ]
 
 
@@ -132,10 +136,11 @@ def test_attention_fwd_bwd(ops, emu, dtype, B, H, Nq, Nkv, d):
     C = H * d
     q, k, v = _qkv(B, Nq, Nkv, C, dtype, 3, fused=True)
     scale = d**-0.5
-    cross = Nkv == 77
+    cross = Nkv in (77, 600)
     tok = None
     if cross:
-        tok = torch.tensor([[5, 70], [76, 0]][:B], dtype=torch.int32, device='cuda').contiguous()
+        rows = [[5, 70], [Nkv - 1, 0]] * ((B + 1) // 2)
+        tok = torch.tensor(rows[:B], dtype=torch.int32, device='cuda').contiguous()
     o, lse, pcols = ops.attn_fwd(q, k, v, H, scale, tok_idx=tok)
     o_r, lse_r, pcols_r = emu.attn_fwd(q, k, v, H, scale, tok_idx=tok)
     _check(f'attn_fwd.o[{Nq}x{Nkv}x{d}]', o, o_r, dtype)

@@ -12,7 +12,7 @@ timeout 420 python bench.py > "${OUT}/${TAG}_bench_train_n1.json" 2> "${OUT}/${T
 timeout 300 python bench.py --mode regional > "${OUT}/${TAG}_bench_regional_n1.json" 2> "${OUT}/${TAG}_bench_regional_n1.err"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof
-timeout 420 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python "${ROOT}/bench.py" --steps 3 --warmup 2 --no-cpu-baseline \
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o b -- python "${ROOT}/bench.py" --steps 3 --warmup 2 --no-cpu-baseline \
     > "${OUT}/${TAG}_bench_train_under_rocprof.json" 2> "${OUT}/${TAG}_rocprof.err"
 f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -60 "$f" > "${OUT}/${TAG}_rocprofv3_kernel_stats_bench_train.csv"
