@@ -77,6 +77,18 @@ def synthetic_batch(B, size, device, seed):
                 prompts=['a <potter1> <potter2> in the park, 4K, high quality'] * B)
 
 
+def _pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs, gfx950-corrected), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    try:
+        with open(path) as f:
+            ent = json.load(f).get(kernel_name)
+        return float(ent['total']) if ent else None
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
 def roofline_from_profile(records):
     lib_ms = sum(r['total_ms'] for r in records)
     top = records[0]
@@ -88,7 +100,8 @@ def roofline_from_profile(records):
     else:
         achieved, peak, unit = top['bytes'] / sec / 1e9, PEAK_HBM_GBPS, 'GB/s'
     return dict(kernel=top['name'], bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit,
-                frac=round(achieved / peak, 5), traffic=None, avg_us=round(top['avg_us'], 2), launches=top['calls'],
+                frac=round(achieved / peak, 5), traffic=_pmc_traffic(top['name']), avg_us=round(top['avg_us'], 2),
+                launches=top['calls'],
                 share_of_library_gpu_time=round(top['total_ms'] / max(1e-9, lib_ms), 4),
                 algorithmic_flops_per_launch=top['flops'], algorithmic_bytes_per_launch=top['bytes'])
 

