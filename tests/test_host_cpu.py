@@ -293,3 +293,76 @@ def test_groupnorm_closed_form_backward_matches_autograd(silu):
     (ref, ) = torch.autograd.grad(out, xr, dy)
     got = emu_ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats.double(), 4, silu)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-6)
+
+
+# ---- gradient fusion host logic (mixofshow.utils.lsq) ------------------------------------------------------------
+def test_update_quasi_newton_host_logic_vs_reference_golden(emulated_hip, golden):
+    """The product's Gram-form L-BFGS (chunked accumulation, hi+lo split of fp32 features, conv weights, best-iterate
+    rule) with the two kernels emulated in fp64, against the iterates the REAL reference produced (golden fixture)."""
+    from mixofshow.utils import lsq
+    from oracle import fusion_ref
+    for name, c in golden['lbfgs'].items():
+        W = lsq.update_quasi_newton(c['X'], c['Y'], c['W0'].clone(), c['iters'], torch.device('cpu'))
+        assert W.shape == c['W0'].shape and W.dtype == torch.float32 and W.device.type == 'cpu'
+        l_ref = fusion_ref.lsq_loss_ref(c['X'], c['Y'], c['W']).item()
+        l_got = fusion_ref.lsq_loss_ref(c['X'], c['Y'], W).item()
+        l0 = fusion_ref.lsq_loss_ref(c['X'], c['Y'], c['W0']).item()
+        # same minimiser: never worse than the reference's iterate beyond fp32 rounding of W, far below the start
+        assert l_got <= l_ref * (1 + 1e-4) + 1e-12 * max(1.0, l0), f'{name}: {l_got} vs reference {l_ref}'
+        assert l_got < 1e-2 * l0 or l_got <= l_ref * (1 + 1e-4)
+        if name in ('over', 'spatial'):     # strictly convex cases: the minimiser itself is pinned
+            rel = (W - c['W']).norm() / c['W'].norm()
+            assert rel < 1e-3, f'{name}: rel dW {rel:.2e}'
+
+
+def test_gram_accumulator_chunks_and_split(emulated_hip):
+    """G, P, c are independent of chunking and of the representation of the features (half, fp32-on-a-half-grid,
+    general fp32 through the hi+lo split)."""
+    from mixofshow.utils.lsq import GramAccumulator
+    torch.manual_seed(3)
+    X, Y = torch.randn(300, 24), torch.randn(300, 8)
+    full = GramAccumulator(24, 8, 'cpu')
+    full.add(X, Y, exact_fp32=True)
+    parts = GramAccumulator(24, 8, 'cpu')
+    for s in range(0, 300, 77):                       # ragged last chunk
+        parts.add(X[s:s + 77], Y[s:s + 77], exact_fp32=True)
+    assert parts.n == full.n == 300
+    for a, b in ((full.G, parts.G), (full.P, parts.P), (full.c, parts.c)):
+        torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+    # hi+lo split reproduces the fp32 Gram to ~2^-22
+    torch.testing.assert_close(full.G, X.double().t() @ X.double(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(full.P, Y.double().t() @ X.double(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(full.c.reshape(()), (Y.double()**2).sum(), rtol=1e-12, atol=0)
+    # conv features (b, C, h, w) are flattened to (b*h*w, C)
+    conv = GramAccumulator(4, 2, 'cpu')
+    Xc, Yc = torch.randn(2, 4, 3, 3).half(), torch.randn(2, 2, 3, 3).half()
+    conv.add(Xc, Yc)
+    Xr = Xc.permute(0, 2, 3, 1).reshape(-1, 4).double()
+    torch.testing.assert_close(conv.G, Xr.t() @ Xr)
+    assert conv.n == 18
+
+
+# ---- TrainEngine: embedding-norm freeze rule (reference train_edlora.py:123-143) ----------------------------------
+def test_engine_embedding_norm_freeze_rule(emulated_hip):
+    """Once the mean norm of the concept rows reaches the threshold the rows stop moving (the reference restores them
+    from a snapshot after every step); LoRA factors keep training."""
+    from mixofshow.pipelines.train_loop import TrainEngine
+    tr = _trainer(attn_reg_weight=None)
+    opt = dict(optim_g=dict(type='AdamW', lr=0.0, weight_decay=0.01, betas=[0.9, 0.999]), emb_norm_threshold=1e9)
+    eng = TrainEngine(tr, opt, total_iter=100, mixed_precision='no')
+    b = _batch()
+    eng.step(b)
+    assert not bool(eng.stop_flag)
+    rows1 = tr.concept_embedding.detach().clone()
+    eng.threshold = 0.0                                  # next step crosses the threshold: flag set AFTER that update
+    out = eng.step(b)
+    assert bool(eng.stop_flag) and torch.isfinite(out['Norm_mean'])
+    rows2 = tr.concept_embedding.detach().clone()
+    assert not torch.equal(rows1, rows2)                 # the crossing step itself still updates (reference order)
+    lora_before = [p.detach().clone() for l in tr.unet_lora for p in (l.lora_down.weight, l.lora_up.weight)]
+    for _ in range(2):
+        eng.step(b)
+    torch.testing.assert_close(tr.concept_embedding.detach(), rows2, rtol=0, atol=0)   # frozen bit-exactly
+    lora_after = [p.detach() for l in tr.unet_lora for p in (l.lora_down.weight, l.lora_up.weight)]
+    assert any(not torch.equal(a, b_) for a, b_ in zip(lora_before, lora_after))
+    assert eng.global_step == 4
