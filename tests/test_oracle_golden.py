@@ -126,3 +126,25 @@ def test_bind_and_merge(golden):
     assert n == 1
     for k, v in m['merged_te'].items():
         torch.testing.assert_close(merged_te[k], v, rtol=1e-6, atol=1e-6)
+
+
+def test_lsq_analytic_known_answers(emulated_hip):
+    """SURVEY 8(c) known answers for the fusion solver, for the oracle restatement AND the product's Gram-form solver
+    (kernels emulated): (1) n >= Cin, full rank => the normal-equation solution; (2) orthogonal sample rows, n < Cin =>
+    W0 + sum_i (y_i - W0 x_i) x_i^T / |x_i|^2 (L-BFGS never leaves W0 + span of the samples)."""
+    from mixofshow.utils import lsq
+    torch.manual_seed(0)
+    X, Y, W0 = torch.randn(200, 12), torch.randn(200, 6), torch.randn(6, 12) * 0.1
+    W_ne = torch.linalg.solve(X.double().t() @ X.double(), X.double().t() @ Y.double()).t().float()
+    for solver in (lambda: fusion_ref.update_quasi_newton_ref(X, Y, W0.clone(), 200),
+                   lambda: lsq.update_quasi_newton(X, Y, W0.clone(), 200, torch.device('cpu'))):
+        torch.testing.assert_close(solver(), W_ne, rtol=2e-3, atol=2e-4)
+    Q, _ = torch.linalg.qr(torch.randn(16, 5))             # 5 orthonormal directions in R^16
+    Xo = (Q.t() * torch.tensor([1.0, 2.0, 0.5, 3.0, 1.5])[:, None]).contiguous()     # rows x_i, mutually orthogonal
+    Yo, W1 = torch.randn(5, 4), torch.randn(4, 16) * 0.1
+    W_exp = W1 + sum(torch.outer(Yo[i] - W1 @ Xo[i], Xo[i]) / Xo[i].dot(Xo[i]) for i in range(5))
+    for solver in (lambda: fusion_ref.update_quasi_newton_ref(Xo, Yo, W1.clone(), 200),
+                   lambda: lsq.update_quasi_newton(Xo, Yo, W1.clone(), 200, torch.device('cpu'))):
+        W = solver()
+        torch.testing.assert_close(W, W_exp, rtol=2e-3, atol=2e-4)
+        assert fusion_ref.lsq_loss_ref(Xo, Yo, W).item() < 1e-8
