@@ -366,3 +366,21 @@ def test_engine_embedding_norm_freeze_rule(emulated_hip):
     lora_after = [p.detach() for l in tr.unet_lora for p in (l.lora_down.weight, l.lora_up.weight)]
     assert any(not torch.equal(a, b_) for a, b_ in zip(lora_before, lora_after))
     assert eng.global_step == 4
+
+
+def test_regional_cli_grammar_vs_reference_golden(golden):
+    """The product CLI's region grammar against what the REAL reference's prepare_text returned (golden fixture), plus
+    the edge cases of the grammar: trailing separator, empty box = whole image, no regions."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'regionally_controlable_sampling.py')
+    spec = importlib.util.spec_from_file_location('mos_regional_cli', path)
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    g = golden['prepare_text']
+    assert cli.prepare_text('three people', g['arg'], g['height'], g['width']) == g['result']
+    p, regs = cli.prepare_text('ctx', '[a cat]-*-[blurry]-*-[]|[a dog]-*-[]-*-[0, 0, 256, 512]|', 512, 1024)
+    assert p == 'ctx' and regs == [('a cat', 'blurry', [0, 0, 1, 1]), ('a dog', '', [0.0, 0.0, 0.5, 0.5])]
+    assert cli.prepare_text('ctx', '', 512, 512) == ('ctx', [])
+    a = cli.parse_args(['--pretrained_model', 'm', '--keypose_adaptor_weight', '0.5', '--prompt_rewrite', 'x'])
+    assert (a.seed, a.keypose_adaptor_weight, a.region_sketch_adaptor_weight, a.height) == (16141, 0.5, '', 512)
