@@ -944,6 +944,16 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part, int nspli
 // ---- host dispatch -----------------------------------------------------------------------------
 template <int D> constexpr int fwd_qw() { return D <= 80 ? 64 : 32; }
 
+#ifndef MOS_DKDV_V2
+#define MOS_DKDV_V2 0   // 1: dispatch the experimental software-pipelined dK/dV kernel at d = 40 (mos_attn_dkdv_v2.inc)
+#endif
+#ifndef MOS_DKDV_V2_NK
+#define MOS_DKDV_V2_NK 1
+#endif
+#if MOS_DKDV_V2
+#include "mos_attn_dkdv_v2.inc"
+#endif
+
 template <int D> constexpr size_t fwd_lds(size_t es) { return 2 * (HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
 template <int D> constexpr size_t dq_lds(size_t es) { return 2 * (2 * HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
 template <int D> constexpr size_t dkdv_lds(size_t es) {
@@ -1050,7 +1060,7 @@ int launch_region(const void* q, const void* k, const void* v, void* o, const mo
 }
 
 constexpr int DQ_NW = MOS_DQ_NW, DKDV_NW = MOS_DKDV_NW;   // waves per block of the wide d = 40 variants
-struct BwdPlan { int nw_q, nw_k, nqb, nkb, nsplit, q_per_split; };
+struct BwdPlan { int nw_q, nw_k, nqb, nkb, nsplit, q_per_split; bool v2; };
 // waves per block of the backward kernels: 8 where the register budget allows four waves per SIMD (d = 40) and the
 // grid still holds >= 512 blocks of 256 rows; 4 otherwise
 BwdPlan plan_bwd(const mos_attn_shape* s) {
@@ -1060,6 +1070,15 @@ BwdPlan plan_bwd(const mos_attn_shape* s) {
     p.nw_k = (s->d == 40 && bh * ((s->Nkv + 32 * DKDV_NW - 1) / (32 * DKDV_NW)) >= 512) ? DKDV_NW : 4;
     p.nqb = (s->Nq + 32 * p.nw_q - 1) / (32 * p.nw_q);
     p.nkb = (s->Nkv + 32 * p.nw_k - 1) / (32 * p.nw_k);
+    p.v2 = false;
+#if MOS_DKDV_V2
+    constexpr int V2_KEYS = 128 * MOS_DKDV_V2_NK;           // keys per 4-wave block
+    if (s->d == 40 && bh * ((s->Nkv + V2_KEYS - 1) / V2_KEYS) >= 256) {
+        p.v2 = true;
+        p.nw_k = 4;
+        p.nkb = (s->Nkv + V2_KEYS - 1) / V2_KEYS;
+    }
+#endif
     const int64_t base = (int64_t)p.nkb * s->B * s->H;
     const int qtiles = (s->Nq + KV_TILE - 1) / KV_TILE;
     int ns = (int)((512 + base - 1) / base);
@@ -1130,6 +1149,17 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         AttnKey key(tname<T>(), s, 4.0);
         MosProfScope prof(st, "attn_bwd_dkdv", key.s, key.flops, key.bytes * 1.5);
         constexpr int NWMAX = (D == 40) ? DKDV_NW : 4;
+#if MOS_DKDV_V2
+        if (p.v2 && D == 40) {
+            if (pc) {
+                set_lds(&attn_bwd_dkdv_v2_kernel<T, true, DKDV_V2_NK>, lds);
+                hipLaunchKernelGGL((attn_bwd_dkdv_v2_kernel<T, true, DKDV_V2_NK>), grid, dim3(256), lds, st, a);
+            } else {
+                set_lds(&attn_bwd_dkdv_v2_kernel<T, false, DKDV_V2_NK>, lds);
+                hipLaunchKernelGGL((attn_bwd_dkdv_v2_kernel<T, false, DKDV_V2_NK>), grid, dim3(256), lds, st, a);
+            }
+        } else
+#endif
         if (p.nw_k > 4 && NWMAX > 4) {
             if (pc) {
                 set_lds(&attn_bwd_dkdv_kernel<T, D, true, NWMAX>, lds);
