@@ -162,7 +162,6 @@ template <typename T>
 __global__ __launch_bounds__(256) void skinny_nt_kernel(const T* __restrict__ X, int64_t ldx,
                                                         const T* __restrict__ S, T* __restrict__ Tout,
                                                         int M, int K) {
-    typedef typename MT<T>::v8 v8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lg = lane >> 4;
     const int mbase = (blockIdx.x * 4 + wave) * 16;
