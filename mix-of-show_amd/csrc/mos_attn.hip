@@ -1071,7 +1071,7 @@ BwdPlan plan_bwd(const mos_attn_shape* s) {
     p.nqb = (s->Nq + 32 * p.nw_q - 1) / (32 * p.nw_q);
     p.nkb = (s->Nkv + 32 * p.nw_k - 1) / (32 * p.nw_k);
     p.v2 = false;
-#if MOS_DKDV_V2
+#if MOS_DKDV_V2 == 1 || MOS_DKDV_V2 == 2
     constexpr int V2_KEYS = 128 * MOS_DKDV_V2_NK;           // keys per 4-wave block
     if (s->d == 40 && bh * ((s->Nkv + V2_KEYS - 1) / V2_KEYS) >= 256) {
         p.v2 = true;
@@ -1149,7 +1149,19 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         AttnKey key(tname<T>(), s, 4.0);
         MosProfScope prof(st, "attn_bwd_dkdv", key.s, key.flops, key.bytes * 1.5);
         constexpr int NWMAX = (D == 40) ? DKDV_NW : 4;
-#if MOS_DKDV_V2
+#if MOS_DKDV_V2 == 3
+        if (D == 40 && (int64_t)a.H * a.nkb * a.B >= 256 && p.nw_k == 4) {      // one block per CU, 128 keys per block
+            const size_t lds3 = 3 * ((2 * HD<D>::ROW_TILE_ELEMS + 2 * HD<D>::TR_TILE_ELEMS) * sizeof(T) +
+                                     KV_TILE * (2 + MOS_MAX_PCOLS) * sizeof(float));
+            if (pc) {
+                set_lds(&attn_bwd_dkdv_v3_kernel<T, true>, lds3);
+                hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<T, true>), grid, dim3(256), lds3, st, a);
+            } else {
+                set_lds(&attn_bwd_dkdv_v3_kernel<T, false>, lds3);
+                hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<T, false>), grid, dim3(256), lds3, st, a);
+            }
+        } else
+#elif MOS_DKDV_V2
         if (p.v2 && D == 40) {
             if (pc) {
                 set_lds(&attn_bwd_dkdv_v2_kernel<T, true, DKDV_V2_NK>, lds);

@@ -40,11 +40,12 @@ for l in body[a:b]:
         out.append(l.strip().replace('s_waitcnt ', 'W:'))
     elif t in ('s_barrier', ) or 'sched_barrier' in l:
         out.append('BARRIER' if t == 's_barrier' else '|')
-    elif t.startswith('v_exp'):
-        if out and out[-1].startswith('exp'):
-            out[-1] = f'expx{int(out[-1][4:]) + 1}'
+    elif t.startswith('v_') :            # other VALU (v_exp counted separately as e<n>): v<n>
+        tag = 'e' if t.startswith('v_exp') else 'v'
+        if out and out[-1][:1] == tag and out[-1][1:].isdigit():
+            out[-1] = f'{tag}{int(out[-1][1:]) + 1}'
         else:
-            out.append('expx1')
+            out.append(f'{tag}1')
 if run:
     out.append(f'MFMAx{run}')
 print(' '.join(out))
