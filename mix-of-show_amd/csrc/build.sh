@@ -8,8 +8,14 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ff
 SRCS="mos_api mos_gemm mos_attn mos_gram mos_norm"
 mkdir -p "${HERE}/_build"
 pids=()
+# mos_attn only: at one wave per SIMD hipcc selects the AccVGPR form of every MFMA and then copies the accumulators the
+# VALU touches (softmax) through v_accvgpr_read/write -- 6..10 copies per MFMA in the d = 80/160 and region kernels.
+# The VGPR form keeps them in arch VGPRs (main-loop VALU count -40 %; region kernels -15..-26 % measured, parity
+# unchanged). Two-wave kernels (d = 40) compile to the same code either way.
+EXTRA_mos_attn="-mllvm -amdgpu-mfma-vgpr-form=1"
 for f in ${SRCS}; do
-  ( ${HIPCC} ${FLAGS} -c "${HERE}/${f}.hip" -o "${HERE}/_build/${f}.o" ) &
+  extra_var="EXTRA_${f}"
+  ( ${HIPCC} ${FLAGS} ${!extra_var:-} -c "${HERE}/${f}.hip" -o "${HERE}/_build/${f}.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
