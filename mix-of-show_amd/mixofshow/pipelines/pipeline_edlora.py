@@ -69,6 +69,7 @@ class StableDiffusionPipeline:
             os.makedirs(os.path.join(path, name), exist_ok=True)
             sd = {k: v.detach().cpu().contiguous() for k, v in getattr(self, name).state_dict().items()}
             save_file(sd, os.path.join(path, name, fname))
+            pretrained.save_model_config(getattr(self, name), os.path.join(path, name))
         os.makedirs(os.path.join(path, 'tokenizer'), exist_ok=True)
         added = getattr(self.tokenizer, 'added', None)
         if added is not None:

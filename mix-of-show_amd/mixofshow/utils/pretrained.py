@@ -53,6 +53,35 @@ def _load_state(folder):
     raise FileNotFoundError(f'no weights found in {folder}')
 
 
+def _model_kwargs(folder, cls):
+    """Constructor arguments from `<folder>/config.json` (the diffusers layout keeps one per sub-model; real
+    checkpoints carry many more keys than the local modules take — only the ones in the constructor are used).
+    Missing file = the SD-1.5 defaults."""
+    import inspect
+    import json
+    cfg_path = os.path.join(folder, 'config.json')
+    if not os.path.isfile(cfg_path):
+        return {}
+    with open(cfg_path) as f:
+        cfg = json.load(f)
+    accepted = set(inspect.signature(cls.__init__).parameters) - {'self'}
+    out = {k: v for k, v in cfg.items() if k in accepted}
+    if isinstance(out.get('attention_head_dim'), (list, tuple)):   # diffusers allows one value per block
+        out['attention_head_dim'] = out['attention_head_dim'][0]
+    for k in ('block_out_channels', ):
+        if k in out:
+            out[k] = tuple(out[k])
+    return out
+
+
+def save_model_config(model, folder):
+    """`config.json` next to the weights (what `_model_kwargs` reads back)."""
+    import json
+    cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(model.config).items()}
+    with open(os.path.join(folder, 'config.json'), 'w') as f:
+        json.dump(cfg, f, indent=1)
+
+
 def remap_text_encoder_keys(sd):
     """Accept both key styles: reference-era `text_model.encoder...` and transformers>=5 `encoder...`."""
     out = {}
@@ -89,8 +118,9 @@ def load_unet(path):
     preset, seed = parse_synthetic(path)
     if preset is not None:
         return _seeded(seed, lambda: UNet2DConditionModel(**PRESETS[preset]['unet']))
-    m = UNet2DConditionModel()
-    m.load_state_dict(_load_state(os.path.join(path, 'unet')))
+    folder = os.path.join(path, 'unet')
+    m = UNet2DConditionModel(**_model_kwargs(folder, UNet2DConditionModel))
+    m.load_state_dict(_load_state(folder))
     return m
 
 
@@ -106,8 +136,13 @@ def load_text_encoder(path):
                 m.text_model.embeddings.position_embedding.weight.mul_(0.014)
             return m
         return _seeded(seed + 1, make)
-    m = CLIPTextModel()
-    m.load_state_dict(remap_text_encoder_keys(_load_state(os.path.join(path, 'text_encoder'))))
+    folder = os.path.join(path, 'text_encoder')
+    sd = remap_text_encoder_keys(_load_state(folder))
+    kw = _model_kwargs(folder, CLIPTextModel)
+    # a fused / tuned checkpoint carries the concept rows: the table size is whatever was saved
+    kw['vocab_size'] = sd['text_model.embeddings.token_embedding.weight'].shape[0]
+    m = CLIPTextModel(**kw)
+    m.load_state_dict(sd)
     return m
 
 
@@ -115,8 +150,9 @@ def load_vae(path):
     preset, seed = parse_synthetic(path)
     if preset is not None:
         return _seeded(seed + 2, lambda: AutoencoderKL(**PRESETS[preset]['vae']))
-    m = AutoencoderKL()
-    m.load_state_dict(remap_vae_keys(_load_state(os.path.join(path, 'vae'))))
+    folder = os.path.join(path, 'vae')
+    m = AutoencoderKL(**_model_kwargs(folder, AutoencoderKL))
+    m.load_state_dict(remap_vae_keys(_load_state(folder)))
     return m
 
 
@@ -125,4 +161,5 @@ def load_scheduler(path, kind='ddpm'):
     return DDPMScheduler() if kind == 'ddpm' else DPMSolverMultistepScheduler()
 
 
-__all__ = ['load_unet', 'load_text_encoder', 'load_vae', 'load_scheduler', 'load_tokenizer', 'parse_synthetic']
+__all__ = ['load_unet', 'load_text_encoder', 'load_vae', 'load_scheduler', 'load_tokenizer', 'parse_synthetic',
+           'save_model_config']

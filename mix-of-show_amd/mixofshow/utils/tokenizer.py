@@ -80,4 +80,10 @@ def load_tokenizer(pretrained_path):
     if os.path.isfile(os.path.join(tok_dir, 'vocab.json')):
         from transformers import CLIPTokenizer
         return CLIPTokenizer.from_pretrained(tok_dir)
-    return SyntheticCLIPTokenizer()
+    tok = SyntheticCLIPTokenizer()
+    added = os.path.join(tok_dir, 'added_tokens.json')      # written by StableDiffusionPipeline.save_pretrained
+    if os.path.isfile(added):
+        import json
+        with open(added) as f:
+            tok.added = {t: int(i) for t, i in sorted(json.load(f).items(), key=lambda kv: kv[1])}
+    return tok
