@@ -92,7 +92,8 @@ def parse_args(argv=None):
 def main(argv=None):
     from PIL import Image
     args = parse_args(argv)
-    pipe = build_model(args.pretrained_model, torch.device('cuda'), args.keypose_adapter_path, args.sketch_adapter_path)
+    device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')     # the kernels themselves need the GPU
+    pipe = build_model(args.pretrained_model, device, args.keypose_adapter_path, args.sketch_adapter_path)
     height, width = args.height, args.width
     conditions = {}
     for kind, (mode, _) in ADAPTER_KINDS.items():

@@ -62,3 +62,12 @@ def test_compose_concepts_end_to_end(emulated_hip, tmp_path):
     assert rp.new_concept_cfg == new_cfg
     assert rp.tokenizer.convert_tokens_to_ids('<new63>') == ids[-1]
     assert rp.scheduler.__class__.__name__ == 'DPMSolverMultistepScheduler'
+    # the whole sampling CLI on the fused directory: two regions, 50 DPM-Solver++ steps at 64x64
+    save_dir = tmp_path / 'samples'
+    cli.main(['--pretrained_model', str(out), '--prompt', 'two people', '--negative_prompt', 'blurry',
+              '--prompt_rewrite', '[a <potter1> <potter2>]-*-[blurry]-*-[0, 0, 64, 30]|[a <thanos1> <thanos2>]-*-[]-*-[0, 28, 64, 64]',
+              '--height', '64', '--width', '64', '--seed', '3', '--suffix', 'cpu', '--save_dir', str(save_dir)])
+    files = sorted(os.listdir(save_dir / 'seed_3'))
+    assert len(files) == 2 and files[0].startswith('two_people---cpu---') and files[0].endswith('.png')
+    with open(save_dir / 'seed_3' / files[1]) as f:
+        assert json.load(f)['prompt_rewrite'].startswith('[a <potter1>')
