@@ -84,3 +84,44 @@ def test_two_rank_allreduce_matches_single_process_average(tmp_path):
         tr(**_rank_batch(rank)).backward()
         grads.append(engine.bucket.flat.clone())
     torch.testing.assert_close(r0['reduced'], (grads[0] + grads[1]) / 2, rtol=1e-5, atol=1e-8)
+
+
+def _cli_worker(rank, world, port, root, recipe):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    _setup_emulation()
+    import argparse
+    import train_edlora
+    from mixofshow.pipelines.train_loop import TrainEngine
+    seen = {}
+    real_step = TrainEngine.step
+
+    def spy(self, batch):                      # remember the last engine to read the final parameters
+        seen['engine'] = self
+        seen.setdefault('prompts', []).append(tuple(batch['prompts']))
+        return real_step(self, batch)
+
+    TrainEngine.step = spy
+    train_edlora.train(root, argparse.Namespace(opt=recipe))
+    eng = seen['engine']
+    params = torch.cat([p.detach().reshape(-1) for p in eng.trainer.trainable_parameters()])
+    torch.save(dict(params=params, steps=eng.global_step, n_batches=len(seen['prompts'])),
+               os.path.join(root, f'cli_rank{rank}.pt'))
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_train_cli(tmp_path):
+    """train_edlora.train under a 2-rank gloo group: DistributedSampler shards the data, every step all-reduces the
+    bucket, both ranks finish with identical parameters, the step count is len(dataset) / (batch * world) and only
+    rank 0 writes the checkpoint."""
+    from tests.test_train_cli_cpu import _recipe
+    recipe = _recipe(tmp_path, total_images=4, val=False)      # 4 images x enlarge 2 = 8 samples
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_cli_worker, args=(world, port, str(tmp_path), recipe), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / 'cli_rank0.pt'), torch.load(tmp_path / 'cli_rank1.pt')
+    assert r0['steps'] == r1['steps'] == 2                     # 8 samples / (batch 2 x world 2)
+    assert r0['n_batches'] == r1['n_batches'] == 2
+    torch.testing.assert_close(r0['params'], r1['params'], rtol=0, atol=0)
+    models = tmp_path / 'experiments' / 'cli_cpu' / 'models'
+    assert sorted(os.listdir(models)) == ['edlora_model-latest.pth']
