@@ -384,3 +384,32 @@ def test_regional_cli_grammar_vs_reference_golden(golden):
     assert cli.prepare_text('ctx', '', 512, 512) == ('ctx', [])
     a = cli.parse_args(['--pretrained_model', 'm', '--keypose_adaptor_weight', '0.5', '--prompt_rewrite', 'x'])
     assert (a.seed, a.keypose_adaptor_weight, a.region_sketch_adaptor_weight, a.height) == (16141, 0.5, '', 512)
+
+
+def test_engine_gradient_accumulation(emulated_hip):
+    """grad_accum = 2: two micro-batches, ONE optimiser step on the mean of their gradients (accelerate's
+    accumulate() semantics, reference train_edlora.py:110-131); the step counter and LR schedule advance once."""
+    from mixofshow.pipelines.train_loop import TrainEngine
+    opt = dict(optim_g=dict(type='AdamW', lr=0.0, weight_decay=0.01, betas=[0.9, 0.999]), emb_norm_threshold=1e9)
+    b1, b2 = _batch(), _batch()
+    g = torch.Generator().manual_seed(9)
+    b2['latents'] = torch.randn(b2['latents'].shape, generator=g)
+    b2['noise'] = torch.randn(b2['noise'].shape, generator=g)
+
+    tr = _trainer(attn_reg_weight=None)
+    eng = TrainEngine(tr, opt, total_iter=10, mixed_precision='no', grad_accum=2)
+    out1 = eng.step(b1)
+    assert eng.global_step == 0 and 'Norm_mean' not in out1          # first micro-batch: no optimiser step yet
+    before = [p.detach().clone() for p in tr.trainable_parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(before, [p.detach() for p in tr.trainable_parameters()]))
+    eng.step(b2)
+    assert eng.global_step == 1
+
+    ref = _trainer(attn_reg_weight=None)
+    ref_eng = TrainEngine(ref, opt, total_iter=10, mixed_precision='no', grad_accum=1)
+    ref_eng.bucket.zero()
+    (ref(**b1) / 2).backward()
+    (ref(**b2) / 2).backward()
+    ref_eng._finish_step(torch.zeros(()))
+    for a, b in zip(tr.trainable_parameters(), ref.trainable_parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-8)
