@@ -413,3 +413,44 @@ def test_engine_gradient_accumulation(emulated_hip):
     ref_eng._finish_step(torch.zeros(()))
     for a, b in zip(tr.trainable_parameters(), ref.trainable_parameters()):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-8)
+
+
+def test_lora_dataset_from_image_folders(tmp_path):
+    """The PIL loader behind `datasets.train` for real concept folders: concept_list json, caption files, mask
+    folder, <TOK> replacement, resize + centre crop to `size`, [-1, 1] normalisation, 1/8-resolution masks."""
+    import json
+    import numpy as np
+    from PIL import Image
+    from mixofshow.data.lora_dataset import LoraDataset, SyntheticLoraDataset, build_train_dataset
+    img_dir, cap_dir, mask_dir = tmp_path / 'image', tmp_path / 'caption', tmp_path / 'mask'
+    for d in (img_dir, cap_dir, mask_dir):
+        d.mkdir()
+    rng = np.random.default_rng(0)
+    for i, (w, h) in enumerate([(96, 64), (64, 128)]):                        # landscape and portrait
+        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8), 'RGB').save(img_dir / f'{i}.png')
+        (cap_dir / f'{i}.txt').write_text(f'a  <TOK> number {i} ')
+        m = np.zeros((h, w), dtype=np.uint8)
+        m[h // 4:3 * h // 4, w // 4:3 * w // 4] = 255
+        Image.fromarray(m, 'L').save(mask_dir / f'{i}.png')
+    clist = tmp_path / 'concept.json'
+    clist.write_text(json.dumps([dict(instance_prompt='<TOK>', instance_data_dir=str(img_dir),
+                                      caption_dir=str(cap_dir), mask_dir=str(mask_dir))]))
+    opt = dict(name='LoraDataset', concept_list=str(clist), use_caption=True, use_mask=True,
+               instance_transform=[dict(type='HumanResizeCropFinalV3', size=64, crop_p=0.5), dict(type='ToTensor')],
+               replace_mapping={'<TOK>': '<potter1> <potter2>'}, dataset_enlarge_ratio=3)
+    ds = build_train_dataset(opt)
+    assert isinstance(ds, LoraDataset) and len(ds) == 6
+    seen = set()
+    for i in range(len(ds)):
+        it = ds[i]
+        assert it['images'].shape == (3, 64, 64) and -1.0 <= it['images'].min() and it['images'].max() <= 1.0
+        assert it['masks'].shape == (1, 8, 8) and it['img_masks'].shape == (1, 8, 8)
+        assert set(it['masks'].unique().tolist()) <= {0.0, 1.0} and 0 < it['masks'].sum() < 64
+        assert it['masks'][0, 4, 4] == 1 and it['masks'][0, 0, 0] == 0                   # centred box survives the crop
+        seen.add(it['prompts'])
+    assert seen == {'a <potter1> <potter2> number 0', 'a <potter1> <potter2> number 1'}  # replaced, spaces squeezed
+    # without captions / masks: the instance prompt and all-ones masks
+    plain = LoraDataset(dict(opt, use_caption=False, use_mask=False))
+    assert plain[0]['prompts'] == '<potter1> <potter2>' and plain[0]['masks'].min() == 1
+    # a missing concept list falls back to the synthetic dataset (what bench.py and the shipped recipe use)
+    assert isinstance(build_train_dataset(dict(opt, concept_list=str(tmp_path / 'nope.json'))), SyntheticLoraDataset)
