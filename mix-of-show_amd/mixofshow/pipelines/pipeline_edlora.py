@@ -143,25 +143,19 @@ class StableDiffusionPipeline:
         return [Image.fromarray((im * 255).round().astype(np.uint8)) for im in images]
 
 
-class EDLoRAPipeline(StableDiffusionPipeline):
-
-    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, safety_checker=None, feature_extractor=None,
-                 requires_safety_checker=False):
-        super().__init__(vae, text_encoder, tokenizer, unet, scheduler)
-        revise_edlora_unet_attention_forward(unet)  # reference :93
-        self.new_concept_cfg = None
+    # ---- sampling (shared by the plain and the ED-LoRA pipeline) -------------------------------------------
+    _requires_concept_cfg = False
+    new_concept_cfg = None
 
     def set_new_concept_cfg(self, new_concept_cfg=None):
         self.new_concept_cfg = new_concept_cfg
 
-    def set_controller(self, controller):
-        self.controller = controller
-        revise_edlora_unet_attention_controller_forward(self.unet, controller)
-
     def _encode_prompt(self, prompt, new_concept_cfg, device, num_images_per_prompt, do_classifier_free_guidance,
                        negative_prompt=None, prompt_embeds=None, negative_prompt_embeds=None):
-        """(B,16,77,768) layer-wise embeddings; negative embeddings repeated over the 16 layers and
-        concatenated in front for classifier-free guidance (reference :111-190)."""
+        """ED-LoRA: (B,16,77,768) layer-wise embeddings, negative embeddings repeated over the 16 layers and
+        concatenated in front for classifier-free guidance (reference :111-190). Plain LoRA / no concepts (one token
+        per concept word, or no table): ordinary (B,77,768) embeddings, what diffusers' StableDiffusionPipeline —
+        the class the reference picks when `enable_edlora` is false (test_edlora.py:90) — computes."""
         assert num_images_per_prompt == 1, 'only support num_images_per_prompt=1 now'
         if isinstance(prompt, str):
             batch_size = 1
@@ -171,11 +165,17 @@ class EDLoRAPipeline(StableDiffusionPipeline):
             batch_size = prompt_embeds.shape[0]
         tok = self.tokenizer
         if prompt_embeds is None:
-            ids = tok(bind_concept_prompt(prompt, new_concept_cfg), padding='max_length', max_length=tok.model_max_length,
-                      truncation=True, return_tensors='pt').input_ids
+            if new_concept_cfg:
+                texts = bind_concept_prompt(prompt, new_concept_cfg)      # 16 (ED-LoRA) or 1 (LoRA) per prompt
+            else:
+                texts = [prompt] if isinstance(prompt, str) else list(prompt)
+            ids = tok(texts, padding='max_length', max_length=tok.model_max_length, truncation=True,
+                      return_tensors='pt').input_ids
             prompt_embeds = self.text_encoder(ids.to(device))[0]
             prompt_embeds = prompt_embeds.reshape(batch_size, -1, *prompt_embeds.shape[1:])
         prompt_embeds = prompt_embeds.to(dtype=self.text_encoder.dtype, device=device)
+        if prompt_embeds.dim() == 3:
+            prompt_embeds = prompt_embeds[:, None]
         _, layer_num, seq_len, _ = prompt_embeds.shape
         if do_classifier_free_guidance and negative_prompt_embeds is None:
             if negative_prompt is None:
@@ -195,7 +195,7 @@ class EDLoRAPipeline(StableDiffusionPipeline):
             n = negative_prompt_embeds.to(dtype=self.text_encoder.dtype, device=device)
             n = n.view(batch_size, 1, n.shape[1], -1).repeat(1, layer_num, 1, 1)
             prompt_embeds = torch.cat([n, prompt_embeds])
-        return prompt_embeds
+        return prompt_embeds[:, 0] if layer_num == 1 else prompt_embeds
 
     @torch.no_grad()
     def __call__(self, prompt=None, height=None, width=None, num_inference_steps=50, guidance_scale=7.5,
@@ -208,7 +208,7 @@ class EDLoRAPipeline(StableDiffusionPipeline):
         batch_size = 1 if isinstance(prompt, str) else (len(prompt) if isinstance(prompt, list) else prompt_embeds.shape[0])
         device = self._execution_device
         do_cfg = guidance_scale > 1.0
-        assert self.new_concept_cfg is not None
+        assert self.new_concept_cfg is not None or not self._requires_concept_cfg
         prompt_embeds = self._encode_prompt(prompt, self.new_concept_cfg, device, num_images_per_prompt, do_cfg,
                                             negative_prompt, prompt_embeds=prompt_embeds,
                                             negative_prompt_embeds=negative_prompt_embeds)
@@ -253,3 +253,19 @@ class EDLoRAPipeline(StableDiffusionPipeline):
         if not return_dict:
             return image
         return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None)
+
+
+class EDLoRAPipeline(StableDiffusionPipeline):
+
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, safety_checker=None, feature_extractor=None,
+                 requires_safety_checker=False):
+        super().__init__(vae, text_encoder, tokenizer, unet, scheduler)
+        revise_edlora_unet_attention_forward(unet)  # reference :93
+        self.new_concept_cfg = None
+
+    _requires_concept_cfg = True
+
+    def set_controller(self, controller):
+        self.controller = controller
+        revise_edlora_unet_attention_controller_forward(self.unet, controller)
+

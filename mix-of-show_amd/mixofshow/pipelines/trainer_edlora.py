@@ -189,8 +189,9 @@ class EDLoRATrainer(nn.Module):
     def tokenize(self, prompts, batch):
         """Host side of the text path: 16-way concept binding + tokenisation (+ positions of the concept tokens in
         the first prompt of each sample). Returns CPU tensors (ids (B*16, 77) int64, positions (B, T) int32 | None)."""
-        if self.enable_edlora:
-            prompts = bind_concept_prompt(prompts, new_concept_cfg=self.new_concept_cfg)
+        # ED-LoRA: 16 layer-wise prompts per sample. Plain LoRA (one token per concept word): the reference leaves the
+        # prompt alone (:220-221) and expects `<newK>` in the captions; binding 1:1 accepts both spellings.
+        prompts = bind_concept_prompt(prompts, new_concept_cfg=self.new_concept_cfg)
         ids = self.tokenizer(prompts, padding='max_length', max_length=self.tokenizer.model_max_length,
                              truncation=True, return_tensors='pt').input_ids
         pos = self._concept_positions(ids, batch) if self.attn_reg_weight is not None else None

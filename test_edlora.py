@@ -8,7 +8,7 @@ import mos_path  # noqa: F401
 import torch
 
 from mixofshow.data.prompt_dataset import PromptDataset
-from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline
+from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline, StableDiffusionPipeline
 from mixofshow.utils.convert_edlora_to_diffusers import convert_edlora
 from mixofshow.utils.options import load_options
 
@@ -30,7 +30,8 @@ def test(root_path, args):
     opt.setdefault('path', {})
     opt['path']['visualization'] = osp.join(root_path, 'results', opt['name'], 'visualization')
     device = 'cuda' if torch.cuda.is_available() else 'cpu'
-    pipe = EDLoRAPipeline.from_pretrained(opt['models']['pretrained_path'], torch_dtype=torch.float16).to(device)
+    pipeclass = EDLoRAPipeline if opt['models']['enable_edlora'] else StableDiffusionPipeline     # reference :90
+    pipe = pipeclass.from_pretrained(opt['models']['pretrained_path'], torch_dtype=torch.float16).to(device)
     pipe, cfg = convert_edlora(pipe, torch.load(opt['path']['lora_path'], weights_only=False),
                                enable_edlora=opt['models']['enable_edlora'], alpha=opt['models'].get('alpha', 1.0))
     pipe.set_new_concept_cfg(cfg)

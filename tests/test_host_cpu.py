@@ -454,3 +454,40 @@ def test_lora_dataset_from_image_folders(tmp_path):
     assert plain[0]['prompts'] == '<potter1> <potter2>' and plain[0]['masks'].min() == 1
     # a missing concept list falls back to the synthetic dataset (what bench.py and the shipped recipe use)
     assert isinstance(build_train_dataset(dict(opt, concept_list=str(tmp_path / 'nope.json'))), SyntheticLoraDataset)
+
+
+def test_plain_lora_mode_train_convert_sample(emulated_hip):
+    """`enable_edlora: false` (reference: one embedding per concept word, diffusers' StableDiffusionPipeline at
+    inference, test_edlora.py:90): trainer step with the regulariser on, checkpoint with (1, C) rows, merge, sample."""
+    from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline, StableDiffusionPipeline
+    from mixofshow.pipelines.trainer_edlora import EDLoRATrainer
+    from mixofshow.utils.convert_edlora_to_diffusers import convert_edlora
+    cfg = dict(text_embedding=dict(enable_tuning=True, lr=1e-3),
+               text_encoder=dict(enable_tuning=True, lora_cfg=dict(rank=4, alpha=1.0, where='CLIPAttention'), lr=1e-5),
+               unet=dict(enable_tuning=True, lora_cfg=dict(rank=4, alpha=1.0, where='Attention'), lr=1e-4))
+    torch.manual_seed(0)
+    tr = EDLoRATrainer('synthetic://tiny', '<potter1>+<potter2>', '<rand-0.013>+man', False, finetune_cfg=cfg,
+                       noise_offset=0.01, attn_reg_weight=0.01, reg_full_identity=False, use_mask_loss=True)
+    assert tr.concept_embedding.shape == (2, 64)
+    b = _batch()
+    loss = tr(**b)
+    loss.backward()
+    assert torch.isfinite(loss) and tr.concept_embedding.grad.abs().sum() > 0       # the bound tokens are in the graph
+    same = tr(**dict(b, prompts=['a <new0> <new1> in the park'] * 2))                # reference spelling
+    torch.testing.assert_close(same, loss)
+    d = tr.delta_state_dict()
+    assert {k: tuple(v.shape) for k, v in d['new_concept_embedding'].items()} == {'<potter1>': (1, 64), '<potter2>': (1, 64)}
+    lat = torch.randn(1, 4, 8, 8, generator=torch.manual_seed(3))
+    outs = []
+    for cls in (StableDiffusionPipeline, EDLoRAPipeline):
+        pipe = cls.from_pretrained('synthetic://tiny', torch_dtype=torch.float32)
+        pipe, ccfg = convert_edlora(pipe, {'params': d}, enable_edlora=False, alpha=0.7)
+        assert ccfg['<potter2>']['concept_token_names'] == ['<new1>']
+        pipe.set_new_concept_cfg(ccfg)
+        outs.append(pipe(prompt='a <potter1> <potter2> dog', negative_prompt='blurry', height=64, width=64,
+                         num_inference_steps=2, output_type='latent', latents=lat.clone()).images)
+        assert outs[-1].shape == (1, 4, 8, 8) and torch.isfinite(outs[-1]).all()
+    torch.testing.assert_close(outs[0], outs[1])         # single-layer embeddings: both classes take the same path
+    plain = StableDiffusionPipeline.from_pretrained('synthetic://tiny', torch_dtype=torch.float32)
+    assert plain(prompt='a dog', height=64, width=64, num_inference_steps=2, output_type='latent',
+                 latents=lat.clone()).images.shape == (1, 4, 8, 8)                   # no concept table at all

@@ -105,7 +105,8 @@ def save_and_validation(opt, trainer, global_step, logger, rank):
         valset_cfg = opt['datasets']['val_vis']
         loader = torch.utils.data.DataLoader(PromptDataset(valset_cfg), batch_size=valset_cfg['batch_size_per_gpu'])
         for lora_alpha in opt['val']['alpha_list']:
-            pipe = EDLoRAPipeline.from_pretrained(opt['models']['pretrained_path'], torch_dtype=torch.float16)
+            pipeclass = EDLoRAPipeline if enable_edlora else StableDiffusionPipeline           # reference :179
+            pipe = pipeclass.from_pretrained(opt['models']['pretrained_path'], torch_dtype=torch.float16)
             pipe.to(trainer.concept_embedding.device)
             pipe, cfg = convert_edlora(pipe, torch.load(save_path, weights_only=False), enable_edlora=enable_edlora,
                                        alpha=lora_alpha)
