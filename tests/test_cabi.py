@@ -83,3 +83,38 @@ def test_product_never_imports_oracle():
             if re.search(r'^\s*(from|import)\s+oracle\b', open(f).read(), flags=re.M):
                 bad.append(f)
     assert not bad, f'product files import the oracle: {bad}'
+
+
+def test_workspace_size_functions_host_side():
+    """The `mos_*_workspace_bytes` entry points are pure host functions: callable without a GPU. They pin the launch
+    plans (split counts) the kernels use: the caller allocates exactly this much."""
+    import ctypes
+    from mixofshow.hip import lib
+    L = lib.load()
+
+    def attn_ws(B, H, Nq, Nkv, d):
+        s = lib.AttnShape(B, H, Nq, Nkv, d, 0, 0, 0, 0, 0, 0, 0, 0, 1.0)
+        return L.mos_attn_bwd_workspace_bytes(ctypes.byref(s))
+
+    def rows(B, H, Nq):
+        return 4 * ((B * H * Nq + 3) // 4 * 4)
+
+    # level-0 self attention of the bench: >= 512 key blocks already, no query splits -> only the D vector
+    assert attn_ws(4, 8, 4096, 4096, 40) == rows(4, 8, 4096)
+    # cross attention, 77 keys = one key block per (b, h): queries are split to fill the chip, fp32 partials for dK, dV
+    ws = attn_ws(4, 8, 4096, 77, 40)
+    extra = ws - rows(4, 8, 4096)
+    per_split = 2 * 4 * 8 * 77 * 40 * 4
+    assert extra > 0 and extra % per_split == 0 and 2 <= extra // per_split <= 64
+    assert attn_ws(4, 8, 4096, 77, 40) <= attn_ws(4, 8, 8192, 77, 40)            # monotone in the number of queries
+    assert L.mos_attn_bwd_workspace_bytes(None) == 0
+    # LoRA backward: partial sums of dA / dB (at most 32 chunks... of 16 x max(N, K) floats) — positive, monotone
+    w1, w2 = L.mos_lora_bwd_workspace_bytes(16384, 320, 320), L.mos_lora_bwd_workspace_bytes(16384, 960, 320)
+    assert 0 < w1 <= w2 and w1 % 4 == 0
+    # Gram accumulation: chunks x padded (Cout + Cin) x Cin floats; degenerate shapes -> 0
+    g = L.mos_gram_workspace_bytes(20000, 320, 320)
+    assert g > 0 and g % (2 * 384 * 320 * 4) == 0 or g % (320 * 4) == 0
+    assert L.mos_gram_workspace_bytes(0, 320, 320) == 0
+    assert L.mos_lsq_workspace_bytes(320, 768) == 5 * 12 * 8
+    # GroupNorm: B x G x splits x 2 floats; invalid channel/group combination -> 0
+    assert L.mos_groupnorm_workspace_bytes(4, 320, 4096, 32) > 0 and L.mos_groupnorm_workspace_bytes(4, 320, 4096, 33) == 0
