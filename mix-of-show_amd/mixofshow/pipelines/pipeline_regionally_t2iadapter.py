@@ -10,6 +10,7 @@ context prompt and of all regions come from ONE fused [to_k; to_v] GEMM per laye
 steps (they are step-invariant), and one kernel (`mos_region_cross_attn_fwd`) computes, for every query, the base
 attention or the count-normalised sum of the covering regions' attentions — no masks, no syncs, no scatter.
 """
+import ast
 import math
 from types import SimpleNamespace
 
@@ -230,7 +231,7 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
             if region_weight != '':
                 for item in region_weight.split('|'):
                     region, rw = item.split('-')
-                    region, rw = eval(region), eval(rw)  # noqa: S307 — reference grammar (:500-501)
+                    region, rw = ast.literal_eval(region), float(ast.literal_eval(rw))   # grammar of reference :500-501
                     fh, fw = f.shape[2:]
                     h0, w0, h1, w1 = region
                     h0, h1, w0, w1 = h0 / height, h1 / height, w0 / width, w1 / width
