@@ -209,7 +209,7 @@ def test_training_steps_match_reference_path_and_engine_runs():
         den += r.detach().pow(2).sum().item()
     rel = (num / den)**0.5
     print(f'[parity] parameters after 3 AdamW steps: rel_l2_diff={rel:.3e}')
-    assert rel < 2e-3
+    assert rel < 3e-3        # observed 1.1e-3 .. 1.2e-3 (bf16 path vs fp32 twin; run-to-run spread 2e-4 .. 3e-4)
     assert engine.global_step == 3 and not bool(engine.stop_flag)   # synthetic CLIP rows have real-CLIP-like norms
 
 
