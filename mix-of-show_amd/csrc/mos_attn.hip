@@ -34,6 +34,9 @@
 #ifndef MOS_STAGGER
 #define MOS_STAGGER 0   // 1: odd wave slots run at priority 1; 2: odd wave slots start ~half a tile late
 #endif
+#ifndef MOS_DKDV_FOLD
+#define MOS_DKDV_FOLD 0   // 1 (experimental, d = 40): -lse/scale and -D ride in the free pad columns 40..42 of the Q / dO tiles
+#endif
 #ifndef MOS_DKDV_LDS_PAD
 #define MOS_DKDV_LDS_PAD 0   // experiment: extra dynamic LDS per block (forces one block per CU)
 #endif
@@ -738,6 +741,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
     load_row_frags<T, D>(kf, (const T*)a.k + (int64_t)b * a.k_bs + (int64_t)kc * a.k_rs + h * D, kvalid, hh);
     load_row_frags<T, D>(vf, (const T*)a.v + (int64_t)b * a.v_bs + (int64_t)kc * a.v_rs + h * D, kvalid, hh);
     const float c = a.scale * LOG2E;
+    // FOLD (d = 40: the contraction is padded 40 -> 48): the query side carries -lse/scale (resp. -D) split over three
+    // half-precision pad columns 40..42, the key side carries 1 there, so the MFMA itself delivers q.k - lse/scale and
+    // dO.v - D: no per-tile statistics reads from LDS, one VALU op less per pair, 32 registers less.
+    constexpr bool FOLD = (MOS_DKDV_FOLD != 0) && D == 40;
+    if constexpr (FOLD) {
+        if (hh == 1) {                       // lanes with hh = 1 hold columns 40..47 in fragment ks = 2
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { kf[KS - 1][e] = (T)1.0f; vf[KS - 1][e] = (T)1.0f; }
+        }
+    }
     int mytok = -1;  // index t of the exported column this lane's key corresponds to, if any
     if constexpr (PCOLS) {
 #pragma unroll
@@ -787,8 +800,20 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
         if (tid < KV_TILE) {
             float* sb = stat_ + bf * ST;
             const bool ok = tid < st_nv;
-            sb[tid] = ok ? st_lse * LOG2E : 0.f;
-            sb[KV_TILE + tid] = ok ? st_D : 0.f;
+            if constexpr (FOLD) {
+                auto split3 = [](float x, T* dst) {     // x = hi + mid + lo in T (24 significant bits), 4th = 0
+                    const T hi = (T)x;
+                    const float r1 = x - (float)hi;
+                    const T mid = (T)r1;
+                    const T lo = (T)(r1 - (float)mid);
+                    dst[0] = hi; dst[1] = mid; dst[2] = lo; dst[3] = (T)0.0f;
+                };
+                split3(ok ? -st_lse / a.scale : 0.f, Qs_ + bf * RT + tid * RS + D);
+                split3(ok ? -st_D : 0.f, dOs_ + bf * RT + tid * RS + D);
+            } else {
+                sb[tid] = ok ? st_lse * LOG2E : 0.f;
+                sb[KV_TILE + tid] = ok ? st_D : 0.f;
+            }
             if constexpr (PCOLS) {
 #pragma unroll
                 for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
@@ -830,11 +855,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
                 aq[ks] = as_v8<T>(ld16(Qs + off));
                 ado[ks] = as_v8<T>(ld16(dOs + off));
             }
+            if constexpr (!FOLD) {
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int ql = 32 * t + 8 * r4 + 4 * hh;
-                l4[r4] = *reinterpret_cast<const f32x4*>(lse_s + ql);
-                d4[r4] = *reinterpret_cast<const f32x4*>(D_s + ql);
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int ql = 32 * t + 8 * r4 + 4 * hh;
+                    l4[r4] = *reinterpret_cast<const f32x4*>(lse_s + ql);
+                    d4[r4] = *reinterpret_cast<const f32x4*>(D_s + ql);
+                }
             }
         };
         read_rows(0);
@@ -866,13 +893,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
                     const int r = 4 * r4 + rr;
                     // keys past Nkv (lanes of the last key block) need no masking: each lane's key is one column of
                     // dK^T / dV^T, columns never mix, and the store skips invalid keys
-                    const float p = __builtin_amdgcn_exp2f(s[r] * c - l4[r4][rr]);
-                    float g = dp[r];
+                    float p, g = dp[r];
+                    if constexpr (FOLD) p = __builtin_amdgcn_exp2f(s[r] * c);       // s already holds q.k - lse/scale
+                    else p = __builtin_amdgcn_exp2f(s[r] * c - l4[r4][rr]);
                     if constexpr (PCOLS) {
                         if (mytok >= 0) g += dpc_s[(32 * t + 8 * r4 + 4 * hh + rr) * MOS_MAX_PCOLS + mytok];
                     }
                     s[r] = p;
-                    dp[r] = p * (g - d4[r4][rr]);
+                    if constexpr (FOLD) dp[r] = p * g;                              // dp already holds dO.v - D
+                    else dp[r] = p * (g - d4[r4][rr]);
                 }
             }
             v8 pf[2], dsf[2];

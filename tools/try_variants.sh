@@ -10,6 +10,7 @@ VARIANTS=(
   "v2nk1|-DMOS_DKDV_V2=1 -DMOS_DKDV_V2_NK=1" # two-stage pipelined dK/dV, one key group
   "v2nk2|-DMOS_DKDV_V2=1 -DMOS_DKDV_V2_NK=2" # two-stage, two key groups (spills today)
   "dq8|-DMOS_DQ_NW=8"                        # 8-wave dQ blocks
+  "fold|-DMOS_DKDV_FOLD=1"                   # dK/dV d=40: -lse/scale and -D folded into the pad columns of the MFMA contraction
   "noslp|-fno-slp-vectorize"                 # no v_pk_{mul,add}_f32 (2804 -> 24 in mos_attn; the guide calls packed f32 VALU an anti-lever beside MFMAs)
 )
 case "${1:-}" in
