@@ -34,6 +34,9 @@
 #ifndef MOS_STAGGER
 #define MOS_STAGGER 0   // 1: odd wave slots run at priority 1; 2: odd wave slots start ~half a tile late
 #endif
+#ifndef MOS_FWD_LSUM
+#define MOS_FWD_LSUM 0    // 1 (experimental, d <= 80): softmax row sums come out of the P.V MFMA (ones row in V^T's padding)
+#endif
 #ifndef MOS_DKDV_FOLD
 #define MOS_DKDV_FOLD 0   // 1 (experimental, d = 40): -lse/scale and -D ride in the free pad columns 40..42 of the Q / dO tiles
 #endif
@@ -257,7 +260,9 @@ struct TrStage {
 
 // ---- one attention pass of a wave's NQ x 32 queries over all keys of one source ----------------
 // Returns unnormalised O^T accumulators, running max m (raw score units) and PER-LANE partial sums l.
-template <typename T, int D, int NQ, bool PCOLS>
+// LSUM: the caller put a row of ones into row D of the transposed V tiles (a padding row), so accumulator row D of O^T
+// IS the running row sum (rescaled with O^T for free): no per-element adds here, `l` is left untouched.
+template <typename T, int D, int NQ, bool PCOLS, bool LSUM = false>
 __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vbase, int64_t v_rs, int Nkv,
                                        float c /* scale*log2e */, T* Ks_, T* Vt_,
                                        const typename MT<T>::v8 (&qf)[NQ][HD<D>::KS],
@@ -353,9 +358,9 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
                 for (int r = 0; r < 16; ++r) {
                     const float p = __builtin_amdgcn_exp2f(s[iq][t][r] * c - mc);
                     s[iq][t][r] = p;
-                    ls += p;
+                    if constexpr (!LSUM) ls += p;
                 }
-            l[iq] = l[iq] * alpha + ls;
+            if constexpr (!LSUM) l[iq] = l[iq] * alpha + ls;
             if (__any(alpha != 1.0f)) {  // wave-uniform: once the running max has settled no lane rescales
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
@@ -417,6 +422,14 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
 
     zero_row_pads<T, D>(Ks, tid); zero_row_pads<T, D>(Ks + HD<D>::ROW_TILE_ELEMS, tid);
     zero_tr_pads<T, D>(Vt, tid); zero_tr_pads<T, D>(Vt + HD<D>::TR_TILE_ELEMS, tid);
+    constexpr bool LSUM = (MOS_FWD_LSUM != 0) && HD<D>::DV > D;
+    if constexpr (LSUM) {      // row D of both V^T buffers = 1 for every key (keys past Nkv have p = 0 anyway)
+        __syncthreads();       // after the zero fill of the padding rows (other threads' words)
+        if (tid < KV_TILE) {
+            Vt[D * TS + tid] = (T)1.0f;
+            Vt[HD<D>::TR_TILE_ELEMS + D * TS + tid] = (T)1.0f;
+        }
+    }
 
     const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
     const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * D;
@@ -442,12 +455,21 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
     f32x16 o[NQ][HD<D>::DT];
     float m[NQ], l[NQ];
     const float c = a.scale * LOG2E;
-    attend<T, D, NQ, PCOLS>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, a.n_pcols, cap, tid, l31, hh);
+    attend<T, D, NQ, PCOLS, LSUM>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, a.n_pcols, cap, tid, l31,
+                                  hh);
 
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
         const int qi = q0 + 32 * iq + l31;
-        const float lt = l[iq] + __shfl_xor(l[iq], 32);
+        float lt;
+        if constexpr (LSUM) {
+            // accumulator row D = 32*(D/32) + (D%32); (D%32) is 8 or 16 -> register 4 or 8 of the lanes with hh = 0
+            constexpr int RL = (D % 32) / 8 * 4;
+            static_assert((D % 32) % 8 == 0 && D % 32 != 0, "row D must sit in a register of the hh = 0 lanes");
+            lt = __shfl(o[iq][D / 32][RL], l31);
+        } else {
+            lt = l[iq] + __shfl_xor(l[iq], 32);
+        }
         const float inv = 1.0f / lt;
         store_out_rows<T, D>(op + (int64_t)qi * a.o_rs, qi < a.Nq, o[iq], inv, hh);
         const int64_t row = ((int64_t)b * a.H + h) * a.Nq + qi;
