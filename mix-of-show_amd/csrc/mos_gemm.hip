@@ -16,6 +16,14 @@
 #include <type_traits>
 #include "mos_common.h"
 
+// tuning knobs (tools/build_variant.sh)
+#ifndef MOS_TN_REDUCE_UNROLL
+#define MOS_TN_REDUCE_UNROLL 0
+#endif
+#ifndef MOS_TN_TARGET_WG
+#define MOS_TN_TARGET_WG 512      // workgroups the LoRA-gradient kernel aims at (tuning knob)
+#endif
+
 namespace {
 
 constexpr int GEMM_BM = 128;
@@ -265,10 +273,29 @@ __global__ void skinny_tn_reduce_kernel(const float* __restrict__ partial, float
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= MOS_LORA_PAD * C) return;
     const int j = idx / C, c = idx - j * C;
+#if MOS_TN_REDUCE_UNROLL
+    // experimental: four independent accumulators so that the loads of a thread are in flight together (the plain
+    // loop is a chain of ~100 dependent L2 round trips per thread: ~10 us for a few hundred KB)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j < NJ) {
+        const float* pp = partial + (int64_t)j * C + c;
+        const int64_t cs = (int64_t)NJ * C;
+        int ch = 0;
+        for (; ch + 4 <= nchunk; ch += 4) {
+            s0 += pp[(ch + 0) * cs];
+            s1 += pp[(ch + 1) * cs];
+            s2 += pp[(ch + 2) * cs];
+            s3 += pp[(ch + 3) * cs];
+        }
+        for (; ch < nchunk; ++ch) s0 += pp[ch * cs];
+    }
+    out[idx] = (s0 + s1) + (s2 + s3);
+#else
     float s = 0.f;
     if (j < NJ)
         for (int ch = 0; ch < nchunk; ++ch) s += partial[((int64_t)ch * NJ + j) * C + c];
     out[idx] = s;
+#endif
 }
 
 template <typename T>
@@ -338,7 +365,7 @@ int launch_skinny_nt(const void* X, int64_t ldx, const void* S, void* Tout, int 
 
 inline int tn_rows_per_chunk(int M, int C) {
     const int colblocks = (C + 63) / 64;
-    int nchunk = (512 + colblocks - 1) / colblocks;   // aim at >= ~512 workgroups
+    int nchunk = (MOS_TN_TARGET_WG + colblocks - 1) / colblocks;   // aim at >= ~512 workgroups
     const int maxchunk = (M + 63) / 64;
     if (nchunk > maxchunk) nchunk = maxchunk;
     if (nchunk < 1) nchunk = 1;
