@@ -491,3 +491,47 @@ def test_plain_lora_mode_train_convert_sample(emulated_hip):
     plain = StableDiffusionPipeline.from_pretrained('synthetic://tiny', torch_dtype=torch.float32)
     assert plain(prompt='a dog', height=64, width=64, num_inference_steps=2, output_type='latent',
                  latents=lat.clone()).images.shape == (1, 4, 8, 8)                   # no concept table at all
+
+
+def test_region_processor_random_boxes_vs_oracle(emulated_hip):
+    """Randomised region lists (overlapping, nested, degenerate / zero-area, touching the border, up to 8 regions)
+    through the product processor (kernels emulated) and the oracle's restatement of region_rewrite: the mask
+    rounding (ceil starts / floor ends), the count normalisation and the base-where-uncovered rule must agree."""
+    import random
+    from mixofshow.models.attention import Attention
+    from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionT2I_AttnProcessor
+    from oracle import region_ref
+    from oracle.attention_shim import Attention as Shim
+    torch.manual_seed(0)
+    rnd = random.Random(0)
+    C, heads, Cc = 64, 8, 48
+    prod = Attention(C, cross_attention_dim=Cc, heads=heads, dim_head=C // heads)
+    with torch.no_grad():
+        for p in prod.parameters():
+            p.copy_((torch.randn_like(p) * (0.5 / p.shape[-1]**0.5 if p.dim() > 1 else 0.02)).half().float())
+    ref = Shim(C, cross_attention_dim=Cc, heads=heads, dim_head=C // heads)
+    ref.load_state_dict(prod.state_dict())
+    ref_proc = region_ref.RegionT2I_AttnProcessorRef(0)
+    for trial in range(24):
+        fh, fw = rnd.choice([(8, 12), (6, 6), (4, 10)])
+        H, W = fh * 8, fw * 8
+        hs = torch.randn(2, fh * fw, C).half().float()
+        ctx = torch.randn(2, 77, Cc).half().float()
+        regions = []
+        for _ in range(rnd.randint(1, 8)):
+            kind = rnd.random()
+            if kind < 0.15:                                   # zero area after rounding
+                h0 = rnd.random() * 0.9; w0 = rnd.random() * 0.9
+                box = [h0, w0, h0 + 0.01, w0 + 0.01]
+            elif kind < 0.3:                                  # whole image / touching the border
+                box = [0.0, 0.0, 1.0, rnd.choice([0.5, 1.0])]
+            else:
+                h0, h1 = sorted(rnd.random() for _ in range(2))
+                w0, w1 = sorted(rnd.random() for _ in range(2))
+                box = [h0, w0, h1, w1]
+            regions.append((torch.randn(2, 77, Cc).half().float(), box))
+        kw = dict(region_list=regions, height=H, width=W)
+        y = RegionT2I_AttnProcessor(0)(prod, hs.half(), encoder_hidden_states=ctx.half(),
+                                       region_list=[(r[0].half(), r[1]) for r in regions], height=H, width=W)
+        y_ref = ref_proc(ref, hs, encoder_hidden_states=ctx, **kw)
+        torch.testing.assert_close(y.float(), y_ref, rtol=3e-2, atol=5e-3, msg=lambda m: f'trial {trial}: {m}')
