@@ -51,6 +51,13 @@ def merge_lora_into_weight(original_state_dict, lora_state_dict, modification_la
     return new_sd
 
 
+def _snapshot(model):
+    """Detached CLONES of a state dict (reference: copy.deepcopy(state_dict), :500/:660). `state_dict()` tensors alias
+    the parameters, and `load_state_dict(merged)` copies in place — a shallow copy would be overwritten by concept 1
+    and every later concept would be merged on top of it."""
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
 def init_stable_diffusion(pretrained_model_path, device):
     pipe = StableDiffusionPipeline.from_pretrained(pretrained_model_path, torch_dtype=torch.float16).to(device)
     pipe.scheduler = DPMSolverMultistepScheduler()
@@ -193,7 +200,7 @@ def merge_text_encoder(concept_list, optimize_iters, new_concept_cfg, tokenizer,
         m = mods[wname.replace('.weight', '')]
         handles.append(m.register_forward_hook(
             lambda mod, fin, fout, wname=wname: rec.record(wname, mod, fin[0], fout)))
-    original = copy.copy(text_encoder.state_dict())
+    original = _snapshot(text_encoder)          # deep: load_state_dict below writes into the live tensors
     for concept, lora in zip(concept_list, text_encoder_list):
         merged = merge_lora_into_weight(original, lora, layer_names, 'text_encoder', concept['text_encoder_alpha'], device)
         text_encoder.load_state_dict(merged)
@@ -261,7 +268,7 @@ def merge_spatial_attention(concept_list, optimize_iters, new_concept_cfg, token
 
     for a in tapped:
         object.__setattr__(a, '_mos_tap', tap)
-    original = copy.copy(unet.state_dict())
+    original = _snapshot(unet)
     revise_edlora_unet_attention_forward(unet)
     for concept, lora in zip(concept_list, unet_spatial_attn_list):
         merged = merge_lora_into_weight(original, lora, layer_names, 'unet', concept['unet_alpha'], device)

@@ -3,7 +3,7 @@
 The reference's LoraDataset (mixofshow/data/lora_dataset.py:13-102 + pil_transform.py) is CPU data preparation
 built on torchvision / cv2 (neither is installed here) and is OUT OF SCOPE of the hot path. Two
 datasets are provided behind the same `datasets.train` option block:
-  * `SyntheticLoraDataset` (name: SyntheticLoraDataset, or any config whose concept_list does not exist): seeded
+  * `SyntheticLoraDataset` (name: SyntheticLoraDataset, or concept_list: synthetic://...): seeded
     tensors of the shapes the trainer consumes — images U(-1,1) (3,512,512), masks = centred box of ones in
     (1,64,64), img_masks ones, captions with the concept tokens. Used by bench.py and the tests.
   * `LoraDataset`: a PIL-only loader for real concept folders supporting resize + centre-crop to `size`, ToTensor,
@@ -104,13 +104,17 @@ class LoraDataset(Dataset):
         if mask is not None:
             mk = self._load(mask, 'L', self.size, nearest=True)[None]
             out['masks'] = torch.nn.functional.interpolate(mk[None], size=(m, m), mode='nearest')[0]
-        else:
-            out['masks'] = torch.ones(1, m, m)
+        # no mask file: the key is omitted (reference lora_dataset.py:90-94) and the loop falls back to img_masks
         return out
 
 
 def build_train_dataset(opt):
     name = opt.get('name', 'LoraDataset')
-    if name == 'SyntheticLoraDataset' or not os.path.exists(str(opt.get('concept_list', ''))):
+    concept_list = str(opt.get('concept_list', ''))
+    if name == 'SyntheticLoraDataset' or concept_list.startswith('synthetic://'):
         return SyntheticLoraDataset(opt)
+    if not os.path.exists(concept_list):
+        # a typo must not silently train on noise
+        raise FileNotFoundError(f'datasets.train.concept_list {concept_list!r} does not exist (use name: '
+                                'SyntheticLoraDataset or concept_list: synthetic://... for the seeded synthetic data)')
     return LoraDataset(opt)

@@ -11,6 +11,7 @@ import torch
 from . import ops
 
 _default_compute_dtype = torch.float16
+MAX_PACKED_RANK = ops.MOS_LORA_PAD      # LoRA ranks of the sites fused into one GEMM share a 16-wide MFMA operand
 
 
 def set_default_compute_dtype(dtype):

@@ -48,10 +48,15 @@ def lora_pack(downs, ups, alphas, K, dtype, device):
     """Pack fp32 master LoRA factors of up to 4 sites sharing one input into MFMA operands.
 
     downs[g]: (r, K) fp32, ups[g]: (n_g, r) fp32. Returns A16 (16,K), A16T (K,16), Bp16 (N,16), BpT (16,N)."""
-    _dev(*downs, *ups)
     n_sites = len(downs)
     r = downs[0].shape[0]
-    assert 1 <= n_sites <= 4 and n_sites * r <= MOS_LORA_PAD, f'{n_sites} sites of rank {r} exceed the packed rank 16'
+    if r > MOS_LORA_PAD:
+        raise ValueError(f'LoRA rank {r} is not supported by the fused HIP path: the rank dimension is one '
+                         f'{MOS_LORA_PAD}-wide MFMA operand (rank <= {MOS_LORA_PAD}); see INTEGRATION.md')
+    if not (1 <= n_sites <= 4 and n_sites * r <= MOS_LORA_PAD):
+        raise ValueError(f'{n_sites} LoRA sites of rank {r} do not fit one packed rank-{MOS_LORA_PAD} operand; fuse '
+                         'fewer projections per call (mixofshow.models.attention falls back to one GEMM per projection)')
+    _dev(*downs, *ups)
     s = _lib.LoraSites()
     s.n_sites, s.rank, s.K = n_sites, r, K
     keep = []

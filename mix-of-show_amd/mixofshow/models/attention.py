@@ -86,7 +86,7 @@ def _lora_site(linear):
     lora = getattr(linear, '_mos_lora', None)
     if lora is None:
         return None
-    return (lora.lora_down.weight, lora.lora_up.weight, lora._alpha_value)
+    return (lora.lora_down.weight, lora.lora_up.weight, lora.alpha_value())
 
 
 def _sites(*linears):
@@ -95,6 +95,8 @@ def _sites(*linears):
         return []
     if any(x is None for x in s):
         return None  # mixed: caller falls back to per-projection calls
+    if len(s) > 1 and sum(x[0].shape[0] for x in s) > F_hip.MAX_PACKED_RANK:
+        return None  # ranks do not fit one packed rank-16 operand together: one GEMM per projection instead
     return s
 
 
@@ -165,6 +167,12 @@ def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_i
 def _check_plain(attn):
     assert attn.spatial_norm is None and attn.group_norm is None and not attn.norm_cross, \
         'spatial_norm / group_norm / norm_cross are not part of the SD-1.5 transformer blocks'
+    if attn.upcast_attention or attn.upcast_softmax:
+        # the reference honours these flags (pipeline_regionally_t2iadapter.py:63-73); the fused kernels always keep
+        # scores / softmax statistics in fp32 registers and round P once to the half MFMA operand, which is neither
+        # the un-upcast nor the upcast torch arithmetic bit for bit — refuse rather than silently ignore the request
+        raise NotImplementedError('upcast_attention / upcast_softmax are not selectable on the fused HIP attention '
+                                  '(scores and softmax are always accumulated in fp32); SD-1.5 sets neither')
 
 
 class MosAttnProcessor:

@@ -174,7 +174,10 @@ class LoRALinearLayer(nn.Module):
             self.lora_down = nn.Linear(cin, rank, bias=False)
             self.lora_up = nn.Linear(rank, cout, bias=False)
         self.register_buffer('alpha', torch.tensor(alpha))
-        self._alpha_value = float(alpha)  # host copy: reading the buffer would be a device sync per call
+        # host copy of the buffer (reading it per call would be a device sync); refreshed whenever the buffer object
+        # or its version changes (load_state_dict / .to() / in-place writes), see alpha_value()
+        self._alpha_value = float(alpha)
+        self._alpha_tag = None
         nn.init.kaiming_uniform_(self.lora_down.weight, a=math.sqrt(5))
         nn.init.zeros_(self.lora_up.weight)
         # keep a handle on the wrapped module without registering it as a child (no state-dict keys, no cycle
@@ -185,6 +188,16 @@ class LoRALinearLayer(nn.Module):
         object.__setattr__(original_module, '_mos_lora', self)
         original_module.forward = self.forward
 
+    def alpha_value(self):
+        """Host value of the `alpha` buffer; one device read after each change of the buffer, none in steady state."""
+        a = self.alpha
+        tag = (a.data_ptr(), a._version)
+        if tag != self._alpha_tag:
+            if self._alpha_tag is not None or a.device.type != 'cpu':
+                self._alpha_value = float(a.item())
+            self._alpha_tag = tag
+        return self._alpha_value
+
     def forward(self, hidden_states):
         mod = self._wrapped
         cd = F_hip.compute_dtype_for(hidden_states)
@@ -192,7 +205,7 @@ class LoRALinearLayer(nn.Module):
         need_wt = torch.is_grad_enabled()
         W16, Wt16 = self._cache.weight('w', [mod.weight], cd, transposed=need_wt)
         b32 = self._cache.bias('w', [mod.bias])
-        site = [(self.lora_down.weight, self.lora_up.weight, self._alpha_value)]
+        site = [(self.lora_down.weight, self.lora_up.weight, self.alpha_value())]
         if self.is_conv:
             b, c, h, w = hidden_states.shape
             x = hidden_states.permute(0, 2, 3, 1).reshape(b * h * w, c)

@@ -38,6 +38,10 @@ class RegionT2I_AttnProcessor:
         self._kv_key = None
         self._kv = None
 
+    def reset_cache(self):
+        self._kv_key = None
+        self._kv = None
+
     def _layer_states(self, states):
         return states[:, self.cross_attention_idx] if states.dim() == 4 else states
 
@@ -272,6 +276,12 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
         if adapter_states is not None and do_cfg:
             adapter_states = [torch.cat([s] * 2, dim=0) if s.shape[0] == batch_size else s for s in adapter_states]
         cak = {'region_list': region_list, 'height': height, 'width': width}
+        # the per-layer source K/V caches are keyed on tensor identity (address / version / shape); a new call with new
+        # prompts can re-use the very same addresses (caching allocator), so every call starts with empty caches
+        for m in self.unet.modules():
+            proc = getattr(m, 'processor', None)
+            if isinstance(proc, RegionT2I_AttnProcessor):
+                proc.reset_cache()
 
         def unet_call(x, t):
             residuals = [s.clone() for s in adapter_states] if adapter_states is not None else None

@@ -236,14 +236,21 @@ class EDLoRATrainer(nn.Module):
         loss = ((loss * loss_mask).sum([1, 2, 3]) / loss_mask.sum([1, 2, 3])).mean()
 
         if self.attn_reg_weight is not None:
-            attention_loss = self.cal_attn_reg(self.controller.get_average_attention(), masks)
-            loss = loss + torch.where(torch.isnan(attention_loss), torch.zeros_like(attention_loss), attention_loss)
+            # reference :257 skips the regulariser when it is NaN (full mask: no pixel outside). Here the masked means
+            # are NaN-free on BOTH passes (clamped denominators) and the whole term is multiplied by a device flag, so
+            # the step stays sync-free / graph-capturable and the MSE gradient survives a full mask.
+            attention_loss, valid = self.cal_attn_reg(self.controller.get_average_attention(), masks, return_valid=True)
+            loss = loss + attention_loss * valid.to(attention_loss.dtype)
             self.controller.reset()
         return loss
 
-    def cal_attn_reg(self, attention_maps, masks, text_input_ids=None):
+    def cal_attn_reg(self, attention_maps, masks, text_input_ids=None, return_valid=False):
         """reference :263-313 on column-sliced maps: attention_maps[place] = [(B, H, N, T), ...]; column 0 is the
-        adjective token (penalised outside the mask), column 1 the subject token (aligned with the mask)."""
+        adjective token (penalised outside the mask), column 1 the subject token (aligned with the mask).
+
+        The reference's boolean-mask means are NaN when no pixel of a resolution lies outside the mask. With
+        `return_valid` the function returns (finite total, valid flag) — `valid` False exactly where the reference
+        value is NaN; without it the reference value itself (NaN included) is returned."""
         groups = {}
         for maps in attention_maps.values():
             for m in maps:
@@ -251,6 +258,7 @@ class EDLoRATrainer(nn.Module):
                 res = int(math.sqrt(N))
                 groups.setdefault(res, []).append(m.reshape(B, H, res, res, T))
         total = 0
+        valid = None
         for res in sorted(groups, reverse=True):
             cm = torch.cat(groups[res], dim=1)
             cm = cm.sum(1) / cm.shape[1]                       # mean over heads of all layers: (B, res, res, T)
@@ -260,13 +268,18 @@ class EDLoRATrainer(nn.Module):
             gt = F.interpolate(masks.float(), size=subj.shape[1:], mode='nearest').squeeze(1)
             outside = (gt == 0).to(subj.dtype)
             n_out = outside.sum()
+            ok = n_out > 0
+            valid = ok if valid is None else (valid & ok)
+            denom = n_out.clamp(min=1.0)              # 0/0 would poison the backward pass even under a `where`
             if self.reg_full_identity:
                 l_subj = F.mse_loss(subj.float(), gt.float(), reduction='mean')
             else:
-                l_subj = (subj * outside).sum() / n_out
-            l_adj = (adj * outside).sum() / n_out
+                l_subj = (subj * outside).sum() / denom
+            l_adj = (adj * outside).sum() / denom
             total = total + self.attn_reg_weight * (l_subj + l_adj)
-        return total
+        if return_valid:
+            return total, valid
+        return torch.where(valid, total, torch.full_like(total, float('nan')))
 
     # ------------------------------------------------------------------------------------------
     def delta_state_dict(self):

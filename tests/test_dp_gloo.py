@@ -63,7 +63,7 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_allreduce_matches_single_process_average(tmp_path):
+def test_two_rank_allreduce_matches_single_process_average(tmp_path, emulated_hip):
     world, port = 2, 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0 = torch.load(tmp_path / 'rank0.pt')
@@ -75,8 +75,8 @@ def test_two_rank_allreduce_matches_single_process_average(tmp_path):
     torch.testing.assert_close(r0['reduced'], (r0['local'] + r1['local']) / 2, rtol=0, atol=1e-9)
     torch.testing.assert_close(r0['params'], r1['params'], rtol=0, atol=0)    # lock-step after AdamW
     assert abs(r0['loss'] - r1['loss']) < 1e-12                               # reduce_loss_dict averaged
-    # single-process reference: same two batches, gradients averaged by hand
-    _setup_emulation()
+    # single-process reference: same two batches, gradients averaged by hand (emulation through the fixture, so
+    # the patch does not leak into later tests of this process)
     tr, engine = _make_engine()
     grads = []
     for rank in range(world):

@@ -190,6 +190,20 @@ def test_attn_reg_full_mask_nan_guard(emulated_hip):
     b['masks'] = torch.ones_like(b['masks'])          # no pixel outside the mask -> regulariser is NaN -> skipped
     loss = tr(**b)
     assert torch.isfinite(loss)
+    loss.backward()
+    grads = [p.grad.clone() for p in tr.trainable_parameters()]
+    assert all(torch.isfinite(g).all() for g in grads), 'the skipped regulariser must not poison the backward pass'
+    # reference :257: the MSE gradient is still applied -> gradients equal those of a trainer without the regulariser
+    tr2 = _trainer(attn_reg_weight=None)
+    loss2 = tr2(**b)
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) < 1e-6
+    for g, p2 in zip(grads, tr2.trainable_parameters()):
+        torch.testing.assert_close(g, p2.grad, rtol=1e-5, atol=1e-8)
+    # the reference-valued form (no return_valid) still reports NaN for a full mask
+    tr(**{**b, 'masks': b['masks']})
+    v = tr.cal_attn_reg({'x': [torch.rand(2, 2, 16, 2)]}, torch.ones(2, 1, 8, 8))
+    assert torch.isnan(v)
 
 
 def test_concept_rows_equal_full_table_adamw():
@@ -449,11 +463,15 @@ def test_lora_dataset_from_image_folders(tmp_path):
         assert it['masks'][0, 4, 4] == 1 and it['masks'][0, 0, 0] == 0                   # centred box survives the crop
         seen.add(it['prompts'])
     assert seen == {'a <potter1> <potter2> number 0', 'a <potter1> <potter2> number 1'}  # replaced, spaces squeezed
-    # without captions / masks: the instance prompt and all-ones masks
+    # without captions / masks: the instance prompt, and NO 'masks' key (reference lora_dataset.py:90-94: the loop
+    # falls back to img_masks)
     plain = LoraDataset(dict(opt, use_caption=False, use_mask=False))
-    assert plain[0]['prompts'] == '<potter1> <potter2>' and plain[0]['masks'].min() == 1
-    # a missing concept list falls back to the synthetic dataset (what bench.py and the shipped recipe use)
-    assert isinstance(build_train_dataset(dict(opt, concept_list=str(tmp_path / 'nope.json'))), SyntheticLoraDataset)
+    assert plain[0]['prompts'] == '<potter1> <potter2>' and 'masks' not in plain[0]
+    # a missing concept list is an error (a typo must not silently train on noise); synthetic data is opt-in by name
+    with pytest.raises(FileNotFoundError):
+        build_train_dataset(dict(opt, concept_list=str(tmp_path / 'nope.json')))
+    assert isinstance(build_train_dataset(dict(opt, concept_list='synthetic://potter')), SyntheticLoraDataset)
+    assert isinstance(build_train_dataset(dict(opt, name='SyntheticLoraDataset')), SyntheticLoraDataset)
 
 
 def test_plain_lora_mode_train_convert_sample(emulated_hip):
@@ -535,3 +553,59 @@ def test_region_processor_random_boxes_vs_oracle(emulated_hip):
                                        region_list=[(r[0].half(), r[1]) for r in regions], height=H, width=W)
         y_ref = ref_proc(ref, hs, encoder_hidden_states=ctx, **kw)
         torch.testing.assert_close(y.float(), y_ref, rtol=3e-2, atol=5e-3, msg=lambda m: f'trial {trial}: {m}')
+
+
+# ---- packed-rank limit, alpha buffer, upcast flags --------------------------------------------------
+@pytest.mark.parametrize('rank,cross', [(8, None), (8, 48), (16, None)])
+def test_lora_ranks_above_the_packed_limit_fall_back_to_per_projection(emulated_hip, rank, cross):
+    """3 sites x rank 8 (or 16) do not fit ONE rank-16 operand: the layer must run one GEMM per projection and still
+    match the reference LoRA layer; a single site above rank 16 raises a clear error (not an assert)."""
+    from mixofshow.models.edlora import EDLoRA_AttnProcessor, LoRALinearLayer
+    prod, ref = _mk_layers(cross)
+    torch.manual_seed(4)
+    for name in ('to_q', 'to_k', 'to_v', 'to_out.0'):
+        pm = prod.to_out[0] if name == 'to_out.0' else getattr(prod, name)
+        rm = ref.to_out[0] if name == 'to_out.0' else getattr(ref, name)
+        a = LoRALinearLayer(name, pm, rank=rank, alpha=0.7)
+        b = R.LoRALinearLayerRef(name, rm, rank=rank, alpha=0.7)
+        with torch.no_grad():
+            a.lora_up.weight.copy_((torch.randn_like(a.lora_up.weight) * 0.05).half().float())
+            a.lora_down.weight.copy_(a.lora_down.weight.half().float())
+            b.lora_up.weight.copy_(a.lora_up.weight)
+            b.lora_down.weight.copy_(a.lora_down.weight)
+    prod.set_processor(EDLoRA_AttnProcessor(1))
+    ref.set_processor(R.EDLoRA_AttnProcessorRef(1))
+    x = torch.randn(2, 64, 64).half()
+    ehs = torch.randn(2, 4, 77, 48).half() if cross else None
+    yp = prod(x, encoder_hidden_states=ehs)
+    yr = ref(x.float(), encoder_hidden_states=ehs.float() if cross else None)
+    torch.testing.assert_close(yp.float(), yr, rtol=2e-2, atol=3e-3)
+
+
+def test_lora_rank_above_16_is_a_clear_error():
+    import mixofshow.hip.ops as ops                      # the REAL lora_pack holds the check (no kernel is reached)
+    with pytest.raises(ValueError, match='rank 32 is not supported'):
+        ops.lora_pack([torch.zeros(32, 64)], [torch.zeros(64, 32)], [1.0], 64, torch.float16, torch.device('cpu'))
+
+
+def test_alpha_buffer_reload_is_honoured(emulated_hip):
+    from mixofshow.models.edlora import LoRALinearLayer
+    lin = torch.nn.Linear(32, 32, bias=False)
+    lora = LoRALinearLayer('x', lin, rank=4, alpha=1.0)
+    with torch.no_grad():
+        lora.lora_up.weight.normal_(0, 0.1)
+    x = torch.randn(3, 32).half()
+    y1 = lin(x).float()
+    sd = lora.state_dict()
+    sd['alpha'] = torch.tensor(0.25)
+    lora.load_state_dict(sd)
+    y2 = lin(x).float()
+    base = x.float() @ lin.weight.half().float().t()
+    torch.testing.assert_close(y2 - base, 0.25 * (y1 - base), rtol=5e-2, atol=2e-3)
+
+
+def test_upcast_flags_raise_on_the_fused_path(emulated_hip):
+    from mixofshow.models.attention import Attention
+    a = Attention(64, heads=8, dim_head=8, upcast_softmax=True)
+    with pytest.raises(NotImplementedError, match='upcast'):
+        a(torch.randn(1, 16, 64).half())

@@ -110,3 +110,39 @@ def test_regional_pipeline_with_t2i_adapters(emulated_hip):
     # precomputed adapter features take the same path
     kp = pipe._adapter_states(pipe.keypose_adapter, [pose], 1.0, '', H, W)
     torch.testing.assert_close(run(adapter_states=kp), only_pose, rtol=1e-5, atol=1e-5)
+
+
+def test_region_kv_cache_is_dropped_at_every_call(emulated_hip):
+    """the per-layer source K/V cache is keyed on tensor identity; a second call with other prompts may get
+    the same addresses from the caching allocator. Every pipeline call must start with empty caches: poison them with
+    a wrong entry under a key that WOULD match and check the result is unaffected."""
+    from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionT2I_AttnProcessor, RegionallyT2IAdapterPipeline
+    H, W = 64, 64
+    pipe = RegionallyT2IAdapterPipeline.from_pretrained('synthetic://tiny?seed=0', torch_dtype=torch.float32)
+    pipe.set_new_concept_cfg(_concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>']))
+    latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(3))
+
+    def run(text):
+        prompt = [('two people', [(text, '', [0.0, 0.0, 1.0, 0.6])])]
+        return pipe(prompt=prompt, negative_prompt=[''], height=H, width=W, num_inference_steps=2, guidance_scale=7.5,
+                    latents=latents.clone(), output_type='latent').images
+
+    a = run('a <potter1> <potter2>')
+    procs = [m.processor for m in pipe.unet.modules() if isinstance(getattr(m, 'processor', None), RegionT2I_AttnProcessor)]
+    cached = [p for p in procs if p._kv is not None]
+    assert cached, 'cross-attention layers cache their source K/V during a call'
+
+    class _AlwaysEqual(tuple):
+        def __eq__(self, other):
+            return True
+
+        def __ne__(self, other):
+            return False
+
+        __hash__ = tuple.__hash__
+
+    for p in cached:                                  # stale entry whose key matches anything
+        p._kv = torch.zeros_like(p._kv)
+        p._kv_key = _AlwaysEqual()
+    b = run('a <potter1> <potter2>')
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
