@@ -120,9 +120,11 @@ class DiagonalGaussianDistribution:
         self.logvar = logvar.clamp(-30.0, 20.0)
         self.std = torch.exp(0.5 * self.logvar)
 
-    def sample(self, generator=None):
-        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
-        return self.mean + self.std * noise
+    def sample(self, generator=None, noise=None):
+        """`noise`: pre-drawn standard-normal tensor (device-independent randomness for parity tests / multi-rank runs)."""
+        if noise is None:
+            noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * noise.to(self.mean)
 
     def mode(self):
         return self.mean

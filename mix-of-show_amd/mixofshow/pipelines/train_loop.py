@@ -79,7 +79,7 @@ class TrainEngine:
         tr = self.trainer
         dev = tr.concept_embedding.device
         st = {}
-        for k in ('images', 'masks', 'img_masks', 'noise', 'timesteps', 'latents'):
+        for k in ('images', 'masks', 'img_masks', 'noise', 'timesteps', 'latents', 'latent_noise'):
             v = example_batch.get(k)
             if torch.is_tensor(v):
                 v = v.to(dev)
@@ -98,6 +98,7 @@ class TrainEngine:
             with torch.autocast(dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                 loss = tr(st.get('images'), None, st.get('masks', st['img_masks']), st['img_masks'],
                           noise=st.get('noise'), timesteps=st.get('timesteps'), latents=st.get('latents'),
+                          latent_noise=st.get('latent_noise'),
                           text_input_ids=st['ids'], token_positions=st['pos'])
             self.scaler.scale(loss).backward()
             return loss.detach()
@@ -115,7 +116,7 @@ class TrainEngine:
 
     def _graph_step(self, batch):
         tr, st = self.trainer, self._static
-        for k in ('images', 'masks', 'img_masks', 'noise', 'timesteps', 'latents'):
+        for k in ('images', 'masks', 'img_masks', 'noise', 'timesteps', 'latents', 'latent_noise'):
             if k in st and torch.is_tensor(batch.get(k)):
                 v = batch[k]
                 # an async copy out of pageable host memory may run after the host tensor is gone: only device or
@@ -149,7 +150,7 @@ class TrainEngine:
         if self._micro == 0:
             self.bucket.zero()
         masks = batch['masks'] if 'masks' in batch else batch['img_masks']
-        extra = {k: batch[k] for k in ('noise', 'timesteps', 'latents') if k in batch}
+        extra = {k: batch[k] for k in ('noise', 'timesteps', 'latents', 'latent_noise') if k in batch}
         dev_type = tr.concept_embedding.device.type
         images = batch['images']
         if self.channels_last and images is not None:

@@ -10,7 +10,7 @@ What is done differently (results equivalent):
   * attention regulariser: the controller receives the probabilities of the concept-token columns only
     ((B,H,N,T) per layer, produced inside the cross-attention kernel) instead of sixteen (B*H,N,77) maps;
     boolean-mask means are written as masked sums (no device->host sync); the NaN guard of :257 is a `where`.
-  * `forward` accepts optional pre-drawn `noise` / `timesteps` / `latents` so that parity tests and multi-rank
+  * `forward` accepts optional pre-drawn `noise` / `timesteps` / `latents` / `latent_noise` (the VAE posterior sample) so that parity tests and multi-rank
     runs can use device-independent (CPU-generated) randomness.
 """
 import itertools
@@ -198,11 +198,11 @@ class EDLoRATrainer(nn.Module):
         return ids, pos
 
     def forward(self, images, prompts, masks, img_masks, noise=None, timesteps=None, latents=None,
-                text_input_ids=None, token_positions=None):
+                text_input_ids=None, token_positions=None, latent_noise=None):
         """`text_input_ids` / `token_positions` (device tensors from `tokenize`) bypass the host tokeniser: this is
         what makes the step capturable in a hipGraph (TrainEngine.enable_graph)."""
         if latents is None:
-            latents = self.vae.encode(images).latent_dist.sample() * 0.18215
+            latents = self.vae.encode(images).latent_dist.sample(noise=latent_noise) * 0.18215
         bsz = latents.shape[0]
         if noise is None:
             noise = torch.randn_like(latents)

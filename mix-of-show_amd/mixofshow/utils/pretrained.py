@@ -114,10 +114,69 @@ def _seeded(seed, fn):
         return fn()
 
 
+@torch.no_grad()
+def calibrate_synthetic_unet(unet, branch_gain=0.35, out_gain=0.5, qk_gain=3.0, attn_out_gain=1.0):
+    """Make a random-init UNet behave like a trained epsilon-predictor as far as SCALES go (synthetic
+    weights "scaled so activations stay O(1)"), so that 50 sampler steps are a contraction instead of a chaotic
+    amplifier (an untrained net predicts eps ~ 0 and DPM-Solver then multiplies the latent by 1/alpha_T ~ 15):
+
+      * every residual branch ends in a down-scaled layer (ResnetBlock2D.conv2, Attention.to_out[0], FeedForward.net[2],
+        Transformer2DModel.proj_out x `branch_gain`, zero bias) — original LDM zero-initialises exactly these;
+      * an identity path carries the input latent to the output: conv_in writes +-x_c into channels 2c / 2c+1, the
+        outermost skip connection hands them to the last up-block ResNet whose 1x1 shortcut copies them, and conv_out
+        reads SiLU(u) - SiLU(-u) = u back, so eps_hat = x / rms(x) + (everything else) * `out_gain`: at high noise that
+        IS the noise, and the sampler's x0-prediction stays O(1) for every t.
+
+    All attention / LoRA / text paths still feed eps_hat through the second term; tests report the sensitivity."""
+    from mixofshow.models.unet_2d_condition import FeedForward, ResnetBlock2D, Transformer2DModel
+    from mixofshow.models.attention import Attention
+    for m in unet.modules():
+        outs = []
+        if isinstance(m, ResnetBlock2D):
+            outs.append(m.conv2)
+        elif isinstance(m, Attention):
+            # default init gives attention logits of std ~0.3 (softmax ~ uniform: the layer degenerates to a mean of V
+            # and its output hardly depends on the scores); trained SD-1.5 logits are several units wide
+            m.to_q.weight.mul_(qk_gain)
+            m.to_k.weight.mul_(qk_gain)
+            m.to_out[0].weight.mul_(attn_out_gain / branch_gain)
+            outs.append(m.to_out[0])
+        elif isinstance(m, FeedForward):
+            outs.append(m.net[2])
+        elif isinstance(m, Transformer2DModel):
+            outs.append(m.proj_out)
+        for layer in outs:
+            layer.weight.mul_(branch_gain)
+            if layer.bias is not None:
+                layer.bias.zero_()
+    cin = unet.conv_in.weight.shape[1]
+    n_id = 2 * cin
+    last = unet.up_blocks[-1].resnets[-1]
+    c0 = unet.conv_in.weight.shape[0]
+    assert last.conv_shortcut is not None and last.conv_shortcut.weight.shape[1] == 2 * c0 and n_id <= c0
+    unet.conv_in.weight[:n_id].zero_()
+    unet.conv_in.bias[:n_id].zero_()
+    last.conv_shortcut.weight[:n_id].zero_()
+    last.conv_shortcut.bias[:n_id].zero_()
+    unet.conv_out.weight.mul_(out_gain)
+    unet.conv_out.bias.zero_()
+    unet.conv_out.weight[:, :n_id].zero_()
+    kh = unet.conv_in.weight.shape[2] // 2
+    for c in range(cin):
+        unet.conv_in.weight[2 * c, c, kh, kh] = 1.0
+        unet.conv_in.weight[2 * c + 1, c, kh, kh] = -1.0
+        last.conv_shortcut.weight[2 * c, c0 + 2 * c, 0, 0] = 1.0          # skip half of cat([x, skip]) = [c0, 2 c0)
+        last.conv_shortcut.weight[2 * c + 1, c0 + 2 * c + 1, 0, 0] = 1.0
+        if c < unet.conv_out.weight.shape[0]:
+            unet.conv_out.weight[c, 2 * c, kh, kh] = 1.0
+            unet.conv_out.weight[c, 2 * c + 1, kh, kh] = -1.0
+    return unet
+
+
 def load_unet(path):
     preset, seed = parse_synthetic(path)
     if preset is not None:
-        return _seeded(seed, lambda: UNet2DConditionModel(**PRESETS[preset]['unet']))
+        return _seeded(seed, lambda: calibrate_synthetic_unet(UNet2DConditionModel(**PRESETS[preset]['unet'])))
     folder = os.path.join(path, 'unet')
     m = UNet2DConditionModel(**_model_kwargs(folder, UNet2DConditionModel))
     m.load_state_dict(_load_state(folder))

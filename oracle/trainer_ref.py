@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from oracle import edlora_ref as R
 
 
-def make_reference_twin(trainer, device='cpu', dtype=torch.float32):
+def make_reference_twin(trainer, device='cpu', dtype=torch.float32, round_frozen_to=None):
     """Rebuild the trainer's modules from the same (synthetic, seeded or on-disk) weights, copy its trainable
     state, and put the ORACLE attention path on them. Returns a dict of modules + metadata."""
     import mos_path  # noqa: F401
@@ -24,6 +24,15 @@ def make_reference_twin(trainer, device='cpu', dtype=torch.float32):
     vae = pretrained.load_vae(src).to(device, dtype)
     for p in list(unet.parameters()) + list(te.parameters()) + list(vae.parameters()):
         p.requires_grad_(False)
+    if round_frozen_to is not None:
+        # fp16-emulating mode: autocast rounds the frozen Linear/Conv weights and biases to half at every
+        # use; the twin keeps fp32 arithmetic but sees the same weight VALUES
+        for root in (unet, te, vae):
+            for m in root.modules():
+                if isinstance(m, (torch.nn.Linear, torch.nn.Conv2d)):
+                    for p in (m.weight, m.bias):
+                        if p is not None:
+                            p.data = p.data.to(round_frozen_to).to(dtype)
     te.resize_token_embeddings(len(trainer.tokenizer))
     concept = torch.nn.Parameter(trainer.concept_embedding.detach().to(device, dtype).clone())
     emb = te.text_model.embeddings
@@ -52,11 +61,12 @@ def make_reference_twin(trainer, device='cpu', dtype=torch.float32):
                 store=store, trainer=trainer)
 
 
-def reference_forward(twin, images, prompts, masks, img_masks, noise=None, timesteps=None, latents=None):
+def reference_forward(twin, images, prompts, masks, img_masks, noise=None, timesteps=None, latents=None,
+                      latent_noise=None):
     """trainer_edlora.py:202-261."""
     tr = twin['trainer']
     if latents is None:
-        latents = twin['vae'].encode(images).latent_dist.sample() * 0.18215
+        latents = twin['vae'].encode(images).latent_dist.sample(noise=latent_noise) * 0.18215
     bsz = latents.shape[0]
     if noise is None:
         noise = torch.randn_like(latents)

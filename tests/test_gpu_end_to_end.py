@@ -3,8 +3,14 @@ processors (plain torch restatement of the reference: baddbmm / softmax / bmm, p
 3-GEMM LoRA) on identical weights, seeds and CPU-generated latents. Non-attention operators are shared, as
 BASELINE.json's north_star prescribes, so the difference isolates the hot path.
 
-Tolerance: BASELINE.json states 1e-3 on denoised latents (fp16). Latents are O(1); we check max-abs error after the
-full 50-step loop against 1e-3 * max(1, |latents|_max) for the fp16 pipelines.
+Tolerance (BASELINE.json north_star): 1e-3 on denoised latents, fp16. It is checked TEACHER-FORCED on the BASELINE
+configs (`synthetic://sd15`, all four UNet levels, d = 40 / 80 / 160): the oracle path runs the 50-step loop once and
+records the latent it fed to the UNet at every step; the HIP path is given the same latent at every step and must
+reproduce (a) the UNet's raw epsilon (both CFG halves) and (b) the latent after the scheduler update within
+1e-3 * max(1, |.|max), per step. The free-running 50-step difference is printed as a report (and loosely bounded:
+a wrong kernel changes the image, not the 3rd digit). The synthetic weights are calibrated (mixofshow.utils.pretrained.
+calibrate_synthetic_unet) so that latents stay O(1) over the 50 steps; the tests also print how strongly epsilon
+depends on the attention path (removing attention / scaling the logits by 5 %), i.e. what a 1e-3 bound can detect.
 """
 import copy
 import json
@@ -16,6 +22,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = 'cuda'
+TOL = 1e-3          # BASELINE.json north_star: fp16 tolerance on denoised latents
 
 
 def _concept_cfg(tokenizer, text_encoder, names):
@@ -32,15 +39,6 @@ def _concept_cfg(tokenizer, text_encoder, names):
     return cfg
 
 
-def _latent_report(name, a, b, tol_scale=1e-3):
-    a, b = a.float(), b.float()
-    err = (a - b).abs().max().item()
-    scale = max(1.0, b.abs().max().item())
-    print(f'[parity] {name}: max_abs_err={err:.3e} latents_absmax={b.abs().max().item():.3f} tol={tol_scale * scale:.3e}')
-    assert torch.isfinite(a).all()
-    assert err <= tol_scale * scale, f'{name}: {err:.3e} > {tol_scale * scale:.3e}'
-
-
 def test_graft_smoke():
     import __graft_entry__ as g
     g.smoke()
@@ -48,8 +46,7 @@ def test_graft_smoke():
 
 class _Fp32Layer:
     """Yardstick: the oracle processor evaluated in fp32 on an fp32 copy of the layer (same fp16-valued weights and
-    inputs), output rounded once — i.e. the exact attention layer. Both the HIP path and the reference's fp16 path
-    are measured against it: the HIP path must be at least as close as the reference path is."""
+    inputs), output rounded once — i.e. the exact attention layer."""
 
     def __init__(self, inner):
         self.inner = inner
@@ -67,73 +64,176 @@ class _Fp32Layer:
         return self.inner(self.copy, hidden_states.float(), encoder_hidden_states=ehs, **kw).to(hidden_states.dtype)
 
 
-def _three_way(name, run, install_ref, install_fp32):
-    out = run()
-    install_ref()
-    ref16 = run()
-    install_fp32()
-    truth = run()
-    scale = max(1.0, truth.float().abs().max().item())
-    e_hip = (out.float() - truth.float()).abs().max().item()
-    e_ref = (ref16.float() - truth.float()).abs().max().item()
-    e_pair = (out.float() - ref16.float()).abs().max().item()
-    print(f'[parity] {name}: |hip-exact|={e_hip:.3e} |ref_fp16-exact|={e_ref:.3e} |hip-ref_fp16|={e_pair:.3e} '
-          f'latents_absmax={scale:.3f} rel(hip-exact)={e_hip / scale:.3e} rel(ref-exact)={e_ref / scale:.3e}')
-    assert torch.isfinite(out).all()
-    # the HIP path must sit inside the reference path's own fp16 noise band around the exact result. With random
-    # weights the 50-step trajectory amplifies rounding chaotically: two runs of the SAME eager loop already differ by
-    # ~7e-3 * scale (library kernels with atomics), so the band is 2x the reference path's error with that floor.
-    assert e_hip <= max(2.0 * e_ref, 1e-2 * scale), f'{name}: hip error {e_hip:.3e} vs reference-path error {e_ref:.3e}'
+def _install_fp32(unet):
+    for m in unet.modules():
+        if m.__class__.__name__ == 'Attention':
+            m.set_processor(_Fp32Layer(m.processor))
 
 
-def test_edlora_pipeline_denoised_latents_vs_reference_path():
+@torch.no_grad()
+def _denoise_loop(pipe, prompt_embeds, latents0, cak=None, forced=None, steps=50, guidance_scale=7.5):
+    """The sampling loop of the reference pipelines (pipeline_edlora.py:271-301 / pipeline_regionally_t2iadapter.py:
+    548-580) written out so that every step's (input latent, raw UNet epsilon, post-scheduler latent) can be
+    recorded and the input latent can be teacher-forced. Returns a list of (x_in, eps_raw, x_out)."""
+    sched = pipe.scheduler
+    sched.set_timesteps(steps, device=latents0.device)
+    lat = latents0.to(prompt_embeds.dtype) * sched.init_noise_sigma
+    rec = []
+    for i, t in enumerate(sched.timesteps):
+        if forced is not None:
+            lat = forced[i]
+        x = sched.scale_model_input(torch.cat([lat] * 2), t)
+        eps = pipe.unet(x, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak).sample
+        u, c = eps.chunk(2)
+        new = sched.step(u + guidance_scale * (c - u), t, lat).prev_sample
+        rec.append((lat, eps, new))
+        lat = new
+    return rec
+
+
+def _absmax(t):
+    return t.float().abs().max().item()
+
+
+def _teacher_forced_report(name, rec_ref, rec_hip, rec_free, rec_exact=None):
+    worst_e = worst_x = 0.0
+    emax = xmax = 0.0
+    for i, ((x_in, e_ref, x_ref), (x_in2, e_hip, x_hip)) in enumerate(zip(rec_ref, rec_hip)):
+        assert torch.equal(x_in, x_in2)
+        se, sx = max(1.0, _absmax(e_ref)), max(1.0, _absmax(x_ref))
+        de, dx = _absmax(e_hip.float() - e_ref.float()) / se, _absmax(x_hip.float() - x_ref.float()) / sx
+        worst_e, worst_x = max(worst_e, de), max(worst_x, dx)
+        emax, xmax = max(emax, _absmax(e_ref)), max(xmax, _absmax(x_ref))
+    free = _absmax(rec_free[-1][2].float() - rec_ref[-1][2].float()) / max(1.0, _absmax(rec_ref[-1][2]))
+    msg = (f'[parity] {name} (teacher-forced, 50 steps): worst per-step |eps_hip-eps_ref|/max(1,|eps|) = {worst_e:.3e}, '
+           f'|x_hip-x_ref|/max(1,|x|) = {worst_x:.3e}; |eps|max {emax:.2f}, |x|max {xmax:.2f}; '
+           f'free-running 50-step |x_hip-x_ref|/max(1,|x|) = {free:.3e}')
+    if rec_exact is not None:
+        ee = max(_absmax(a[1].float() - b[1].float()) / max(1.0, _absmax(b[1])) for a, b in zip(rec_ref, rec_exact))
+        eh = max(_absmax(a[1].float() - b[1].float()) / max(1.0, _absmax(b[1])) for a, b in zip(rec_hip, rec_exact))
+        msg += f'; vs exact (fp32) attention: ref_fp16 {ee:.3e}, hip {eh:.3e}'
+    print(msg)
+    assert xmax <= 8.0, f'{name}: calibrated synthetic latents should stay O(1), got {xmax}'
+    assert worst_x <= TOL, f'{name}: post-scheduler latent differs by {worst_x:.3e} (teacher-forced)'
+    assert worst_e <= TOL, f'{name}: raw epsilon differs by {worst_e:.3e} (teacher-forced)'
+    assert free <= 2e-2, f'{name}: free-running latents differ by {free:.3e}'
+
+
+@torch.no_grad()
+def _sensitivity(name, pipe, prompt_embeds, x, cak=None):
+    """What the bound can see: how much epsilon moves when the attention path is removed / its logits scaled 5 %."""
+    t = torch.tensor(500, device=x.device)
+    xin = torch.cat([x] * 2)
+    base = pipe.unet(xin, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak).sample.float()
+    attns = [m for m in pipe.unet.modules() if m.__class__.__name__ == 'Attention']
+    for m in attns:
+        m.scale *= 1.05
+    scaled = pipe.unet(xin, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak).sample.float()
+    for m in attns:
+        m.scale /= 1.05
+    saved = [m.to_out[0].weight.clone() for m in attns]
+    for m in attns:
+        m.to_out[0].weight.zero_()
+    removed = pipe.unet(xin, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak).sample.float()
+    for m, w in zip(attns, saved):
+        m.to_out[0].weight.copy_(w)
+    a, b = _absmax(scaled - base), _absmax(removed - base)
+    print(f'[parity] {name}: sensitivity of epsilon to the attention path: logits x1.05 -> {a:.3e}, attention removed -> '
+          f'{b:.3e} (bound {TOL:.0e} * {max(1.0, _absmax(base)):.2f})')
+    assert b >= 50 * TOL, 'fixture too insensitive: the attention path hardly reaches epsilon'
+    return a, b
+
+
+def test_edlora_sd15_teacher_forced_per_step_latents():
+    """BASELINE configs: SD-1.5 architecture, 512x512, 50 DPM-Solver++ steps, CFG 7.5, ED-LoRA layer-wise prompts
+    (reference pipeline_edlora.py:271-301)."""
+    from mixofshow.models.edlora import revise_edlora_unet_attention_forward
     from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline
     from oracle import edlora_ref as R
-    pipe = EDLoRAPipeline.from_pretrained('synthetic://small?seed=0', torch_dtype=torch.float16).to(DEV)
+    pipe = EDLoRAPipeline.from_pretrained('synthetic://sd15?seed=0', torch_dtype=torch.float16).to(DEV)
     cfg = _concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>'])
     pipe.set_new_concept_cfg(cfg)
-    latents = torch.randn((1, 4, 64, 64), generator=torch.manual_seed(1))     # PromptDataset recipe, index 1
-    kw = dict(prompt='a <potter1> <potter2> in the park', height=512, width=512, num_inference_steps=50,
-              guidance_scale=7.5, output_type='latent')
+    emb = pipe._encode_prompt('a <potter1> <potter2> in the park', cfg, DEV, 1, True, None)
+    latents = torch.randn((1, 4, 64, 64), generator=torch.manual_seed(1)).to(DEV)     # PromptDataset recipe, index 1
+    hip_procs = {n: m.processor for n, m in pipe.unet.named_modules() if m.__class__.__name__ == 'Attention'}
+    rec_free = _denoise_loop(pipe, emb, latents)
+    _sensitivity('edlora sd15 512x512', pipe, emb, latents.half())
+    for m in pipe.unet.modules():
+        if m.__class__.__name__ == 'Attention':
+            m.set_processor(R.PlainAttnProcessorRef())
+    R.install_ref_processors(pipe.unet)
+    rec_ref = _denoise_loop(pipe, emb, latents)
+    forced = [r[0] for r in rec_ref]
+    _install_fp32(pipe.unet)
+    rec_exact = _denoise_loop(pipe, emb, latents, forced=forced)
+    for n, m in pipe.unet.named_modules():
+        if n in hip_procs:
+            m.set_processor(hip_procs[n])
+    rec_hip = _denoise_loop(pipe, emb, latents, forced=forced)
+    _teacher_forced_report('edlora sd15 512x512', rec_ref, rec_hip, rec_free, rec_exact)
 
-    def install_ref():
-        for m in pipe.unet.modules():
-            if m.__class__.__name__ == 'Attention':
-                m.set_processor(R.PlainAttnProcessorRef())
-        R.install_ref_processors(pipe.unet)
 
-    def install_fp32():
-        for m in pipe.unet.modules():
-            if m.__class__.__name__ == 'Attention':
-                m.set_processor(_Fp32Layer(m.processor))
-
-    _three_way('edlora_sample_50steps', lambda: pipe(latents=latents.clone(), **kw).images, install_ref, install_fp32)
-
-
-def test_regional_pipeline_denoised_latents_vs_reference_path():
+def _regional_setup(preset):
     from bench import regional_prompt
     from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionallyT2IAdapterPipeline
-    from oracle import region_ref
     H, W = 512, 768
-    pipe = RegionallyT2IAdapterPipeline.from_pretrained('synthetic://small?seed=0', torch_dtype=torch.float16).to(DEV)
+    pipe = RegionallyT2IAdapterPipeline.from_pretrained(f'synthetic://{preset}?seed=0', torch_dtype=torch.float16).to(DEV)
     cfg = _concept_cfg(pipe.tokenizer, pipe.text_encoder,
                        ['<potter1>', '<potter2>', '<hermione1>', '<hermione2>', '<thanos1>', '<thanos2>'])
     pipe.set_new_concept_cfg(cfg)
-    latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14))
+    prompt, neg = regional_prompt(H, W)
+    prompt[0][1].append(('a castle', neg, [100 / H, 150 / W, 400 / H, 300 / W]))   # overlaps regions 1 and 2
+    emb, region_list = pipe._encode_region_prompt(prompt, cfg, DEV, 1, True, [neg], height=H, width=W)
+    cak = {'region_list': region_list, 'height': H, 'width': W}
+    latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14)).to(DEV)
+    return pipe, emb, cak, latents
 
-    def run():
-        prompt, neg = regional_prompt(H, W)
-        # an overlapping 4th region exercises the count normalisation
-        prompt[0][1].append(('a castle', neg, [100 / H, 150 / W, 400 / H, 300 / W]))
-        return pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50, guidance_scale=7.5,
-                    latents=latents.clone(), output_type='latent').images
 
-    def install_fp32():
-        for m in pipe.unet.modules():
-            if m.__class__.__name__ == 'Attention':
-                m.set_processor(_Fp32Layer(m.processor))
+def test_regional_sd15_teacher_forced_per_step_latents():
+    """BASELINE configs[4]: 3 regions (+1 overlapping) at 512x768, 50 steps, CFG pair per call
+    (reference pipeline_regionally_t2iadapter.py:548-580)."""
+    from oracle import region_ref
+    pipe, emb, cak, latents = _regional_setup('sd15')
+    hip_procs = {n: m.processor for n, m in pipe.unet.named_modules() if m.__class__.__name__ == 'Attention'}
+    rec_free = _denoise_loop(pipe, emb, latents, cak=cak)
+    _sensitivity('regional sd15 512x768', pipe, emb, latents.half(), cak=cak)
+    region_ref.install_region_processors_ref(pipe.unet)
+    rec_ref = _denoise_loop(pipe, emb, latents, cak=cak)
+    forced = [r[0] for r in rec_ref]
+    _install_fp32(pipe.unet)
+    rec_exact = _denoise_loop(pipe, emb, latents, cak=cak, forced=forced)
+    for n, m in pipe.unet.named_modules():
+        if n in hip_procs:
+            m.set_processor(hip_procs[n])
+            m.processor.reset_cache()
+    rec_hip = _denoise_loop(pipe, emb, latents, cak=cak, forced=forced)
+    _teacher_forced_report('regional sd15 512x768', rec_ref, rec_hip, rec_free, rec_exact)
 
-    _three_way('regional_sample_50steps', run, lambda: region_ref.install_region_processors_ref(pipe.unet), install_fp32)
+
+def test_pipeline_call_equals_written_out_loop():
+    """The product's own `pipe(...)` entry points run the loop the teacher-forced tests write out (same latents)."""
+    from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline
+    pipe = EDLoRAPipeline.from_pretrained('synthetic://small?seed=0', torch_dtype=torch.float16).to(DEV)
+    cfg = _concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>'])
+    pipe.set_new_concept_cfg(cfg)
+    latents = torch.randn((1, 4, 64, 64), generator=torch.manual_seed(1))
+    out = pipe(prompt='a <potter1> <potter2> in the park', height=512, width=512, num_inference_steps=50,
+               guidance_scale=7.5, latents=latents.clone(), output_type='latent').images
+    emb = pipe._encode_prompt('a <potter1> <potter2> in the park', cfg, DEV, 1, True, None)
+    rec = _denoise_loop(pipe, emb, latents.to(DEV))
+    d = _absmax(out.float() - rec[-1][2].float())
+    print(f'[parity] EDLoRAPipeline.__call__ vs written-out loop: max|d| = {d:.3e}')
+    assert d <= 2e-3 * max(1.0, _absmax(out))
+    rp, emb, cak, lat = _regional_setup('small')
+    from bench import regional_prompt
+    prompt, neg = regional_prompt(512, 768)
+    prompt[0][1].append(('a castle', neg, [100 / 512, 150 / 768, 400 / 512, 300 / 768]))
+    out = rp(prompt=prompt, negative_prompt=[neg], height=512, width=768, num_inference_steps=50, guidance_scale=7.5,
+             latents=lat.clone(), output_type='latent').images
+    rec = _denoise_loop(rp, emb, lat, cak=cak)
+    d = _absmax(out.float() - rec[-1][2].float())
+    print(f'[parity] RegionallyT2IAdapterPipeline.__call__ vs written-out loop: max|d| = {d:.3e}')
+    assert d <= 2e-3 * max(1.0, _absmax(out))
 
 
 def test_hipgraph_regional_sampling_equals_eager_sampling():
@@ -154,15 +254,12 @@ def test_hipgraph_regional_sampling_equals_eager_sampling():
     r_graph = rp(latents=lat.clone(), hipgraph=True, **rkw).images
     assert rp.last_call_graphed, 'capture fell back to eager'
     d = (r_eager.float() - r_graph.float()).abs().max().item()
-    # yardstick: the eager loop's own run-to-run spread (library GEMM/conv kernels with atomics, amplified over 50
-    # steps of a random-init UNet); a replayed graph launches the same kernels on the same data
+    # a replayed graph launches the same kernels on the same data; yardstick = the eager loop's own run-to-run spread
     spread = (r_eager.float() - r_eager2.float()).abs().max().item()
     scale = max(1.0, r_eager.float().abs().max().item())
     print(f'[parity] hipgraph vs eager regional sampling: max|d|={d:.3e}, eager run-to-run max|d|={spread:.3e}, '
           f'latents absmax={scale:.2f}')
-    # both numbers are samples of the same chaotic amplification (observed 0.47 .. 0.50 on a latent range of 65); a
-    # wrong replay (stale latents / timestep) yields a different image, i.e. differences of the order of `scale`
-    assert d <= max(4.0 * spread, 2e-2 * scale)
+    assert d <= max(2.0 * spread, TOL * scale)
 
 
 def test_training_steps_match_reference_path_and_engine_runs():
@@ -213,9 +310,72 @@ def test_training_steps_match_reference_path_and_engine_runs():
     assert engine.global_step == 3 and not bool(engine.stop_flag)   # synthetic CLIP rows have real-CLIP-like norms
 
 
+def test_sd15_fp16_train_step_through_vae_vs_cpu_twin():
+    """BASELINE configs[1] itself: SD-1.5 architecture, 512x512, batch 4, fp16 autocast + GradScaler, images THROUGH the
+    VAE (posterior-sample noise injected), attention regulariser on — one forward+backward against the oracle twin
+    (fp32 activations, plain torch attention with full probability maps, 3-GEMM LoRA; frozen weights rounded to half
+    where autocast rounds them). Reference: trainer_edlora.py:202-261, train_edlora.py:113-121."""
+    import time
+    from bench import TRAIN_OPT, build_trainer, synthetic_batch
+    from mixofshow.pipelines.train_loop import TrainEngine
+    from oracle import trainer_ref
+    B, size = 4, 512
+    tr = build_trainer('sd15', torch.device(DEV))
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+            l.lora_up.weight.normal_(0, 0.02)
+    engine = TrainEngine(tr, dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g'])), total_iter=100, mixed_precision='fp16')
+    g = torch.Generator().manual_seed(3)
+    b = synthetic_batch(B, size, 'cpu', 50)
+    extra = dict(noise=torch.randn(B, 4, size // 8, size // 8, generator=g),
+                 timesteps=torch.randint(0, 1000, (B, ), generator=g),
+                 latent_noise=torch.randn(B, 4, size // 8, size // 8, generator=g))
+    dev = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in {**b, **extra}.items()}
+    params = tr.trainable_parameters()
+    scale = engine.scaler.get_scale()
+    for _ in range(6):                               # what GradScaler does on overflow: halve the scale and retry
+        engine.bucket.zero()
+        with torch.autocast('cuda', dtype=torch.float16):
+            loss = tr(dev['images'], dev['prompts'], dev['masks'], dev['img_masks'], noise=dev['noise'],
+                      timesteps=dev['timesteps'], latent_noise=dev['latent_noise'])
+        (loss * scale).backward()
+        if all(torch.isfinite(p.grad).all() for p in params):
+            break
+        scale /= 2
+    grads = [p.grad.detach().float().cpu() / scale for p in params]
+    assert all(torch.isfinite(x).all() for x in grads), 'overflow at every loss scale'
+    twin_dev = os.environ.get('MOS_TWIN_DEVICE', 'cpu')
+    t0 = time.time()
+    twin = trainer_ref.make_reference_twin(tr, device=twin_dev, dtype=torch.float32, round_frozen_to=torch.float16)
+    tb = {k: (v.to(twin_dev) if torch.is_tensor(v) else v) for k, v in {**b, **extra}.items()}
+    loss_ref = trainer_ref.reference_forward(twin, tb['images'], tb['prompts'], tb['masks'], tb['img_masks'],
+                                             noise=tb['noise'], timesteps=tb['timesteps'], latent_noise=tb['latent_noise'])
+    loss_ref.backward()
+    num = den = 0.0
+    per = []
+    for a, r in zip(grads, trainer_ref.twin_parameters(twin)):
+        rg = r.grad.detach().float().cpu()
+        num += (a - rg).pow(2).sum().item()
+        den += rg.pow(2).sum().item()
+        per.append(((a - rg).norm() / rg.norm().clamp_min(1e-30)).item())
+    rel = (num / den) ** 0.5
+    lrel = abs(loss.item() - loss_ref.item()) / abs(loss_ref.item())
+    print(f'[parity] sd15 512x512 B4 fp16 train step through the VAE: loss hip {loss.item():.6f} oracle {loss_ref.item():.6f} '
+          f'(rel {lrel:.2e}); grad rel-L2 {rel:.3e} (concept rows {per[0]:.2e}, worst tensor {max(per):.2e}); loss scale '
+          f'{scale:g}; twin on {twin_dev} took {time.time() - t0:.1f}s')
+    assert lrel <= 1e-3
+    assert rel <= 1e-2
+    # and the engine's full step (GradScaler, all-reduce of the bucket, fused AdamW, norm rule) runs on this config
+    out = engine.step({k: dev[k] for k in ('images', 'prompts', 'masks', 'img_masks', 'noise', 'timesteps', 'latent_noise')})
+    assert torch.isfinite(out['loss']) and abs(out['loss'].item() - loss.item()) <= 1e-3 * abs(loss.item())
+
+
 def test_hipgraph_step_equals_eager_step():
-    """TrainEngine.enable_graph replays the same kernels: 3 steps with given latents/noise/timesteps must give the
-    eager engine's losses and parameters (same seeds, two trainers)."""
+    """TrainEngine.enable_graph replays the same kernels. Main check, free of optimiser chaos: on identical parameters
+    the FIRST step's loss and flat gradient bucket of the graphed engine equal the eager engine's. Then 3 steps: same
+    losses, and parameters inside the eager engine's own run-to-run spread (measured with 3 eager engines; Adam's first
+    steps turn the sign of a noise-level gradient element into a full +-lr move, MIOpen's split-K backward uses atomics)."""
     from bench import TRAIN_OPT, build_trainer, synthetic_batch
     from mixofshow.pipelines.train_loop import TrainEngine
     B = 2
@@ -229,7 +389,7 @@ def test_hipgraph_step_equals_eager_step():
         b['images'] = None
         batches.append(b)
     results = []
-    for graphed in (False, False, True):
+    for graphed in (False, False, False, True):
         tr = build_trainer('small', torch.device(DEV))
         torch.manual_seed(1)
         with torch.no_grad():
@@ -240,25 +400,29 @@ def test_hipgraph_step_equals_eager_step():
         if graphed:
             engine.enable_graph(batches[0])
             assert engine._graph is not None
-        losses = [engine.step(b)['loss'].item() for b in batches]
-        results.append((losses, [p.detach().float().clone() for p in tr.trainable_parameters()]))
-    (le, pe), (le2, pe2), (lg, pg) = results
+        losses, first_grad = [], None
+        for b in batches:
+            losses.append(engine.step(b)['loss'].item())
+            if first_grad is None:
+                first_grad = engine.bucket.flat.detach().float().clone() / engine.scaler.get_scale()
+        results.append((losses, [p.detach().float().clone() for p in tr.trainable_parameters()], first_grad))
 
     def rel(pa, pb):
         num = sum((a - b).pow(2).sum().item() for a, b in zip(pa, pb))
         return (num / sum(a.pow(2).sum().item() for a in pa)) ** 0.5
 
-    # run-to-run spread of the eager step itself (MIOpen's backward-weight kernels use atomics; Adam's first steps
-    # turn a sign flip of a noise-level gradient into a full +-lr move) is the yardstick for "same kernels"
-    spread = rel(pe, pe2)
-    print(f'[parity] eager losses {le} / {le2}, graph losses {lg}; param rel diff eager-eager {spread:.3e}, '
-          f'graph-eager {rel(pe, pg):.3e}')
-    # observed on MI355X: eager-eager 1.6e-4 .. 3.3e-4, graph-eager 2.6e-4 .. 3.4e-4 (same distribution); losses of two
-    # eager runs differ by up to 6e-5 relative. A graph that replayed stale inputs or skipped work is off by orders
-    # of magnitude more (different batch => loss differs in the 2nd digit; the 3-step update itself is ~1e-3).
-    for a, b in zip(le, lg):
+    eager, (lg, pg, gg) = results[:3], results[3]
+    g_spread = max(rel([eager[i][2]], [eager[j][2]]) for i in range(3) for j in range(i))
+    g_graph = max(rel([e[2]], [gg]) for e in eager)
+    p_spread = max(rel(eager[i][1], eager[j][1]) for i in range(3) for j in range(i))
+    p_graph = max(rel(e[1], pg) for e in eager)
+    print(f'[parity] hipgraph step: first-step gradient rel diff graph-eager {g_graph:.3e} (eager-eager {g_spread:.3e}); '
+          f'losses eager {eager[0][0]} graph {lg}; params after 3 steps graph-eager {p_graph:.3e} (eager-eager {p_spread:.3e})')
+    assert torch.isfinite(gg).all() and gg.abs().sum() > 0
+    assert g_graph <= max(3.0 * g_spread, 1e-4)
+    for a, b in zip(eager[0][0], lg):
         assert abs(a - b) <= 3e-4 * abs(a)
-    assert rel(pe, pg) <= max(4.0 * spread, 6e-4)
+    assert p_graph <= max(3.0 * p_spread, 1e-6)
 
 
 def test_update_quasi_newton_vs_reference_golden(golden):
