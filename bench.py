@@ -1,24 +1,32 @@
 """bench.py — headline benchmark of the Mix-of-Show hot path on MI355X (contract: see the task prompt / DESIGN.md).
 
-Default (`--mode train`): BASELINE.json metric part 1, ED-LoRA train images/sec @512x512 on SD-1.5, workload =
-BASELINE.json configs[1] ("Single-concept ED-LoRA tune SD-1.5 512x512 rank=4 batch=4 on 1xMI355X"); with --gpus N>1
-(launched by torch.distributed.run, one rank per GPU over RCCL) the same per-GPU batch => weak scaling (configs[2]).
-A "step" is one full optimisation step: VAE encode, CLIP (16 layer-wise prompts / sample), UNet forward + backward
-through the fused HIP attention path, all-reduce of the LoRA+concept-row gradient bucket, AdamW, embedding-norm rule.
-Weights: seeded random init of the exact SD-1.5 architecture (no checkpoints offline); data: synthetic, resident in
-HBM before the timed region.
+Default (`--mode train`): BOTH halves of BASELINE.json's metric in ONE JSON line.
+  * top level = part 1, ED-LoRA train images/sec @512x512 on SD-1.5, workload = BASELINE.json configs[1] ("Single-concept
+    ED-LoRA tune SD-1.5 512x512 rank=4 batch=4 on 1xMI355X"); with --gpus N>1 (one rank per GPU over RCCL, launched by
+    torch.distributed.run — or by this script itself when WORLD_SIZE is unset) the same per-GPU batch => weak scaling
+    (configs[2]). A "step" is one full optimisation step: VAE encode, CLIP (16 layer-wise prompts / sample), UNet
+    forward + backward through the fused HIP attention path, all-reduce of the LoRA+concept-row gradient bucket, AdamW,
+    embedding-norm rule. The step runs the way the product runs it by default (train_edlora.py): forward+backward
+    replayed from a hipGraph.
+  * `regional` = part 2, 50-step 3-region sample latency at 512x768 (configs[4]), single GPU (replicas only), with its
+    own roofline and cpu_baseline. Skipped (null) for N>1 and with --no-regional.
+`--mode regional` prints part 2 alone; `--mode fusion` times configs[3] (gradient fusion of 14 synthetic ED-LoRAs).
 
-`--mode regional`: metric part 2, 50-step 3-region sample latency at 512x768 (configs[4]); a "step" is one
-complete 50-step sample (CFG pair per UNet call).
+Weights: seeded random init of the exact SD-1.5 architecture, calibrated to O(1) activations (no checkpoints offline);
+data: synthetic, resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0). `roofline` describes the library kernel with the largest share of GPU time, timed
-with HIP events on its launch stream (mos_profile_*), in a short profiled pass right after the timed region so that
-`value` is not perturbed by event recording; `cpu_baseline` times the oracle path (oracle/trainer_ref.py, plain
-torch fp32 = the "CPU diffusers reference path" stand-in) on the host cores for a bounded sample.
+`roofline` describes the library kernel with the largest share of GPU time, timed with HIP events on its launch
+stream (mos_profile_*), in a short profiled pass right after the timed region so that `value` is not perturbed by
+event recording; `attention_path` is the aggregate: SURVEY 8(d)'s algorithmic attention-path FLOPs per step over the
+summed library-kernel time. `cpu_baseline` times the oracle path (oracle/*.py, plain torch fp32 = the "CPU diffusers
+reference path" stand-in) on the host cores for a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,6 +35,10 @@ import torch
 
 PEAK_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
+# algorithmic attention-path FLOPs (QK^T, PV, q/k/v/out projections, LoRA) per trained 512x512 image
+# (fwd + bwd) and per CFG-pair UNet call at 512x768 with 3 regions
+ATTN_PATH_GFLOP_PER_TRAINED_IMAGE = 604.0
+ATTN_PATH_GFLOP_PER_REGIONAL_CALL = 829.5
 
 FINETUNE_CFG = dict(
     text_embedding=dict(enable_tuning=True, lr=1e-3),
@@ -34,7 +46,7 @@ FINETUNE_CFG = dict(
     unet=dict(enable_tuning=True, lora_cfg=dict(rank=4, alpha=1.0, where='Attention'), lr=1e-4))
 TRAIN_OPT = dict(optim_g=dict(type='AdamW', lr=0.0, weight_decay=0.01, betas=[0.9, 0.999]), emb_norm_threshold=0.55)
 
-
+ROOT = os.path.dirname(os.path.abspath(__file__))
 _T0 = time.time()
 
 
@@ -77,13 +89,30 @@ def synthetic_batch(B, size, device, seed):
                 prompts=['a <potter1> <potter2> in the park, 4K, high quality'] * B)
 
 
-def _pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE / WRITE_SIZE collected in separate rocprofv3 --pmc runs, gfx950-corrected), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+# ---- roofline helpers ---------------------------------------------------------------------------------------------
+def kernel_source_fingerprint():
+    """sha256 (16 hex) over the kernel sources + build recipe: the identity of the code the PMC passes profiled."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'mix-of-show_amd', 'csrc')
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith(('.hip', '.h', '.inc', '.sh')):
+            with open(os.path.join(d, fn), 'rb') as f:
+                h.update(fn.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_traffic(kernel_name, path=None):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json,
+    written by tools/pmc_traffic.py: FETCH_SIZE / WRITE_SIZE collected in separate passes, gfx950-corrected) — but
+    ONLY if that file was measured on the kernel sources that are in the tree now (fingerprint match); a number
+    profiled on other code is stale and reported as null."""
+    path = path or os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
-            ent = json.load(f).get(kernel_name)
+            d = json.load(f)
+        if d.get('source_sha16') != kernel_source_fingerprint():
+            return None
+        ent = d.get('kernels', {}).get(kernel_name)
         return float(ent['total']) if ent else None
     except (OSError, ValueError, KeyError, TypeError):
         return None
@@ -106,54 +135,124 @@ def roofline_from_profile(records):
                 algorithmic_flops_per_launch=top['flops'], algorithmic_bytes_per_launch=top['bytes'])
 
 
-def cpu_baseline_train(trainer, size, budget_s=60.0):
-    """Oracle path (plain torch fp32, full (B*H,N,77) maps, 3 launches per LoRA site) on the host cores, B=1."""
-    import signal
-    from oracle import trainer_ref
-    # torch's intra-op pool degrades badly when hundreds of threads fight over the many small ops of a UNet
-    # (GroupNorm, SiLU, 77-token GEMMs); 32 threads is what we use and report as `cores`.
-    threads = int(os.environ.get('MOS_CPU_BASELINE_THREADS', min(32, os.cpu_count() or 1)))
-    torch.set_num_threads(threads)
-    times = []
+def attention_path_aggregate(gflop_per_unit, units, library_ms):
+    """algorithmic attention-path FLOPs of the timed unit over the summed library-kernel time."""
+    tflop = gflop_per_unit * units / 1e3
+    achieved = tflop / max(1e-12, library_ms * 1e-3)
+    return dict(algorithmic_tflop=round(tflop, 4), library_kernel_ms=round(library_ms, 3),
+                achieved_tflops=round(achieved, 2), frac_of_mfma_peak=round(achieved / PEAK_MFMA_TFLOPS, 5))
 
-    class _Budget(Exception):
-        pass
+
+def _kernel_table(recs, per, n=14):
+    return [dict(name=r['name'], calls=r['calls'] / per, avg_us=round(r['avg_us'], 2),
+                 ms=round(r['total_ms'] / per, 3), tflops=round(r['flops'] / (r['avg_us'] * 1e-6) / 1e12, 2),
+                 gbps=round(r['bytes'] / (r['avg_us'] * 1e-6) / 1e9, 1)) for r in recs[:n]]
+
+
+# ---- CPU baselines (oracle path on the host cores; bounded samples) ------------------------------------------------
+class _Budget(Exception):
+    pass
+
+
+def _with_alarm(seconds, fn):
+    import signal
 
     def _alarm(signum, frame):
         raise _Budget()
 
     old = signal.signal(signal.SIGALRM, _alarm)
-    signal.alarm(int(os.environ.get('MOS_CPU_BASELINE_TIMEOUT', 240)))   # hard wall-clock bound for the whole leg
+    signal.alarm(int(seconds))
     try:
-        _log(f'cpu_baseline: building the oracle twin on the host ({threads} threads)')
+        return fn()
+    except _Budget:
+        _log('cpu_baseline: wall-clock bound hit')
+        return None
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+
+
+def _cpu_threads():
+    # torch's intra-op pool degrades when hundreds of threads fight over the many small ops of a UNet (GroupNorm, SiLU,
+    # 77-token GEMMs): 32 threads are used; `cores` reports the threads USED, `host_cores` what the box has.
+    threads = int(os.environ.get('MOS_CPU_BASELINE_THREADS', min(32, os.cpu_count() or 1)))
+    torch.set_num_threads(threads)
+    return threads
+
+
+def cpu_baseline_train(trainer, size, budget_s=45.0):
+    """Oracle path (plain torch fp32, full (B*H,N,77) maps, 3 launches per LoRA site) on the host cores, batch 1:
+    1 warm-up + up to 4 timed forward+backward steps, median."""
+    from oracle import trainer_ref
+    threads = _cpu_threads()
+    times = []
+
+    def run():
+        _log(f'cpu_baseline(train): building the oracle twin on the host ({threads} threads of {os.cpu_count()})')
         twin = trainer_ref.make_reference_twin(trainer, device='cpu', dtype=torch.float32)
         b = synthetic_batch(1, size, 'cpu', 123)
         params = trainer_ref.twin_parameters(twin)
         t_all = time.time()
-        for i in range(3):
+        for i in range(5):
             for p in params:
                 p.grad = None
             t0 = time.time()
             loss = trainer_ref.reference_forward(twin, b['images'], b['prompts'], b['masks'], b['img_masks'])
             loss.backward()
-            times.append(time.time() - t0)
-            _log(f'cpu_baseline: step {i} took {times[-1]:.2f}s')
-            if time.time() - t_all + times[-1] > budget_s:   # bounded sample: stop before the next step would overrun
+            dt = time.time() - t0
+            _log(f'cpu_baseline(train): step {i} took {dt:.2f}s')
+            if i > 0:
+                times.append(dt)
+            if time.time() - t_all + dt > budget_s:     # bounded sample: stop before the next step would overrun
                 break
-    except _Budget:
-        _log('cpu_baseline: wall-clock bound hit')
-    finally:
-        signal.alarm(0)
-        signal.signal(signal.SIGALRM, old)
+
+    _with_alarm(int(os.environ.get('MOS_CPU_BASELINE_TIMEOUT', 240)), run)
     if not times:
-        return dict(value=None, unit='images/s', cores=threads, kind='port',
+        return dict(value=None, unit='images/s', cores=threads, host_cores=os.cpu_count(), kind='port',
                     sample='oracle step did not finish inside the wall-clock bound')
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return dict(value=round(1.0 / best, 5), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{len(times)} forward+backward steps at batch 1, {size}x{size}, fp32 torch oracle '
-                       f'(oracle/trainer_ref.py), best of the non-first; optimiser step excluded (negligible)')
+    med = statistics.median(times)
+    return dict(value=round(1.0 / med, 5), unit='images/s', cores=threads, host_cores=os.cpu_count(), kind='port',
+                sample=f'median of {len(times)} forward+backward steps after 1 warm-up, batch 1, {size}x{size}, fp32 torch '
+                       'oracle (oracle/trainer_ref.py: full probability maps, 3-GEMM LoRA); optimiser step excluded')
 
 
+def cpu_baseline_regional(preset, H, W, budget_s=40.0):
+    """One regional UNet call (CFG pair, oracle region processors, fp32) on the host cores, extrapolated x50."""
+    from oracle import region_ref
+    threads = _cpu_threads()
+    times = []
+
+    def run():
+        pipe = build_regional_pipe(preset, torch.device('cpu'), dtype=torch.float32)
+        region_ref.install_region_processors_ref(pipe.unet)
+        prompt, neg = regional_prompt(H, W)
+        with torch.no_grad():
+            emb, region_list = pipe._encode_region_prompt(prompt, pipe.new_concept_cfg, 'cpu', 1, True, [neg], height=H,
+                                                          width=W)
+            cak = {'region_list': region_list, 'height': H, 'width': W}
+            x = torch.randn((2, 4, H // 8, W // 8), generator=torch.manual_seed(14))
+            t_all = time.time()
+            for i in range(4):
+                t0 = time.time()
+                pipe.unet(x, torch.tensor(500), encoder_hidden_states=emb, cross_attention_kwargs=cak)
+                dt = time.time() - t0
+                _log(f'cpu_baseline(regional): UNet call {i} took {dt:.2f}s')
+                if i > 0:
+                    times.append(dt)
+                if time.time() - t_all + dt > budget_s:
+                    break
+
+    _with_alarm(int(os.environ.get('MOS_CPU_BASELINE_TIMEOUT', 240)), run)
+    if not times:
+        return dict(value=None, unit='ms', cores=threads, host_cores=os.cpu_count(), kind='port',
+                    sample='oracle UNet call did not finish inside the wall-clock bound')
+    med = statistics.median(times)
+    return dict(value=round(med * 50 * 1e3, 1), unit='ms', cores=threads, host_cores=os.cpu_count(), kind='port',
+                sample=f'50 x median of {len(times)} regional UNet calls (CFG pair, {H}x{W}, 3 regions) after 1 warm-up, fp32 '
+                       'torch oracle (oracle/region_ref.py); scheduler / text encoding excluded (negligible)')
+
+
+# ---- part 1: training ----------------------------------------------------------------------------------------------
 def run_train(args, rank, world, device):
     from mixofshow.hip import profiler
     from mixofshow.pipelines.train_loop import TrainEngine
@@ -196,32 +295,34 @@ def run_train(args, rank, world, device):
             engine.step(batches[i % 2])
         torch.cuda.synchronize()
     engine._graph = saved_graph
+    lib_ms = sum(r['total_ms'] for r in recs) / 2
     result = dict(
         metric='edlora_train_images_per_sec_512_sd15', value=round(B * world * args.steps / dt, 4), unit='images/s',
         n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
         higher_is_better=True, scaling='weak', vs_baseline=None,
         dtype={'fp16': 'fp16', 'bf16': 'bf16'}.get(args.precision, 'fp16'), data='synthetic',
         config=dict(workload='BASELINE.json configs[1]: single-concept ED-LoRA tune, SD-1.5 UNet/CLIP/VAE '
-                             f'(random init), {size}x{size}, LoRA rank 4 on Attention+CLIPAttention, attn_reg on, '
-                             f'batch {B}/GPU', global_batch=B * world, per_gpu_batch=B, image_size=size,
+                             f'(random init, calibrated), {size}x{size}, LoRA rank 4 on Attention+CLIPAttention, '
+                             f'attn_reg on, batch {B}/GPU', global_batch=B * world, per_gpu_batch=B, image_size=size,
                     parallelism=f'dp{world}', grad_bucket_bytes=engine.bucket.nbytes, preset=args.preset,
-                    hipgraph=graphed),
+                    hipgraph=graphed, host_cores=os.cpu_count(), kernel_source_sha16=kernel_source_fingerprint()),
         roofline=roofline_from_profile(recs) if recs else None,
-        kernels=[dict(name=r['name'], calls_per_step=r['calls'] / 2, avg_us=round(r['avg_us'], 2),
-                      ms_per_step=round(r['total_ms'] / 2, 3),
-                      tflops=round(r['flops'] / (r['avg_us'] * 1e-6) / 1e12, 2)) for r in recs[:12]],
-        library_kernel_ms_per_step=round(sum(r['total_ms'] for r in recs) / 2, 3))
+        attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_TRAINED_IMAGE, B, lib_ms) if recs else None,
+        kernels=_kernel_table(recs, 2), library_kernel_ms_per_step=round(lib_ms, 3))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_train(trainer, size)
+    del engine, trainer
+    torch.cuda.empty_cache()
     return result
 
 
+# ---- part 2: regional sampling ---------------------------------------------------------------------------------------
 REGION_PX = [[2, 2, 512, 184], [7, 184, 512, 345], [1, 488, 512, 747]]  # regionally_sample.sh boxes x (1/2, 768/2048)
 
 
-def build_regional_pipe(preset, device):
+def build_regional_pipe(preset, device, dtype=torch.float16):
     from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionallyT2IAdapterPipeline
-    pipe = RegionallyT2IAdapterPipeline.from_pretrained(f'synthetic://{preset}?seed=0', torch_dtype=torch.float16)
+    pipe = RegionallyT2IAdapterPipeline.from_pretrained(f'synthetic://{preset}?seed=0', torch_dtype=dtype)
     names = ['<potter1>', '<potter2>', '<hermione1>', '<hermione2>', '<thanos1>', '<thanos2>']
     cfg = {}
     for i, n in enumerate(names):
@@ -244,43 +345,155 @@ def regional_prompt(height, width):
     return [(ctx, regions)], neg
 
 
-def run_regional(args, rank, world, device):
+def run_regional(args, rank, world, device, steps=None, warmup=None):
     from mixofshow.hip import profiler
     H, W = 512, 768
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     pipe = build_regional_pipe(args.preset, device)
     prompt, neg = regional_prompt(H, W)
     latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14))
+    graph = args.regional_graph
 
-    def sample():
+    def sample(g):
         return pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50,
-                    guidance_scale=7.5, latents=latents.clone(), output_type='latent',
-                    hipgraph=(args.graph >= 2)).images
+                    guidance_scale=7.5, latents=latents.clone(), output_type='latent', hipgraph=g).images
 
-    for _ in range(args.warmup):
-        sample()
+    for _ in range(warmup):
+        sample(graph)
     _sync_barrier(world)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = sample()
+    for _ in range(steps):
+        out = sample(graph)
     _sync_barrier(world)
     dt = _max_over_ranks(time.perf_counter() - t0, world, device)
     graphed = bool(getattr(pipe, 'last_call_graphed', False))
     recs = []
-    args.graph = 0                                   # HIP events are recorded at launch: profiled pass runs eagerly
-    with profiler.profile(recs):
-        sample()
+    with profiler.profile(recs):                     # HIP events are recorded at launch: profiled pass runs eagerly
+        sample(False)
         torch.cuda.synchronize()
-    return dict(metric='regional_sample_latency_ms_50step_512x768_3regions', value=round(dt / args.steps * 1e3, 2),
-                unit='ms', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 2),
-                higher_is_better=False, scaling='weak', vs_baseline=None, dtype='fp16', data='synthetic',
-                config=dict(workload='BASELINE.json configs[4]: 3-region (potter/hermione/thanos) 512x768, 50 '
-                                     'DPM-Solver++(2M) steps, CFG 7.5, batch 1, SD-1.5 random init, no adapter',
-                            replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all()),
-                            hipgraph=graphed),
-                roofline=roofline_from_profile(recs) if recs else None,
-                kernels=[dict(name=r['name'], calls=r['calls'], avg_us=round(r['avg_us'], 2),
-                              total_ms=round(r['total_ms'], 3)) for r in recs[:12]],
-                library_kernel_ms_per_sample=round(sum(r['total_ms'] for r in recs), 3))
+    lib_ms = sum(r['total_ms'] for r in recs)
+    res = dict(metric='regional_sample_latency_ms_50step_512x768_3regions', value=round(dt / steps * 1e3, 2),
+               unit='ms', n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
+               higher_is_better=False, scaling='weak', vs_baseline=None, dtype='fp16', data='synthetic',
+               config=dict(workload='BASELINE.json configs[4]: 3-region (potter/hermione/thanos) 512x768, 50 '
+                                    'DPM-Solver++(2M) steps, CFG 7.5, batch 1, SD-1.5 random init (calibrated), no adapter',
+                           replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all()),
+                           hipgraph=graphed, host_cores=os.cpu_count()),
+               roofline=roofline_from_profile(recs) if recs else None,
+               attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_REGIONAL_CALL, 50, lib_ms) if recs else None,
+               kernels=_kernel_table(recs, 1), library_kernel_ms_per_sample=round(lib_ms, 3))
+    del pipe
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline_regional(args.preset, H, W)
+    return res
+
+
+# ---- configs[3]: gradient fusion of 14 synthetic ED-LoRAs ------------------------------------------------------------
+def synthetic_edlora_checkpoints(preset, n, out_dir):
+    """SURVEY 8(d) cfg #4: n synthetic ED-LoRA dicts (keys per App. C, seeds 0..n-1, lora_up ~ N(0, 0.02^2),
+    lora_down kaiming, alphas 1.0), two concept words each. Returns the fusion json path."""
+    tr = build_trainer(preset, torch.device('cpu'))
+    template = tr.delta_state_dict()
+    words = ['potter', 'hermione', 'thanos', 'hinton', 'lecun', 'bengio', 'catA', 'dogA', 'dogB', 'chair', 'table', 'vase',
+             'rock', 'pyramid', 'anime', 'style']
+    entries = []
+    for i in range(n):
+        g = torch.Generator().manual_seed(i)
+        d = {'new_concept_embedding': {}, 'text_encoder': {}, 'unet': {}}
+        a, b = f'<{words[i % len(words)]}{i}a>', f'<{words[i % len(words)]}{i}b>'
+        for name in (a, b):
+            d['new_concept_embedding'][name] = torch.randn(16, tr.concept_embedding.shape[1], generator=g) * 0.013
+        for part in ('text_encoder', 'unet'):
+            for k, v in template[part].items():
+                if 'lora_up' in k:
+                    d[part][k] = torch.randn(v.shape, generator=g) * 0.02
+                else:
+                    bound = 1.0 / (v.shape[1] ** 0.5)
+                    d[part][k] = (torch.rand(v.shape, generator=g) * 2 - 1) * bound
+        p = os.path.join(out_dir, f'edlora_{i}.pth')
+        torch.save({'params': d}, p)
+        entries.append(dict(lora_path=p, unet_alpha=1.0, text_encoder_alpha=1.0, concept_name=f'{a} {b}'))
+    cfg = os.path.join(out_dir, 'fuse.json')
+    with open(cfg, 'w') as f:
+        json.dump(entries, f)
+    return cfg
+
+
+def run_fusion(args, rank, world, device):
+    """configs[3]: gradient_fusion.compose_concepts on 14 synthetic ED-LoRAs, iters 500 (CLIP, cross-K/V) / 50 (spatial)
+    as fuse.sh:8-9; a "step" is one complete fusion. Roofline: the Gram kernel. cpu_baseline: ONE level-0 spatial layer
+    (n = 81,920 rows = one concept, 320 -> 320) through the reference-semantics L-BFGS on stored features."""
+    import tempfile
+    import gradient_fusion as gf
+    from mixofshow.hip import profiler
+    n = args.concepts
+    tmp = tempfile.mkdtemp(prefix='mos_fuse_')
+    _log(f'writing {n} synthetic ED-LoRA checkpoints ({args.preset}) to {tmp}')
+    cfg = synthetic_edlora_checkpoints(args.preset, n, tmp)
+    recs, times = [], []
+    for i in range(args.warmup + args.steps):
+        profiling = i == args.warmup + args.steps - 1
+        torch.manual_seed(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if profiling:
+            profiler.begin()
+        gf.compose_concepts(cfg, args.textenc_iters, args.unet_iters, f'synthetic://{args.preset}?seed=0', tmp, 'bench',
+                            device, save=False)
+        torch.cuda.synchronize()
+        if profiling:
+            recs.extend(profiler.end())
+        dt = time.perf_counter() - t0
+        _log(f'fusion pass {i}: {dt:.1f}s')
+        if i >= args.warmup:
+            times.append(dt)
+    gram = [r for r in recs if r['name'].startswith('gram')]
+    res = dict(metric='gradient_fusion_wall_seconds_14_edloras_sd15', value=round(statistics.mean(times), 2), unit='s',
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(statistics.mean(times) * 1e3, 1),
+               higher_is_better=False, scaling='weak', vs_baseline=None, dtype='fp16 features / fp64 Gram + L-BFGS',
+               data='synthetic',
+               config=dict(workload=f'BASELINE.json configs[3]: gradient_fusion of {n} synthetic ED-LoRAs into one SD-1.5 '
+                                    f'UNet + CLIP, L-BFGS iters {args.textenc_iters} (text encoder, cross K/V) / '
+                                    f'{args.unet_iters} (spatial), saving excluded', preset=args.preset, concepts=n,
+                           host_cores=os.cpu_count()),
+               roofline=roofline_from_profile(gram) if gram else None, kernels=_kernel_table(recs, 1, 10))
+    if not args.no_cpu_baseline:
+        from oracle import fusion_ref
+        threads = _cpu_threads()
+        g = torch.Generator().manual_seed(0)
+        X = torch.randn(81920, 320, generator=g).half().float()
+        W0 = torch.randn(320, 320, generator=g) * 0.05
+        Y = (X @ (W0 + 0.01 * torch.randn(320, 320, generator=g)).T).half().float()
+        t0 = time.time()
+        _with_alarm(240, lambda: fusion_ref.update_quasi_newton_ref(X, Y, W0.clone(), args.unet_iters))
+        dt = time.time() - t0
+        res['cpu_baseline'] = dict(value=round(dt, 2), unit='s', cores=threads, host_cores=os.cpu_count(), kind='port',
+                                   sample=f'ONE level-0 spatial layer (n=81920 rows = 1 concept x 20 steps x 4096 tokens, '
+                                          f'320->320) through the reference-semantics L-BFGS ({args.unet_iters} iters, chunked '
+                                          f'fp32 closure, oracle/fusion_ref.py); the full job has 96 spatial + 32 '
+                                          f'cross-K/V + 48 CLIP layers and {n}x the rows per spatial layer')
+    return res
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one per GPU over RCCL), fail loudly
+    if the node cannot run them."""
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} requested but this node exposes {n_dev} HIP device(s); refusing to print a '
+              f'{args.gpus}-GPU line from fewer ranks', file=sys.stderr)
+        sys.exit(2)
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    _log('launching ' + ' '.join(cmd))
+    sys.exit(subprocess.run(cmd).returncode)
 
 
 def main():
@@ -288,25 +501,48 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--mode', default='train', choices=['train', 'regional'])
+    ap.add_argument('--mode', default='train', choices=['train', 'regional', 'fusion'])
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--preset', default='sd15')
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-regional', action='store_true', help='train mode: skip the regional-sample half of the metric')
     ap.add_argument('--channels-last', type=int, default=0)
-    ap.add_argument('--graph', type=int, default=1, help='train: capture fwd+bwd of the step in a hipGraph (default 1); regional: 2 = replay the UNet call '
-                         'from a hipGraph (the loop is GPU-bound, no gain measured)')
+    ap.add_argument('--graph', type=int, default=1, help='train: forward+backward replayed from a hipGraph (the product '
+                    'default, train_edlora.py); 0 = eager')
+    ap.add_argument('--regional-graph', type=int, default=0, help='regional: replay the UNet call from a hipGraph (opt-in '
+                    'in the product too; the loop is GPU-bound)')
+    ap.add_argument('--concepts', type=int, default=14)
+    ap.add_argument('--textenc-iters', type=int, default=500)
+    ap.add_argument('--unet-iters', type=int, default=50)
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        _self_launch(args)
     from mixofshow.parallel import dp
     rank, world, local = dp.init_distributed()
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print('bench.py needs a HIP device (MI355X); there is no CPU fallback', file=sys.stderr)
         sys.exit(2)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
-    res = run_train(args, rank, world, device) if args.mode == 'train' else run_regional(args, rank, world, device)
+    if args.mode == 'train':
+        res = run_train(args, rank, world, device)
+        if world == 1 and not args.no_regional:
+            reg = run_regional(args, rank, world, device, steps=min(args.steps, 3), warmup=min(args.warmup, 1))
+            res['regional'] = dict(value_ms=reg['value'], metric=reg['metric'], steps=reg['steps'], warmup=reg['warmup'],
+                                   config=reg['config'], roofline=reg['roofline'], attention_path=reg['attention_path'],
+                                   cpu_baseline=reg.get('cpu_baseline'), kernels=reg['kernels'],
+                                   library_kernel_ms_per_sample=reg['library_kernel_ms_per_sample'])
+        else:
+            res['regional'] = None
+    elif args.mode == 'regional':
+        res = run_regional(args, rank, world, device)
+    else:
+        res = run_fusion(args, rank, world, device)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -285,7 +285,7 @@ def merge_spatial_attention(concept_list, optimize_iters, new_concept_cfg, token
 
 
 def compose_concepts(concept_cfg, optimize_textenc_iters, optimize_unet_iters, pretrained_model_path, save_path, suffix,
-                     device):
+                     device, save=True):
     logging.info('------Step 1: load stable diffusion checkpoint------')
     pipe, _, test_scheduler = init_stable_diffusion(pretrained_model_path, device)
     tokenizer, text_encoder, unet, vae = pipe.tokenizer, pipe.text_encoder, pipe.unet, pipe.vae
@@ -318,10 +318,11 @@ def compose_concepts(concept_cfg, optimize_textenc_iters, optimize_unet_iters, p
         sd = unet.state_dict()
         sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
         unet.load_state_dict(sd)
-    out = f'{save_path}/combined_model_{suffix}'
-    pipe.save_pretrained(out)
-    with open(os.path.join(out, 'new_concept_cfg.json'), 'w') as f:
-        json.dump(new_concept_cfg, f)
+    if save:
+        out = f'{save_path}/combined_model_{suffix}'
+        pipe.save_pretrained(out)
+        with open(os.path.join(out, 'new_concept_cfg.json'), 'w') as f:
+            json.dump(new_concept_cfg, f)
     return pipe, new_concept_cfg
 
 

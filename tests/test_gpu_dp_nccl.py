@@ -1,0 +1,63 @@
+"""Data-parallel path on real devices: 2 ranks over RCCL (backend "nccl"), one per GPU. Skips on a 1-GPU box (the
+driver's 8-GPU node runs it); the same logic is covered on CPU with gloo in tests/test_dp_gloo.py."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, ROOT)
+    import mos_path  # noqa: F401
+    from bench import TRAIN_OPT, build_trainer, synthetic_batch
+    from mixofshow.parallel import dp
+    from mixofshow.pipelines.train_loop import TrainEngine
+    r, w, local = dp.init_distributed()                     # backend defaults to nccl (= RCCL) on a HIP device
+    assert torch.distributed.get_backend() == 'nccl' and w == world
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    tr = build_trainer('small', dev)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+            l.lora_up.weight.normal_(0, 0.02)
+    engine = TrainEngine(tr, dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g'])), total_iter=100, mixed_precision='fp16')
+    g = torch.Generator().manual_seed(10 + rank)             # ranks see different data
+    b = synthetic_batch(2, 256, dev, 100 + rank)
+    b.update(latents=torch.randn(2, 4, 32, 32, generator=g).to(dev), noise=torch.randn(2, 4, 32, 32, generator=g).to(dev),
+             timesteps=torch.randint(0, 1000, (2, ), generator=g).to(dev))
+    b['images'] = None
+    engine.bucket.zero()
+    with torch.autocast('cuda', dtype=torch.float16):
+        loss = tr(None, b['prompts'], b['masks'], b['img_masks'], noise=b['noise'], timesteps=b['timesteps'],
+                  latents=b['latents'])
+    loss.backward()
+    local_grad = engine.bucket.flat.clone()
+    engine.bucket.allreduce_mean()
+    reduced = engine.bucket.flat.clone()
+    out = engine.step(b)
+    params = torch.cat([p.detach().reshape(-1) for p in tr.trainable_parameters()])
+    torch.save(dict(local=local_grad.cpu(), reduced=reduced.cpu(), params=params.cpu(), loss=float(out['loss'])),
+               os.path.join(out_dir, f'rank{rank}.pt'))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_rccl_allreduce_of_the_gradient_bucket(tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (RCCL over xGMI); covered with gloo on CPU in tests/test_dp_gloo.py')
+    world, port = 2, 29700 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / 'rank0.pt'), torch.load(tmp_path / 'rank1.pt')
+    assert not torch.equal(r0['local'], r1['local'])
+    torch.testing.assert_close(r0['reduced'], r1['reduced'], rtol=0, atol=0)
+    torch.testing.assert_close(r0['reduced'], (r0['local'] + r1['local']) / 2, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(r0['params'], r1['params'], rtol=0, atol=0)        # lock-step after fused AdamW

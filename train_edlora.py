@@ -70,7 +70,8 @@ def train(root_path, args):
     trainer.unet.train()
     trainer.text_encoder.train()
     t0 = time.time()
-    use_graph = bool(opt['train'].get('hipgraph', False)) and device.type == 'cuda' and accum == 1
+    # default ON (bench.py measures this mode): forward+backward replayed from a hipGraph; `train.hipgraph: false` opts out
+    use_graph = bool(opt['train'].get('hipgraph', True)) and device.type == 'cuda' and accum == 1
     while engine.global_step < total_iter:
         batch = _to_device(next(it), device)
         if use_graph and getattr(engine, '_graph', None) is None:
