@@ -80,6 +80,14 @@ typedef struct {
 int mos_lora_pack(const mos_lora_sites* sites_host, int dtype,
                   void* A16, void* A16T, void* Bp16, void* BpT, void* stream);
 
+/* Every group of a model in ONE launch (one descriptor per fused-projection group, array in DEVICE memory): what a
+ * training step needs once per optimiser update instead of one mos_lora_pack launch per projection call. */
+typedef struct {
+    mos_lora_sites s;
+    void* A16; void* A16T; void* Bp16; void* BpT;   /* outputs of this group, `dtype` */
+} mos_lora_group;
+int mos_lora_pack_all(const mos_lora_group* groups_dev, int n_groups, int max_elems, int dtype, void* stream);
+
 /* t[M,16] = x[M,K] . A16^T   (lora_down of all fused sites, one pass over x) */
 int mos_lora_down(const void* x, int64_t ldx, const void* A16, void* t,
                   int M, int K, int dtype, void* stream);
@@ -90,6 +98,13 @@ int mos_lora_down(const void* x, int64_t ldx, const void* A16, void* t,
 int mos_lora_linear_fwd(const void* x, int64_t ldx, const void* W, int64_t ldw,
                         const void* t, const void* Bp16, const float* bias,
                         void* y, int64_t ldy, int M, int N, int K, int dtype, void* stream);
+
+/* Same result with the down projection FUSED into the GEMM: t = x . A16^T is accumulated in the K loop next to the
+ * base product (A16 rides as 16 extra weight rows), rounded to `dtype` and fed to the rank-16 epilogue from registers;
+ * t_out [M,16] (may be NULL) receives it for the backward. One launch, no separate mos_lora_down pass over x. */
+int mos_lora_linear_fused_fwd(const void* x, int64_t ldx, const void* W, int64_t ldw,
+                              const void* A16, const void* Bp16, const float* bias,
+                              void* y, int64_t ldy, void* t_out, int M, int N, int K, int dtype, void* stream);
 
 /* Backward of the above w.r.t. x and the packed LoRA factors (W is frozen: no dW).
  *   dt[M,16]  = dy . BpT^T                      (written to dt)
@@ -106,6 +121,31 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
                         const void* A16T, const void* BpT,
                         void* dt, void* dx, int64_t lddx, float* dA16, float* dBpT,
                         void* ws, int M, int N, int K, int lora_cols, int dtype, void* stream);
+
+/* Fused backward: launch 1 = dx (with dt = dy . BpT^T produced in the same kernel, written to dt); launch 2 = both
+ * factor gradients, reduced over tokens and written STRAIGHT into the fp32 parameter gradients:
+ *   down_grad[g][r, K]      (+)= (dt^T x)[g*r .. g*r+r-1, :]
+ *   up_grad[g][n_rows, r]   (+)= alpha_g * (t^T dy)[g*r .. , n_begin .. n_begin+n_rows)^T
+ * (NULL pointers are skipped; accumulate_* = 1 adds to what is there — gradient buckets, micro-batches).
+ * The final sum over token chunks is done in chunk order by the last block of each column block: deterministic.
+ * counters: >= 128 int32, zeroed ONCE by the caller (self-resetting), not shared between concurrent streams.
+ * ws: mos_lora_bwd_workspace_bytes(M,N,K) bytes. dx may be NULL; grads_host may be NULL (only dt / dx wanted). */
+typedef struct {
+    int n_sites, rank;
+    float* down_grad[4];
+    float* up_grad[4];
+    float alpha[4];
+    int n_begin[4];
+    int n_rows[4];
+    int accumulate_down[4];
+    int accumulate_up[4];
+} mos_lora_grad_out;
+int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                              const void* Wt, int64_t ldwt, const void* t,
+                              const void* A16T, const void* BpT,
+                              void* dt, void* dx, int64_t lddx,
+                              const mos_lora_grad_out* grads_host, void* ws, int* counters,
+                              int M, int N, int K, int lora_cols, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused attention core: softmax(scale * Q K^T) V with online softmax, no materialised P.

@@ -157,22 +157,10 @@ __device__ __forceinline__ void desync_wave_slots() {
 #endif
 #endif
 }
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-// descriptor of `bytes` valid bytes at p; p and bytes are wave-uniform (made provably so: cdna guide T20)
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
-    const uint64_t a = (uint64_t)p;
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0,
-                                             (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
 // bytes of a token-major slice: n rows of D contiguous elements, row stride rs elements (other heads in between)
 template <typename T, int D>
 __device__ __forceinline__ uint32_t slice_bytes(int n, int64_t rs) {
     return (uint32_t)(((int64_t)(n - 1) * rs + D) * (int64_t)sizeof(T));
-}
-__device__ __forceinline__ u32x4 ldbuf16(rsrc_t src, int byte_off) {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, byte_off, 0, 0));
 }
 
 template <typename T, int D, int NT = 256>

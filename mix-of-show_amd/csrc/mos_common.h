@@ -84,6 +84,20 @@ __device__ __forceinline__ uint32_t half_of(u32x4 v, int i) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// ---- buffer-resource loads: rows / bytes past the end of the described range read as ZERO in hardware ----------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// descriptor of `bytes` valid bytes at p; p and bytes are wave-uniform (made provably so: cdna guide T20)
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0,
+                                             (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ u32x4 ldbuf16(rsrc_t src, int byte_off) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, byte_off, 0, 0));
+}
+
 // ---- host-side error plumbing (defined in mos_api.hip) --------------------------------------
 int mos_set_error(int code, const char* fmt, ...);
 int mos_check_launch(const char* what);

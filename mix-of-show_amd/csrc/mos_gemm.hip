@@ -3,9 +3,15 @@
 // Replaces LoRALinearLayer.forward (reference mixofshow/models/edlora.py:244-246):
 //     y = orig(x) + alpha * lora_up(lora_down(x))
 // which the reference runs as 3 GEMM launches (base, K=..->4, 4->N) + scale + add per site.
-// Here:  t = x . A16^T  (one skinny pass over x for ALL fused sites),  then ONE MFMA GEMM with the
-// rank dimension appended to the contraction:  y = [x | t] . [W | alpha*B]^T + bias.
-// Backward (W frozen): dt = dy . BpT^T ; dx = [dy | dt] . [W^T | A^T]^T ; dA = dt^T x ; dB = t^T dy.
+// Here ONE kernel per direction:
+//   forward : y = x.W^T + (x.A16^T).Bp16^T + b.  The down projection t = x.A16^T rides in the same K loop as 16 extra
+//             "weight rows" (A16 staged next to the W tile); its fp32 accumulator, rounded to half, IS the B operand of
+//             the rank-16 epilogue MFMA (same lane layout), so t never leaves registers; the n-tile-0 blocks also store
+//             it for the backward.
+//   backward: dx = dy.Wt^T + (dy.BpT^T).A16T^T with dt = dy.BpT^T produced the same way (W frozen: no dW), then
+//   lora_grad: dA = dt^T x and dB = t^T dy in ONE launch (token reduction, deterministic in-kernel final sum by the last
+//             block of every column block), written straight into the fp32 parameter gradients (alpha folded,
+//             per-site slices, optional accumulate) — no per-parameter glue kernels on the host side.
 //
 // MFMA conventions (v_mfma_f32_16x16x32_{f16,bf16}; D[i][j] = sum_k A[i][k] B[k][j]):
 //   lane l supplies A[i = l&15][k = 8*(l>>4) .. +8] and B[k = 8*(l>>4) .. +8][j = l&15];
@@ -21,78 +27,123 @@
 #define MOS_TN_REDUCE_UNROLL 0
 #endif
 #ifndef MOS_TN_TARGET_WG
-#define MOS_TN_TARGET_WG 512      // workgroups the LoRA-gradient kernel aims at (tuning knob)
+#define MOS_TN_TARGET_WG 512      // workgroups the legacy LoRA-gradient kernel aims at
+#endif
+#ifndef MOS_GRAD_TARGET_WG
+#define MOS_GRAD_TARGET_WG 1024   // workgroups the fused LoRA-gradient kernel aims at
 #endif
 
 namespace {
 
-constexpr int GEMM_BM = 128;
 constexpr int GEMM_BK = 64;
 constexpr int GEMM_LDS_STRIDE = GEMM_BK + 8;  // 144 B rows: 16B-slot index r*9 mod 16 is a bijection
 
-template <typename T, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(
-    const T* __restrict__ X, int64_t ldx, const T* __restrict__ W, int64_t ldw,
-    const T* __restrict__ Taug, const T* __restrict__ Baug, const float* __restrict__ bias,
-    T* __restrict__ Y, int64_t ldy, int M, int N, int K) {
+struct GemmArgs {
+    const void* X; const void* W; const void* Taug; const void* Adown; const void* Baug; const float* bias;
+    void* Y; void* Tout;
+    int64_t ldx, ldw, ldy;
+    int M, N, K, mt, nt;
+};
+
+// Y[M,N] = X[M,K].W[N,K]^T (+ t.Baug^T) (+ bias), t = X.Adown^T computed in the same K loop (FUSED) or read from Taug.
+// Tiles are fetched with buffer loads whose descriptors end at the last valid row: rows past M / N read as zeros in
+// hardware (no clamps, no selects in the prefetch); KTAIL (K % 64 != 0, not an SD-1.5 shape) adds a column select.
+// Block -> tile map is XCD-aware: the nt blocks that share one X row-tile get consecutive slots on ONE XCD (workgroup
+// id % 8), so X is pulled into a single L2 once instead of being re-fetched by up to nt XCDs.
+template <typename T, int BM, int BN, bool FUSED, bool KTAIL>
+__global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
     typedef typename MT<T>::v8 v8;
     typedef typename MT<T>::v4 v4;
-    constexpr int NJ = BN / 32;             // 16-wide n tiles per wave (wave tile = 64 m x BN/2 n)
-    constexpr int XCH = GEMM_BM * 8 / 256;  // 16B chunks of the X tile per thread (4)
-    constexpr int WCH = BN * 8 / 256;       // 16B chunks of the W tile per thread (4 or 2)
+    constexpr int MI = BM / 32;             // 16-row m sub-tiles per wave (wave tile = BM/2 x BN/2)
+    constexpr int NJ = BN / 32;             // 16-wide n sub-tiles per wave
+    constexpr int XCH = BM * 8 / 256;       // 16 B chunks of the X tile per thread
+    constexpr int WCH = BN * 8 / 256;
+    constexpr int LS = GEMM_LDS_STRIDE;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Xs = reinterpret_cast<T*>(smem_raw);                       // [2][128][72]
-    T* Ws = Xs + 2 * GEMM_BM * GEMM_LDS_STRIDE;                   // [2][BN][72]
+    T* Xs = reinterpret_cast<T*>(smem_raw);                       // [2][BM][72]
+    T* Ws = Xs + 2 * BM * LS;                                     // [2][BN][72]
+    T* As = Ws + 2 * BN * LS;                                     // [2][16][72]   (FUSED)
+
+    const int w = blockIdx.x;
+    const int slot = w >> 3;
+    const int n_tile = slot % a.nt;
+    const int m_tile = (slot / a.nt) * 8 + (w & 7);
+    if (m_tile >= a.mt) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int n0 = blockIdx.x * BN;
-    const int m0 = blockIdx.y * GEMM_BM;
+    const int n0 = n_tile * BN;
+    const int m0 = m_tile * BM;
+    const int M = a.M, N = a.N, K = a.K;
 
-    f32x4 acc[NJ][4];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((((int64_t)M - 1) * a.ldx + K) * (int64_t)sizeof(T)));
+    const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * a.ldw + K) * (int64_t)sizeof(T)));
+    const rsrc_t asrc = make_rsrc(FUSED ? a.Adown : a.W, (uint32_t)(FUSED ? 16 * (int64_t)K * sizeof(T) : 16));
 
-    u32x4 xr[XCH], wr[WCH];
+    int xoff[XCH], woff[WCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int c = tid + 256 * i;
+        xoff[i] = (int)((((int64_t)(m0 + (c >> 3))) * a.ldx + (c & 7) * 8) * (int64_t)sizeof(T));
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int c = tid + 256 * i;
+        woff[i] = (int)((((int64_t)(n0 + (c >> 3))) * a.ldw + (c & 7) * 8) * (int64_t)sizeof(T));
+    }
+    const int aoff = (int)(((int64_t)(tid >> 3) * K + (tid & 7) * 8) * (int64_t)sizeof(T));   // tid < 128
+
+    f32x4 acc[NJ][MI];
+    f32x4 acct[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        acct[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    u32x4 xr[XCH], wr[WCH], ar;
     const int nk = (K + GEMM_BK - 1) / GEMM_BK;
 
     auto load_tile = [&](int kt) {
-        const int k0 = kt * GEMM_BK;
+        const int kb = kt * GEMM_BK * (int)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c >> 3, cc = c & 7;
-            const int m = min(m0 + row, M - 1);
-            const int k = k0 + cc * 8;
-            xr[i] = (k < K) ? ld16(X + (int64_t)m * ldx + k) : u32x4{0, 0, 0, 0};
+        for (int i = 0; i < XCH; ++i) xr[i] = ldbuf16(xsrc, xoff[i] + kb);
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) wr[i] = ldbuf16(wsrc, woff[i] + kb);
+        if constexpr (FUSED) {
+            if (tid < 128) ar = ldbuf16(asrc, aoff + kb);
         }
+        if constexpr (KTAIL) {      // columns past K inside a valid row belong to the next row: mask them
+            const bool ok = (kt * GEMM_BK + (tid & 7) * 8) < K;
+            if (!ok) {
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c >> 3, cc = c & 7;
-            const int n = min(n0 + row, N - 1);
-            const int k = k0 + cc * 8;
-            wr[i] = (k < K) ? ld16(W + (int64_t)n * ldw + k) : u32x4{0, 0, 0, 0};
+                for (int i = 0; i < XCH; ++i) xr[i] = u32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) wr[i] = u32x4{0, 0, 0, 0};
+                ar = u32x4{0, 0, 0, 0};
+            }
         }
     };
     auto store_tile = [&](int buf) {
-        T* xs = Xs + buf * GEMM_BM * GEMM_LDS_STRIDE;
-        T* ws = Ws + buf * BN * GEMM_LDS_STRIDE;
+        T* xs = Xs + buf * BM * LS;
+        T* ws = Ws + buf * BN * LS;
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int c = tid + 256 * i;
-            st16(xs + (c >> 3) * GEMM_LDS_STRIDE + (c & 7) * 8, xr[i]);
+            st16(xs + (c >> 3) * LS + (c & 7) * 8, xr[i]);
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
             const int c = tid + 256 * i;
-            st16(ws + (c >> 3) * GEMM_LDS_STRIDE + (c & 7) * 8, wr[i]);
+            st16(ws + (c >> 3) * LS + (c & 7) * 8, wr[i]);
+        }
+        if constexpr (FUSED) {
+            if (tid < 128) st16(As + buf * 16 * LS + (tid >> 3) * LS + (tid & 7) * 8, ar);
         }
     };
 
@@ -103,21 +154,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMAs below
-        const T* xs = Xs + cur * GEMM_BM * GEMM_LDS_STRIDE + (wm * 64 + l15) * GEMM_LDS_STRIDE + lg * 8;
-        const T* ws = Ws + cur * BN * GEMM_LDS_STRIDE + (wn * (BN / 2) + l15) * GEMM_LDS_STRIDE + lg * 8;
+        const T* xs = Xs + cur * BM * LS + (wm * (BM / 2) + l15) * LS + lg * 8;
+        const T* ws = Ws + cur * BN * LS + (wn * (BN / 2) + l15) * LS + lg * 8;
+        const T* as = As + cur * 16 * LS + l15 * LS + lg * 8;
 #pragma unroll
         for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
-            v8 bfrag[4], afrag[NJ];
+            v8 bfrag[MI], afrag[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                bfrag[i] = as_v8<T>(ld16(xs + i * 16 * GEMM_LDS_STRIDE + kk * 32));
+            for (int i = 0; i < MI; ++i) bfrag[i] = as_v8<T>(ld16(xs + i * 16 * LS + kk * 32));
 #pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                afrag[j] = as_v8<T>(ld16(ws + j * 16 * GEMM_LDS_STRIDE + kk * 32));
+            for (int j = 0; j < NJ; ++j) afrag[j] = as_v8<T>(ld16(ws + j * 16 * LS + kk * 32));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = MT<T>::mfma16(afrag[j], bfrag[i], acc[j][i]);
+                for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16(afrag[j], bfrag[i], acc[j][i]);
+            if constexpr (FUSED) {
+                const v8 at = as_v8<T>(ld16(as + kk * 32));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acct[i] = MT<T>::mfma16(at, bfrag[i], acct[i]);
+            }
         }
         if (kt + 1 < nk) store_tile(cur ^ 1);
         __syncthreads();
@@ -125,39 +180,49 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(
 
     // Rank augmentation: y += t[M,16] . Baug[N,16]^T, one K=16 MFMA per tile
     // (v_mfma_f32_16x16x16: lane supplies A[i=l&15][k=4*(l>>4)..+4], B[k][j=l&15]).
-    if (Taug != nullptr) {
-        v4 tb[4], ba[NJ];
+    // FUSED: acct[i] holds t[m = l15][r = 4*lg .. +3] of m sub-tile i — exactly that B operand once rounded to T.
+    if (FUSED || a.Taug != nullptr) {
+        v4 tb[MI], ba[NJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = min(m0 + wm * 64 + i * 16 + l15, M - 1);
-            tb[i] = __builtin_bit_cast(v4, ld8(Taug + (int64_t)m * MOS_LORA_PAD + lg * 4));
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+            if constexpr (FUSED) {
+                const u32x2 tp = pack4<T>(acct[i][0], acct[i][1], acct[i][2], acct[i][3]);
+                tb[i] = __builtin_bit_cast(v4, tp);
+                if (a.Tout != nullptr && n_tile == 0 && wn == 0 && m < M)
+                    st8(reinterpret_cast<T*>(a.Tout) + (int64_t)m * MOS_LORA_PAD + lg * 4, tp);
+            } else {
+                const int mc = min(m, M - 1);
+                tb[i] = __builtin_bit_cast(v4, ld8(reinterpret_cast<const T*>(a.Taug) + (int64_t)mc * MOS_LORA_PAD + lg * 4));
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = min(n0 + wn * (BN / 2) + j * 16 + l15, N - 1);
-            ba[j] = __builtin_bit_cast(v4, ld8(Baug + (int64_t)n * MOS_LORA_PAD + lg * 4));
+            ba[j] = __builtin_bit_cast(v4, ld8(reinterpret_cast<const T*>(a.Baug) + (int64_t)n * MOS_LORA_PAD + lg * 4));
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = MT<T>::mfma16k16(ba[j], tb[i], acc[j][i]);
+            for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16k16(ba[j], tb[i], acc[j][i]);
     }
 
     // Epilogue: lane holds features nb..nb+3 of token m.
+    T* Y = reinterpret_cast<T*>(a.Y);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int nb = n0 + wn * (BN / 2) + j * 16 + lg * 4;
         if (nb >= N) continue;
         float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        if (bias != nullptr) {
-            b0 = bias[nb]; b1 = bias[nb + 1]; b2 = bias[nb + 2]; b3 = bias[nb + 3];
+        if (a.bias != nullptr) {
+            b0 = a.bias[nb]; b1 = a.bias[nb + 1]; b2 = a.bias[nb + 2]; b3 = a.bias[nb + 3];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + l15;
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + l15;
             if (m < M) {
-                const f32x4 a = acc[j][i];
-                st8(Y + (int64_t)m * ldy + nb, pack4<T>(a[0] + b0, a[1] + b1, a[2] + b2, a[3] + b3));
+                const f32x4 v = acc[j][i];
+                st8(Y + (int64_t)m * a.ldy + nb, pack4<T>(v[0] + b0, v[1] + b1, v[2] + b2, v[3] + b3));
             }
         }
     }
@@ -323,34 +388,267 @@ __global__ void lora_pack_kernel(mos_lora_sites s, T* __restrict__ A16, T* __res
     }
 }
 
+template <typename T, int BM, int BN, bool FUSED, bool KTAIL>
+int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
+    const size_t lds = 2 * (size_t)(BM + BN + (FUSED ? 16 : 0)) * GEMM_LDS_STRIDE * sizeof(T);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lora_kernel<T, BM, BN, FUSED, KTAIL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    GemmArgs b = a;
+    b.mt = (a.M + BM - 1) / BM;
+    b.nt = (a.N + BN - 1) / BN;
+    const int mt8 = (b.mt + 7) / 8 * 8;
+    hipLaunchKernelGGL((gemm_lora_kernel<T, BM, BN, FUSED, KTAIL>), dim3(mt8 * b.nt), dim3(256), lds, st, b);
+    return mos_check_launch("gemm_lora");
+}
+
+// Tile choice: 128-wide n tiles when N allows (halves the X re-reads and the relative cost of the fused down
+// projection), 128-row m tiles when that still yields >= 384 workgroups, otherwise 64-row / 64-wide tiles so that the
+// small-M levels (M = 1024, 256) spread over the 256 CUs.
+template <typename T, bool FUSED>
+int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
+    if (a.K % GEMM_BK != 0) return launch_gemm_cfg<T, 64, 64, FUSED, true>(a, st);
+    int bn = (a.N % 128 == 0) ? 128 : 64, bm = 128;
+    auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
+    if (tiles(bm, bn) < 384) bm = 64;
+    if (tiles(bm, bn) < 256 && bn == 128) bn = 64;
+    if (bm == 128 && bn == 128) return launch_gemm_cfg<T, 128, 128, FUSED, false>(a, st);
+    if (bm == 128) return launch_gemm_cfg<T, 128, 64, FUSED, false>(a, st);
+    if (bn == 128) return launch_gemm_cfg<T, 64, 128, FUSED, false>(a, st);
+    return launch_gemm_cfg<T, 64, 64, FUSED, false>(a, st);
+}
+
+// adown != NULL: fused down projection (t computed in-kernel, stored to tout if given); else t (may be NULL) is read.
 template <typename T>
-int launch_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, const void* t, const void* Bp,
-                const float* bias, void* Y, int64_t ldy, int M, int N, int K, hipStream_t st) {
-    // BN=64 wastes no columns at N = 320 (5 tiles); BN=128 otherwise halves the X re-reads.
+int launch_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, const void* t, const void* adown, const void* Bp,
+                const float* bias, void* Y, int64_t ldy, void* tout, int M, int N, int K, hipStream_t st) {
     char key[96];
-    snprintf(key, sizeof(key), "%s M%d N%d K%d%s", sizeof(T) == 2 && std::is_same<T, f16_t>::value ? "f16" : "bf16", M, N, K,
-             t ? " +lora" : "");
-    MosProfScope prof(st, "gemm_nt", key, 2.0 * M * (double)N * (K + (t ? 16 : 0)),
+    const bool lora = (t != nullptr) || (adown != nullptr);
+    snprintf(key, sizeof(key), "%s M%d N%d K%d%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", M, N, K,
+             adown ? " +lora(fused)" : (t ? " +lora" : ""));
+    MosProfScope prof(st, "gemm_nt", key, 2.0 * M * (double)N * (K + (lora ? 16 : 0)) + (adown ? 2.0 * M * 16.0 * K : 0.0),
                       2.0 * ((double)M * K + (double)N * K + (double)M * N));
-    const bool wide = (N % 128 == 0) && ((int64_t)((N + 127) / 128) * ((M + 127) / 128) >= 256);
-    if (wide) {
-        constexpr int BN = 128;
-        const size_t lds = 2 * (GEMM_BM + BN) * GEMM_LDS_STRIDE * sizeof(T);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        dim3 grid((N + BN - 1) / BN, (M + GEMM_BM - 1) / GEMM_BM);
-        hipLaunchKernelGGL((gemm_nt_kernel<T, BN>), grid, dim3(256), lds, st, (const T*)X, ldx, (const T*)W, ldw,
-                           (const T*)t, (const T*)Bp, bias, (T*)Y, ldy, M, N, K);
-    } else {
-        constexpr int BN = 64;
-        const size_t lds = 2 * (GEMM_BM + BN) * GEMM_LDS_STRIDE * sizeof(T);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<T, BN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        dim3 grid((N + BN - 1) / BN, (M + GEMM_BM - 1) / GEMM_BM);
-        hipLaunchKernelGGL((gemm_nt_kernel<T, BN>), grid, dim3(256), lds, st, (const T*)X, ldx, (const T*)W, ldw,
-                           (const T*)t, (const T*)Bp, bias, (T*)Y, ldy, M, N, K);
+    GemmArgs a;
+    a.X = X; a.W = W; a.Taug = t; a.Adown = adown; a.Baug = Bp; a.bias = bias; a.Y = Y; a.Tout = tout;
+    a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.mt = a.nt = 0;
+    return adown ? launch_gemm_t<T, true>(a, st) : launch_gemm_t<T, false>(a, st);
+}
+
+// ---- fused LoRA factor gradients -------------------------------------------------------------------------------------
+// job 0: dA[j][c] = sum_m dt[m][j] x[m][c]   (c < K)      job 1: dB[j][n] = sum_m t[m][j] dy[m][n]   (n < N)
+// grid (nchunk, cbK + cbN): a block reduces `rpc` tokens of one 64-column block into partial[chunk]; the LAST block to
+// finish a column block (atomic ticket) sums the partials in chunk order — deterministic regardless of arrival order —
+// and writes the result either as raw 16 x C matrices (legacy API) or straight into the per-site fp32 parameter gradients.
+// The token reduction is HBM-bound (x and dy are read once); arithmetic is NJ FMAs per loaded element on the VALU.
+struct LoraGradArgs {
+    const void* P[2]; const void* Z[2];
+    int64_t ldz[2];
+    int C[2], cb[2];
+    float* partial[2];
+    float* raw[2];
+    int* counters;
+    int M, rpc, nchunk;
+    mos_lora_grad_out out;
+};
+
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void lora_grad_kernel(const LoraGradArgs a) {
+    typedef typename MT<T>::v8 v8;
+    typedef typename MT<T>::v4 v4;
+    __shared__ float red[4][NJ][64];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const int job = (int)blockIdx.y >= a.cb[0] ? 1 : 0;
+    const int colblk = (int)blockIdx.y - (job ? a.cb[0] : 0);
+    const int C = a.C[job];
+    const T* P = reinterpret_cast<const T*>(a.P[job]);
+    const T* Z = reinterpret_cast<const T*>(a.Z[job]);
+    const int64_t ldz = a.ldz[job];
+    const int cg = tid & 7, ry = tid >> 3;
+    const int c0 = colblk * 64 + cg * 8;
+    const int mb = blockIdx.x * a.rpc;
+    const int me = min(mb + a.rpc, a.M);
+    float acc[NJ][8];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    if (c0 < C) {
+        constexpr int U = 4;
+        for (int m = mb + ry; m < me; m += 32 * U) {
+            u32x4 z[U];
+            u32x2 p[U][NJ / 4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {          // all loads of the unrolled group are issued before any use
+                const int mm = min(m + 32 * u, me - 1);
+                z[u] = ld16(Z + (int64_t)mm * ldz + c0);
+#pragma unroll
+                for (int q = 0; q < NJ / 4; ++q) p[u][q] = ld8(P + (int64_t)mm * MOS_LORA_PAD + q * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (m + 32 * u < me) {
+                    const v8 zv = as_v8<T>(z[u]);
+                    float zf[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) zf[e] = (float)zv[e];
+#pragma unroll
+                    for (int q = 0; q < NJ / 4; ++q) {
+                        const v4 pv = __builtin_bit_cast(v4, p[u][q]);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const float pf = (float)pv[jj];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) acc[q * 4 + jj][e] += pf * zf[e];
+                        }
+                    }
+                }
+            }
+        }
     }
-    return mos_check_launch("gemm_nt");
+    // reduce the 8 row-lanes inside each wave (lane bits 3..5), then the 4 waves through LDS
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = acc[j][e];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            acc[j][e] = v;
+        }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < 8) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wave][j][lane * 8 + e] = acc[j][e];
+    }
+    __syncthreads();
+    float* part = a.partial[job];
+    for (int idx = tid; idx < NJ * 64; idx += 256) {
+        const int j = idx >> 6, c = idx & 63;
+        const int col = colblk * 64 + c;
+        if (col < C) part[((int64_t)blockIdx.x * NJ + j) * C + col] = red[0][j][c] + red[1][j][c] + red[2][j][c] + red[3][j][c];
+    }
+    // ---- last block of this column block: ordered final sum -------------------------------------------------------------
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&a.counters[blockIdx.y], 1) == a.nchunk - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) a.counters[blockIdx.y] = 0;        // self-resetting: the caller zeroes the counters once, ever
+    const int r = a.out.rank;
+    for (int idx = tid; idx < MOS_LORA_PAD * 64; idx += 256) {
+        const int j = idx >> 6, c = idx & 63;
+        const int col = colblk * 64 + c;
+        if (col >= C) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (j < NJ) {
+            const float* pp = part + (int64_t)j * C + col;
+            const int64_t cs = (int64_t)NJ * C;
+            int ch = 0;
+            for (; ch + 4 <= a.nchunk; ch += 4) {
+                s0 += pp[(ch + 0) * cs];
+                s1 += pp[(ch + 1) * cs];
+                s2 += pp[(ch + 2) * cs];
+                s3 += pp[(ch + 3) * cs];
+            }
+            for (; ch < a.nchunk; ++ch) s0 += pp[ch * cs];
+        }
+        const float s = (s0 + s1) + (s2 + s3);
+        if (a.raw[job] != nullptr) {
+            a.raw[job][(int64_t)j * C + col] = s;      // rows >= NJ are zero
+            continue;
+        }
+        const int g = j / r;
+        if (j >= NJ || g >= a.out.n_sites) continue;
+        const int jj = j - g * r;
+        if (job == 0) {
+            float* dst = a.out.down_grad[g];
+            if (dst != nullptr) {
+                float* q = dst + (int64_t)jj * C + col;
+                *q = a.out.accumulate_down[g] ? (*q + s) : s;
+            }
+        } else {
+            float* dst = a.out.up_grad[g];
+            const int nn = col - a.out.n_begin[g];
+            if (dst != nullptr && nn >= 0 && nn < a.out.n_rows[g]) {
+                float* q = dst + (int64_t)nn * r + jj;
+                const float v = a.out.alpha[g] * s;
+                *q = a.out.accumulate_up[g] ? (*q + v) : v;
+            }
+        }
+    }
+}
+
+inline void lora_grad_plan(int M, int N, int K, int* rpc, int* nchunk) {
+    const int cbt = (K + 63) / 64 + (N + 63) / 64;
+    int nc = (MOS_GRAD_TARGET_WG + cbt - 1) / cbt;
+    const int maxc = (M + 63) / 64;
+    if (nc > maxc) nc = maxc;
+    if (nc < 1) nc = 1;
+    int r = (M + nc - 1) / nc;
+    r = (r + 31) / 32 * 32;
+    *rpc = r;
+    *nchunk = (M + r - 1) / r;
+}
+
+template <typename T>
+int launch_lora_grad(const void* dt, const void* x, int64_t ldx, const void* t, const void* dy, int64_t lddy, float* rawA,
+                     float* rawB, const mos_lora_grad_out* out, float* ws, int* counters, int M, int N, int K, int cols,
+                     hipStream_t st) {
+    LoraGradArgs a;
+    a.P[0] = dt; a.Z[0] = x; a.ldz[0] = ldx; a.C[0] = K; a.cb[0] = (K + 63) / 64;
+    a.P[1] = t; a.Z[1] = dy; a.ldz[1] = lddy; a.C[1] = N; a.cb[1] = (N + 63) / 64;
+    a.raw[0] = rawA; a.raw[1] = rawB;
+    a.counters = counters; a.M = M;
+    lora_grad_plan(M, N, K, &a.rpc, &a.nchunk);
+    const int nj = cols <= 4 ? 4 : cols <= 8 ? 8 : cols <= 12 ? 12 : 16;
+    a.partial[0] = ws;
+    a.partial[1] = ws + (int64_t)a.nchunk * nj * K;
+    if (out != nullptr) a.out = *out; else { mos_lora_grad_out z = {}; z.rank = 1; a.out = z; }
+    char key[64];
+    snprintf(key, sizeof(key), "M%d K%d N%d r%d", M, K, N, nj);
+    MosProfScope prof(st, "lora_grad", key, 2.0 * M * (double)nj * ((double)K + N), 2.0 * ((double)M * ((double)K + N) + 32.0 * M));
+    dim3 grid(a.nchunk, a.cb[0] + a.cb[1]);
+    switch (nj) {
+        case 4: hipLaunchKernelGGL((lora_grad_kernel<T, 4>), grid, dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((lora_grad_kernel<T, 8>), grid, dim3(256), 0, st, a); break;
+        case 12: hipLaunchKernelGGL((lora_grad_kernel<T, 12>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((lora_grad_kernel<T, 16>), grid, dim3(256), 0, st, a); break;
+    }
+    return mos_check_launch("lora_grad");
+}
+
+// every group of a model in ONE launch: grid (x blocks, n_groups); descriptors live in device memory
+template <typename T>
+__global__ void lora_pack_all_kernel(const mos_lora_group* __restrict__ groups) {
+    const mos_lora_group g = groups[blockIdx.y];
+    const mos_lora_sites& s = g.s;
+    T* A16 = reinterpret_cast<T*>(g.A16); T* A16T = reinterpret_cast<T*>(g.A16T);
+    T* Bp16 = reinterpret_cast<T*>(g.Bp16); T* BpT = reinterpret_cast<T*>(g.BpT);
+    const int nA = MOS_LORA_PAD * s.K, nB = s.N * MOS_LORA_PAD;
+    const int tot = nA > nB ? nA : nB;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += gridDim.x * blockDim.x) {
+        if (idx < nA) {
+            const int j = idx / s.K, k = idx - j * s.K;
+            float v = 0.f;
+            const int gi = j / s.rank;
+            if (gi < s.n_sites) v = s.down[gi][(int64_t)(j - gi * s.rank) * s.K + k];
+            A16[idx] = (T)v;
+            A16T[(int64_t)k * MOS_LORA_PAD + j] = (T)v;
+        }
+        if (idx < nB) {
+            const int n = idx / MOS_LORA_PAD, j = idx - n * MOS_LORA_PAD;
+            float v = 0.f;
+            const int gi = j / s.rank;
+            if (gi < s.n_sites && n >= s.n_begin[gi] && n < s.n_begin[gi] + s.n_rows[gi])
+                v = s.alpha[gi] * s.up[gi][(int64_t)(n - s.n_begin[gi]) * s.rank + (j - gi * s.rank)];
+            Bp16[idx] = (T)v;
+            BpT[(int64_t)j * s.N + n] = (T)v;
+        }
+    }
 }
 
 template <typename T>
@@ -423,6 +721,22 @@ int mos_lora_pack(const mos_lora_sites* s, int dtype, void* A16, void* A16T, voi
     return mos_check_launch("lora_pack");
 }
 
+int mos_lora_pack_all(const mos_lora_group* groups_dev, int n_groups, int max_elems, int dtype, void* stream) {
+    MOS_REQUIRE(groups_dev && n_groups >= 1 && max_elems >= 1, "mos_lora_pack_all: groups=%p n_groups=%d max_elems=%d",
+                (const void*)groups_dev, n_groups, max_elems);
+    hipStream_t st = (hipStream_t)stream;
+    int xb = (max_elems + 255) / 256;
+    if (xb > 64) xb = 64;
+    MosProfScope prof(st, "lora_pack_all", "", 0.0, 0.0);
+    if (dtype == MOS_F16)
+        hipLaunchKernelGGL((lora_pack_all_kernel<f16_t>), dim3(xb, n_groups), dim3(256), 0, st, groups_dev);
+    else if (dtype == MOS_BF16)
+        hipLaunchKernelGGL((lora_pack_all_kernel<bf16_t>), dim3(xb, n_groups), dim3(256), 0, st, groups_dev);
+    else
+        return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_lora_pack_all: dtype %d", dtype);
+    return mos_check_launch("lora_pack_all");
+}
+
 int mos_lora_down(const void* x, int64_t ldx, const void* A16, void* t, int M, int K, int dtype, void* stream) {
     MOS_REQUIRE(x && A16 && t, "mos_lora_down: NULL argument");
     MOS_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0, "mos_lora_down: M=%d K=%d ldx=%lld (K, ldx %% 8)", M, K,
@@ -433,25 +747,52 @@ int mos_lora_down(const void* x, int64_t ldx, const void* A16, void* t, int M, i
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_lora_down: dtype %d", dtype);
 }
 
+static int gemm_dims_ok(const char* who, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldy) {
+    MOS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0,
+                "%s: M=%d N=%d K=%d ldx=%lld ldw=%lld ldy=%lld", who, M, N, K, (long long)ldx, (long long)ldw, (long long)ldy);
+    MOS_REQUIRE(((int64_t)M * ldx + K) * 2 < (1ll << 31) && ((int64_t)N * ldw + K) * 2 < (1ll << 31),
+                "%s: operand exceeds the 2 GiB range of one buffer descriptor (M=%d ldx=%lld N=%d ldw=%lld)", who, M,
+                (long long)ldx, N, (long long)ldw);
+    return MOS_OK;
+}
+
 int mos_lora_linear_fwd(const void* x, int64_t ldx, const void* W, int64_t ldw, const void* t, const void* Bp16,
                         const float* bias, void* y, int64_t ldy, int M, int N, int K, int dtype, void* stream) {
     MOS_REQUIRE(x && W && y, "mos_lora_linear_fwd: NULL argument");
     MOS_REQUIRE((t == nullptr) == (Bp16 == nullptr), "mos_lora_linear_fwd: t and Bp16 must both be set or both NULL");
-    MOS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && ldy % 4 == 0,
-                "mos_lora_linear_fwd: M=%d N=%d K=%d ldx=%lld ldw=%lld ldy=%lld", M, N, K, (long long)ldx,
-                (long long)ldw, (long long)ldy);
+    int rc = gemm_dims_ok("mos_lora_linear_fwd", M, N, K, ldx, ldw, ldy);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MOS_F16) return launch_gemm<f16_t>(x, ldx, W, ldw, t, Bp16, bias, y, ldy, M, N, K, st);
-    if (dtype == MOS_BF16) return launch_gemm<bf16_t>(x, ldx, W, ldw, t, Bp16, bias, y, ldy, M, N, K, st);
+    if (dtype == MOS_F16) return launch_gemm<f16_t>(x, ldx, W, ldw, t, nullptr, Bp16, bias, y, ldy, nullptr, M, N, K, st);
+    if (dtype == MOS_BF16) return launch_gemm<bf16_t>(x, ldx, W, ldw, t, nullptr, Bp16, bias, y, ldy, nullptr, M, N, K, st);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_lora_linear_fwd: dtype %d", dtype);
 }
 
+int mos_lora_linear_fused_fwd(const void* x, int64_t ldx, const void* W, int64_t ldw, const void* A16, const void* Bp16,
+                              const float* bias, void* y, int64_t ldy, void* t_out, int M, int N, int K, int dtype,
+                              void* stream) {
+    MOS_REQUIRE(x && W && y && A16 && Bp16, "mos_lora_linear_fused_fwd: NULL argument");
+    int rc = gemm_dims_ok("mos_lora_linear_fused_fwd", M, N, K, ldx, ldw, ldy);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MOS_F16) return launch_gemm<f16_t>(x, ldx, W, ldw, nullptr, A16, Bp16, bias, y, ldy, t_out, M, N, K, st);
+    if (dtype == MOS_BF16) return launch_gemm<bf16_t>(x, ldx, W, ldw, nullptr, A16, Bp16, bias, y, ldy, t_out, M, N, K, st);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_lora_linear_fused_fwd: dtype %d", dtype);
+}
+
 int64_t mos_lora_bwd_workspace_bytes(int M, int N, int K) {
+    // legacy two-pass plan and the fused single-launch plan share one size function: the larger of the two
     int64_t best = 0;
     for (int C : {N, K}) {
         const int rpc = tn_rows_per_chunk(M, C);
         const int64_t nchunk = (M + rpc - 1) / rpc;
         const int64_t b = nchunk * MOS_LORA_PAD * C * (int64_t)sizeof(float);
+        if (b > best) best = b;
+    }
+    if (M > 0 && N > 0 && K > 0) {
+        int rpc, nchunk;
+        lora_grad_plan(M, N, K, &rpc, &nchunk);
+        const int64_t b = (int64_t)nchunk * MOS_LORA_PAD * ((int64_t)N + K) * (int64_t)sizeof(float);
         if (b > best) best = b;
     }
     return best;
@@ -470,13 +811,14 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
     int rc = 0;
     if (dtype != MOS_F16 && dtype != MOS_BF16) return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_lora_linear_bwd: dtype %d", dtype);
     const bool h = (dtype == MOS_F16);
-    if (lora) {  // dt = dy . BpT^T
-        rc = h ? launch_skinny_nt<f16_t>(dy, lddy, BpT, dt, M, N, st) : launch_skinny_nt<bf16_t>(dy, lddy, BpT, dt, M, N, st);
+    if (dx) {  // dx = dy . Wt^T + (dy . BpT^T) . A16T^T, dt written on the way
+        rc = gemm_dims_ok("mos_lora_linear_bwd", M, K, N, lddy, ldwt, lddx);
         if (rc) return rc;
-    }
-    if (dx) {  // dx = [dy | dt] . [Wt | A16T]^T
-        rc = h ? launch_gemm<f16_t>(dy, lddy, Wt, ldwt, lora ? dt : nullptr, lora ? A16T : nullptr, nullptr, dx, lddx, M, K, N, st)
-               : launch_gemm<bf16_t>(dy, lddy, Wt, ldwt, lora ? dt : nullptr, lora ? A16T : nullptr, nullptr, dx, lddx, M, K, N, st);
+        rc = h ? launch_gemm<f16_t>(dy, lddy, Wt, ldwt, nullptr, lora ? BpT : nullptr, lora ? A16T : nullptr, nullptr, dx, lddx, lora ? dt : nullptr, M, K, N, st)
+               : launch_gemm<bf16_t>(dy, lddy, Wt, ldwt, nullptr, lora ? BpT : nullptr, lora ? A16T : nullptr, nullptr, dx, lddx, lora ? dt : nullptr, M, K, N, st);
+        if (rc) return rc;
+    } else if (lora) {  // no input gradient wanted: dt = dy . BpT^T on its own
+        rc = h ? launch_skinny_nt<f16_t>(dy, lddy, BpT, dt, M, N, st) : launch_skinny_nt<bf16_t>(dy, lddy, BpT, dt, M, N, st);
         if (rc) return rc;
     }
     if (lora && dA16) {  // dA16[16,K] = dt^T . x
@@ -491,6 +833,37 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
         if (rc) return rc;
     }
     return MOS_OK;
+}
+
+int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
+                              const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
+                              const mos_lora_grad_out* grads_host, void* ws, int* counters, int M, int N, int K,
+                              int lora_cols, int dtype, void* stream) {
+    MOS_REQUIRE(dy && x && t && A16T && BpT && dt, "mos_lora_linear_fused_bwd: NULL argument");
+    MOS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0,
+                "mos_lora_linear_fused_bwd: M=%d N=%d K=%d lddy=%lld ldx=%lld", M, N, K, (long long)lddy, (long long)ldx);
+    MOS_REQUIRE(dx == nullptr || (Wt && lddx % 4 == 0 && ldwt % 8 == 0), "mos_lora_linear_fused_bwd: dx needs Wt");
+    MOS_REQUIRE(grads_host == nullptr || (ws && counters), "mos_lora_linear_fused_bwd: gradients need ws and counters");
+    MOS_REQUIRE(grads_host == nullptr || (grads_host->n_sites >= 1 && grads_host->n_sites <= 4 && grads_host->rank >= 1 &&
+                                          grads_host->n_sites * grads_host->rank <= MOS_LORA_PAD &&
+                                          lora_cols == grads_host->n_sites * grads_host->rank),
+                "mos_lora_linear_fused_bwd: bad gradient descriptor (sites x rank must equal lora_cols = %d)", lora_cols);
+    if (dtype != MOS_F16 && dtype != MOS_BF16) return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_lora_linear_fused_bwd: dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    const bool h = (dtype == MOS_F16);
+    int rc;
+    if (dx) {
+        rc = gemm_dims_ok("mos_lora_linear_fused_bwd", M, K, N, lddy, ldwt, lddx);
+        if (rc) return rc;
+        rc = h ? launch_gemm<f16_t>(dy, lddy, Wt, ldwt, nullptr, BpT, A16T, nullptr, dx, lddx, dt, M, K, N, st)
+               : launch_gemm<bf16_t>(dy, lddy, Wt, ldwt, nullptr, BpT, A16T, nullptr, dx, lddx, dt, M, K, N, st);
+    } else {
+        rc = h ? launch_skinny_nt<f16_t>(dy, lddy, BpT, dt, M, N, st) : launch_skinny_nt<bf16_t>(dy, lddy, BpT, dt, M, N, st);
+    }
+    if (rc) return rc;
+    if (grads_host == nullptr) return MOS_OK;
+    return h ? launch_lora_grad<f16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, counters, M, N, K, lora_cols, st)
+             : launch_lora_grad<bf16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, counters, M, N, K, lora_cols, st);
 }
 
 }  // extern "C"

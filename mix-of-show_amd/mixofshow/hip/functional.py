@@ -71,6 +71,113 @@ class WeightCache:
         return ent['b']
 
 
+# ---- LoRA operand packing: every group of the process in ONE launch per optimiser update -------------------------------
+_direct_grad = False
+
+
+def set_direct_grad_accumulation(flag):
+    """True (set by TrainEngine, which owns the flat gradient bucket): the backward kernel accumulates the LoRA factor
+    gradients straight into existing fp32 `.grad` tensors and autograd receives None for those inputs — no
+    per-parameter slice / transpose / scale / add kernels. False (default): gradients are returned to autograd."""
+    global _direct_grad
+    _direct_grad = bool(flag)
+
+
+class _PackGroup:
+    __slots__ = ('downs', 'ups', 'alphas', 'K', 'bufs', 'vers', 'epoch', 'desc', 'elems')
+
+
+class LoraPackRegistry:
+    """fp32 master LoRA factors -> packed half MFMA operands (A16, A16T, Bp16, BpT; include/mos_hip.h). Groups register
+    on first use; whenever any group's parameters changed since the last pack (tensor version counters: optimiser step,
+    load_state_dict, manual edits) ALL groups are repacked by one `mos_lora_pack_all` launch — 1 launch per training step
+    instead of one per projection call. Inside a captured hipGraph the launch sits where the first projection asked
+    for its operands (`invalidate()` before capture guarantees it is there)."""
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype = device, dtype
+        self.groups = {}
+        self.epoch = 0
+        self.desc_dev = None
+        self.max_elems = 1
+
+    @staticmethod
+    def _vers(g):
+        return tuple(p._version for p in g.downs) + tuple(p._version for p in g.ups) + tuple(
+            p.data_ptr() for p in g.downs) + tuple(p.data_ptr() for p in g.ups) + tuple(g.alphas)
+
+    def invalidate(self):
+        self.epoch += 1
+
+    def get(self, downs, ups, alphas, K):
+        key = tuple(id(p) for p in downs) + tuple(id(p) for p in ups)
+        g = self.groups.get(key)
+        if g is None:
+            g = _PackGroup()
+            g.downs, g.ups, g.alphas, g.K = tuple(downs), tuple(ups), tuple(alphas), K
+            N = sum(u.shape[0] for u in ups)
+            dev, dt = self.device, self.dtype
+            pad = ops.MOS_LORA_PAD
+            g.bufs = (torch.empty((pad, K), dtype=dt, device=dev), torch.empty((K, pad), dtype=dt, device=dev),
+                      torch.empty((N, pad), dtype=dt, device=dev), torch.empty((pad, N), dtype=dt, device=dev))
+            g.elems = pad * max(K, N)
+            g.vers, g.epoch = None, -1
+            g.desc = None
+            self.groups[key] = g
+            self.desc_dev = None
+        else:
+            g.alphas = tuple(alphas)
+        if g.vers != self._vers(g):
+            self.epoch += 1                      # something changed since the last pack: everything is repacked once
+        if g.epoch != self.epoch:
+            self._pack_all()
+        return g.bufs
+
+    def _pack_all(self):
+        import ctypes
+        from . import lib as _lib
+        gs = list(self.groups.values())
+        stale = self.desc_dev is None
+        for g in gs:
+            v = self._vers(g)
+            if g.desc is None or g.vers is None or v[len(g.downs) + len(g.ups):] != g.vers[len(g.downs) + len(g.ups):]:
+                g.desc = ops.lora_group_desc(g.downs, g.ups, g.alphas, g.K, *g.bufs)   # pointers / alphas changed
+                stale = True
+            g.vers = v
+            g.epoch = self.epoch
+        if stale:
+            arr = (_lib.LoraGroup * len(gs))(*[g.desc for g in gs])
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+            self.desc_dev = host.to(self.device)
+            self.max_elems = max(g.elems for g in gs)
+        ops.lora_pack_all(self.desc_dev, len(gs), self.max_elems, self.dtype)
+
+
+_registries = {}
+
+
+def lora_registry(device, dtype):
+    key = (device.type, device.index, dtype)
+    r = _registries.get(key)
+    if r is None:
+        r = LoraPackRegistry(device, dtype)
+        _registries[key] = r
+    return r
+
+
+def invalidate_lora_packs():
+    """Force a repack at the next use (call before capturing a step into a hipGraph)."""
+    for r in _registries.values():
+        r.invalidate()
+
+
+def _lora_operands(downs, ups, alphas, K, dtype, device):
+    ok = device.type == 'cuda' and all(p.dtype == torch.float32 and p.is_contiguous() for p in (*downs, *ups))
+    if ok:
+        return lora_registry(device, dtype).get(downs, ups, alphas, K)
+    return ops.lora_pack(downs, ups, alphas, K, dtype, device)     # per-call packing (host tests / odd layouts)
+
+
 class _LoRALinear(torch.autograd.Function):
 
     @staticmethod
@@ -84,20 +191,20 @@ class _LoRALinear(torch.autograd.Function):
         if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
             x2 = x2.contiguous()
         n_sites = len(params) // 2
+        need_grad = any(ctx.needs_input_grad)
         if n_sites:
             downs, ups = params[0::2], params[1::2]
-            A16, A16T, Bp16, BpT = ops.lora_pack(downs, ups, alphas, K, cd, x2.device)
-            t = ops.lora_down(x2, A16)
-            y = ops.linear_fwd(x2, W16, t, Bp16, bias32)
+            A16, A16T, Bp16, BpT = _lora_operands(downs, ups, alphas, K, cd, x2.device)
+            y, t = ops.linear_fused_fwd(x2, W16, A16, Bp16, bias32, need_t=need_grad)
             ctx.save_for_backward(x2, t, A16T, BpT, Wt16)
+            ctx.params = params if need_grad else None
         else:
             y = ops.linear_fwd(x2, W16, None, None, bias32)
             ctx.save_for_backward(x2, None, None, None, Wt16)
+            ctx.params = None
         ctx.alphas = alphas
         ctx.n_sites = n_sites
-        ctx.site_rows = [p.shape[0] for p in params[1::2]]
         ctx.rank = params[0].shape[0] if n_sites else 0
-        ctx.param_shapes = [p.shape for p in params]
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
         return y.view(*x.shape[:-1], N)
 
@@ -111,24 +218,33 @@ class _LoRALinear(torch.autograd.Function):
         if dy2.stride(1) != 1 or dy2.stride(0) % 8 != 0:
             dy2 = dy2.contiguous()
         need_dx = ctx.needs_input_grad[0]
-        need_lora = ctx.n_sites > 0 and any(ctx.needs_input_grad[5:])
         if need_dx and Wt16 is None:
             raise RuntimeError('mixofshow.hip: backward to the input needs the transposed weight (Wt16)')
-        dx, dA16, dBpT = ops.linear_bwd(dy2, x2, Wt16, t, A16T, BpT, need_dx=need_dx, need_lora=need_lora,
-                                        lora_cols=max(1, ctx.n_sites * ctx.rank))
-        grads = []
-        if ctx.n_sites:
-            r = ctx.rank
-            n0 = 0
-            for g in range(ctx.n_sites):
-                n_g = ctx.site_rows[g]
-                if need_lora:
-                    gd = dA16[g * r:(g + 1) * r].reshape(ctx.param_shapes[2 * g])
-                    gu = (dBpT[g * r:(g + 1) * r, n0:n0 + n_g].t() * ctx.alphas[g]).reshape(ctx.param_shapes[2 * g + 1])
-                    grads += [gd, gu.contiguous()]
-                else:
-                    grads += [None, None]
-                n0 += n_g
+        grads = [None] * (2 * ctx.n_sites)
+        if ctx.n_sites == 0:
+            dx = ops.linear_bwd(dy2, x2, Wt16, None, None, None, need_dx=need_dx, need_lora=False)[0]
+        else:
+            targets = None
+            if any(ctx.needs_input_grad[5:]):
+                targets = []
+                for g in range(ctx.n_sites):
+                    pair, accs = [], []
+                    for q in (2 * g, 2 * g + 1):
+                        p = ctx.params[q]
+                        if not ctx.needs_input_grad[5 + q]:
+                            pair.append(None)
+                            accs.append(False)
+                        elif (_direct_grad and p.grad is not None and p.grad.dtype == torch.float32
+                              and p.grad.is_contiguous() and p.grad.shape == p.shape):
+                            pair.append(p.grad)          # accumulated in place by the kernel; autograd gets None
+                            accs.append(True)
+                        else:
+                            gt = torch.empty(p.shape, dtype=torch.float32, device=dy2.device)
+                            grads[q] = gt
+                            pair.append(gt)
+                            accs.append(False)
+                    targets.append((pair[0], pair[1], ctx.alphas[g], ctx.params[2 * g + 1].shape[0], accs[0], accs[1]))
+            dx = ops.linear_fused_bwd(dy2, x2, Wt16, t, A16T, BpT, targets, ctx.rank, need_dx=need_dx)
         if dx is not None:
             dx = dx.view(ctx.x_shape)
             if dx.dtype != ctx.x_dtype:

@@ -40,6 +40,25 @@ class LoraSites(ctypes.Structure):
     ]
 
 
+class LoraGroup(ctypes.Structure):
+    _fields_ = [('s', LoraSites), ('A16', ctypes.c_void_p), ('A16T', ctypes.c_void_p), ('Bp16', ctypes.c_void_p),
+                ('BpT', ctypes.c_void_p)]
+
+
+class LoraGradOut(ctypes.Structure):
+    _fields_ = [
+        ('n_sites', ctypes.c_int),
+        ('rank', ctypes.c_int),
+        ('down_grad', ctypes.c_void_p * 4),
+        ('up_grad', ctypes.c_void_p * 4),
+        ('alpha', ctypes.c_float * 4),
+        ('n_begin', ctypes.c_int * 4),
+        ('n_rows', ctypes.c_int * 4),
+        ('accumulate_down', ctypes.c_int * 4),
+        ('accumulate_up', ctypes.c_int * 4),
+    ]
+
+
 class AttnShape(ctypes.Structure):
     _fields_ = [
         ('B', ctypes.c_int), ('H', ctypes.c_int), ('Nq', ctypes.c_int), ('Nkv', ctypes.c_int), ('d', ctypes.c_int),
@@ -81,6 +100,10 @@ SIGNATURES = {
                              ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_double),
                              ctypes.POINTER(ctypes.c_double)]),
     'mos_lora_pack': (_i, [ctypes.POINTER(LoraSites), _i, _vp, _vp, _vp, _vp, _vp]),
+    'mos_lora_pack_all': (_i, [_vp, _i, _i, _i, _vp]),
+    'mos_lora_linear_fused_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
+    'mos_lora_linear_fused_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
+                                       ctypes.POINTER(LoraGradOut), _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'mos_lora_down': (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
     'mos_lora_linear_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     'mos_lora_bwd_workspace_bytes': (_i64, [_i, _i, _i]),

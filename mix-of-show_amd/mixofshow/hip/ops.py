@@ -86,6 +86,108 @@ def lora_pack(downs, ups, alphas, K, dtype, device):
     return A16, A16T, Bp16, BpT
 
 
+def lora_group_desc(downs, ups, alphas, K, A16, A16T, Bp16, BpT):
+    """ctypes descriptor (mos_lora_group) of one fused-projection group; `downs`/`ups` are the fp32 master tensors
+    (they must stay alive and in place: the descriptor holds raw pointers)."""
+    n_sites = len(downs)
+    r = downs[0].shape[0]
+    if r > MOS_LORA_PAD:
+        raise ValueError(f'LoRA rank {r} is not supported by the fused HIP path: the rank dimension is one '
+                         f'{MOS_LORA_PAD}-wide MFMA operand (rank <= {MOS_LORA_PAD}); see INTEGRATION.md')
+    if not (1 <= n_sites <= 4 and n_sites * r <= MOS_LORA_PAD):
+        raise ValueError(f'{n_sites} LoRA sites of rank {r} do not fit one packed rank-{MOS_LORA_PAD} operand')
+    g = _lib.LoraGroup()
+    g.s.n_sites, g.s.rank, g.s.K = n_sites, r, K
+    n0 = 0
+    for i in range(n_sites):
+        d, u = downs[i], ups[i]
+        assert d.dtype == torch.float32 and u.dtype == torch.float32 and d.is_contiguous() and u.is_contiguous()
+        g.s.down[i], g.s.up[i] = d.data_ptr(), u.data_ptr()
+        g.s.alpha[i] = float(alphas[i])
+        g.s.n_begin[i] = n0
+        g.s.n_rows[i] = u.shape[0]
+        n0 += u.shape[0]
+    g.s.N = n0
+    g.A16, g.A16T, g.Bp16, g.BpT = A16.data_ptr(), A16T.data_ptr(), Bp16.data_ptr(), BpT.data_ptr()
+    return g
+
+
+def lora_pack_all(groups_dev, n_groups, max_elems, dtype):
+    """Pack every registered LoRA group in one launch. groups_dev: uint8 device tensor holding the mos_lora_group array."""
+    _dev(groups_dev)
+    L = _lib.load()
+    _lib.check(L.mos_lora_pack_all(_p(groups_dev), int(n_groups), int(max_elems), _DT[dtype], _stream()),
+               'mos_lora_pack_all')
+
+
+_grad_counters = {}
+
+
+def _counters(device):
+    c = _grad_counters.get(device)
+    if c is None:
+        c = torch.zeros(256, dtype=torch.int32, device=device)     # zeroed once; the kernel resets what it uses
+        _grad_counters[device] = c
+    return c
+
+
+def linear_fused_fwd(x, W, A16, Bp16, bias=None, need_t=True):
+    """y[M,N] = x . W^T + (x . A16^T) . Bp16^T (+ bias) in ONE kernel; returns (y, t[M,16] | None)."""
+    _dev(x, W, A16, Bp16, bias)
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and W.dtype == x.dtype and A16.shape == (MOS_LORA_PAD, K) and Bp16.shape == (N, MOS_LORA_PAD)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    t = torch.empty((M, MOS_LORA_PAD), dtype=x.dtype, device=x.device) if need_t else None
+    L = _lib.load()
+    _lib.check(L.mos_lora_linear_fused_fwd(_p(x), _rows(x), _p(W), _rows(W), _p(A16), _p(Bp16), _p(bias), _p(y), _rows(y),
+                                           _p(t), M, N, K, _dt(x), _stream()), 'mos_lora_linear_fused_fwd')
+    return y, t
+
+
+def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True):
+    """Backward of linear_fused_fwd in two launches. grad_targets: None (LoRA factors frozen) or a list with one
+    (down_grad, up_grad, alpha, n_rows, accumulate_down, accumulate_up) per site — fp32 contiguous tensors shaped like the parameters (either
+    may be None); the kernel writes / accumulates into them directly. Returns dx | None."""
+    _dev(dy, x, Wt, t, A16T, BpT)
+    M, N = dy.shape
+    K = x.shape[1]
+    dev = dy.device
+    dx = torch.empty((M, K), dtype=dy.dtype, device=dev) if need_dx else None
+    dt = torch.empty((M, MOS_LORA_PAD), dtype=dy.dtype, device=dev)
+    L = _lib.load()
+    g = None
+    ws = None
+    cols = 0
+    if grad_targets:
+        g = _lib.LoraGradOut()
+        g.n_sites = len(grad_targets)
+        n0 = 0
+        for i, (dg, ug, alpha, n_rows, acc_d, acc_u) in enumerate(grad_targets):
+            for tg in (dg, ug):
+                assert tg is None or (tg.dtype == torch.float32 and tg.is_contiguous() and tg.is_cuda)
+            assert dg is None or dg.numel() == rank * K
+            assert ug is None or ug.numel() == rank * int(n_rows)
+            g.rank = int(rank)
+            g.down_grad[i] = dg.data_ptr() if dg is not None else None
+            g.up_grad[i] = ug.data_ptr() if ug is not None else None
+            g.alpha[i] = float(alpha)
+            g.n_begin[i], g.n_rows[i] = n0, int(n_rows)
+            g.accumulate_down[i], g.accumulate_up[i] = int(bool(acc_d)), int(bool(acc_u))
+            n0 += int(n_rows)
+        assert n0 == N
+        cols = g.n_sites * g.rank
+        ws = torch.empty((L.mos_lora_bwd_workspace_bytes(M, N, K) + 3) // 4, dtype=torch.float32, device=dev)
+    _lib.check(L.mos_lora_linear_fused_bwd(_p(dy), _rows(dy), _p(x), _rows(x), _p(Wt), _rows(Wt) if Wt is not None else 0,
+                                           _p(t), _p(A16T), _p(BpT), _p(dt), _p(dx), _rows(dx) if dx is not None else 0,
+                                           ctypes.byref(g) if g is not None else None, _p(ws),
+                                           _p(_counters(dev)) if g is not None else None, M, N, K, int(cols), _dt(dy),
+                                           _stream()), 'mos_lora_linear_fused_bwd')
+    return dx
+
+
 def lora_down(x, A16):
     """t[M,16] = x[M,K] . A16^T"""
     _dev(x, A16)

@@ -33,6 +33,9 @@ class TrainEngine:
             self.optimizer = torch.optim.AdamW(groups, **optim_cfg, foreach=True)
         self.base_lrs = [g['lr'] for g in self.optimizer.param_groups]
         self.bucket = dp.FlatGradBucket(trainer.trainable_parameters())
+        # the LoRA backward kernel accumulates straight into the bucket's `.grad` views (no per-parameter glue kernels)
+        from mixofshow.hip import functional as F_hip
+        F_hip.set_direct_grad_accumulation(True)
         self.mixed_precision = mixed_precision
         self.amp_dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(mixed_precision)
         self.scaler = torch.amp.GradScaler('cuda', enabled=(mixed_precision == 'fp16' and dev.type == 'cuda'))
@@ -109,6 +112,8 @@ class TrainEngine:
             for _ in range(warmup):
                 fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
+        from mixofshow.hip import functional as F_hip
+        F_hip.invalidate_lora_packs()          # the one-launch repack of all LoRA operands must be part of the graph
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self._static_loss = fwd_bwd()

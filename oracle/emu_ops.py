@@ -7,7 +7,7 @@ Emulations compute in fp32 from the (possibly half) inputs and round the result 
 """
 import torch
 
-EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
+EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
             'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd')
 PAD = 16
 
@@ -43,6 +43,35 @@ def linear_fwd(x, W, t=None, Bp16=None, bias=None, out=None):
         out.copy_(y)
         return out
     return y
+
+
+def linear_fused_fwd(x, W, A16, Bp16, bias=None, need_t=True):
+    """mos_lora_linear_fused_fwd: t = x A16^T accumulated in fp32, ROUNDED to the half type, then y as linear_fwd."""
+    t = (x.float() @ A16.float().t()).to(x.dtype)
+    return linear_fwd(x, W, t, Bp16, bias), (t if need_t else None)
+
+
+def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True):
+    """mos_lora_linear_fused_bwd: dt = dy BpT^T (rounded), dx = dy Wt^T + dt A16T^T, factor gradients written /
+    accumulated straight into the per-site fp32 targets (alpha folded into the up gradient)."""
+    dyf = dy.float()
+    dt = (dyf @ BpT.float().t()).to(dy.dtype)
+    dx = None
+    if need_dx:
+        dx = (dyf @ Wt.float().t() + dt.float() @ A16T.float().t()).to(dy.dtype)
+    if grad_targets:
+        dA = dt.float().t() @ x.float()          # (16, K)
+        dB = t.float().t() @ dyf                 # (16, N)
+        n0 = 0
+        for g, (dg, ug, alpha, n_rows, acc_d, acc_u) in enumerate(grad_targets):
+            if dg is not None:
+                v = dA[g * rank:(g + 1) * rank].reshape(dg.shape)
+                dg.copy_(dg + v if acc_d else v)
+            if ug is not None:
+                v = (alpha * dB[g * rank:(g + 1) * rank, n0:n0 + n_rows].t()).reshape(ug.shape)
+                ug.copy_(ug + v if acc_u else v)
+            n0 += n_rows
+    return dx
 
 
 def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True, lora_cols=16):

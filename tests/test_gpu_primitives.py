@@ -101,6 +101,95 @@ def test_lora_linear_fwd_bwd(ops, emu, dtype, M, N, K, sites):
     _check('linear_bwd_plain.dx', dx2, emu.linear_bwd(dy, x, Wt, None, None, None)[0], dtype)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K,sites', [
+    (16384, 960, 320, [320, 320, 320]),   # L0 fused qkv, B=4            (128 x 64 tiles)
+    (16384, 320, 320, [320]),             # L0 out-proj
+    (308, 640, 768, [320, 320]),          # cross K/V on 4x77 text tokens (ragged M, 64 x 64 tiles)
+    (4096, 1920, 640, [640, 640, 640]),   # L1 fused qkv                 (128 x 128 tiles)
+    (4096, 640, 640, [640]),              # L1 out-proj                  (64 x 128 tiles)
+    (1024, 1280, 1280, [1280]),           # L2                           (64 x 64 tiles)
+    (256, 1280, 1280, [1280]),            # L3
+    (100, 320, 320, [320]),               # ragged tile
+    (4928, 2304, 768, [768, 768, 768]),   # CLIP fused q/k/v on 64x77 tokens
+    (72, 328, 200, [328]),                # K % 64 != 0: the column-masked variant
+])
+def test_lora_linear_fused_fwd_bwd(ops, emu, dtype, M, N, K, sites):
+    """One-launch forward (down projection fused into the GEMM) and two-launch backward (dx+dt, then both factor
+    gradients written straight into per-site fp32 targets, with and without accumulation) vs the emulation."""
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(1)
+    x = torch.randn(M, K, generator=g).to(dev, dtype)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev, dtype)
+    bias = (torch.randn(N, generator=g) * 0.1).to(dev)
+    downs, ups = _lora_factors(sites, 4, K, dev, 2)
+    alphas = [1.0, 0.7, 0.3][:len(sites)]
+    A16, A16T, Bp16, BpT = ops.lora_pack(downs, ups, alphas, K, dtype, dev)
+    y, t = ops.linear_fused_fwd(x, W, A16, Bp16, bias)
+    y_ref, t_ref = emu.linear_fused_fwd(x, W, A16, Bp16, bias)
+    _check(f'fused_fwd.t[{M}x{K}]', t, t_ref, dtype)
+    _check(f'fused_fwd.y[{M}x{N}x{K}]', y, y_ref, dtype)
+    dy = torch.randn(M, N, generator=g).to(dev, dtype)
+    Wt = W.t().contiguous()
+
+    def targets(fill, acc):
+        out = []
+        for d, u, a in zip(downs, ups, alphas):
+            out.append((torch.full_like(d, fill), torch.full_like(u, fill), a, u.shape[0], acc, acc))
+        return out
+
+    for fill, acc in ((float('nan'), False), (0.25, True)):      # overwrite must ignore what is there; accumulate adds
+        tg, tr = targets(fill, acc), targets(fill, acc)
+        dx = ops.linear_fused_bwd(dy, x, Wt, t_ref, A16T, BpT, tg, 4)
+        dx_r = emu.linear_fused_bwd(dy, x, Wt, t_ref, A16T, BpT, tr, 4)
+        _check('fused_bwd.dx', dx, dx_r, dtype)
+        for i, (a, b) in enumerate(zip(tg, tr)):
+            _check(f'fused_bwd.down_grad[{i}] acc={acc}', a[0], b[0], dtype, ulps=2.0)
+            _check(f'fused_bwd.up_grad[{i}] acc={acc}', a[1], b[1], dtype, ulps=2.0)
+    # determinism of the in-kernel ordered reduction: bit-identical on a second launch
+    t1, t2 = targets(0.0, False), targets(0.0, False)
+    ops.linear_fused_bwd(dy, x, Wt, t_ref, A16T, BpT, t1, 4)
+    ops.linear_fused_bwd(dy, x, Wt, t_ref, A16T, BpT, t2, 4)
+    for a, b in zip(t1, t2):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # frozen factors: only dx (and dt) are produced; one site's targets missing
+    dx3 = ops.linear_fused_bwd(dy, x, Wt, t_ref, A16T, BpT, None, 4)
+    _check('fused_bwd.dx (frozen LoRA)', dx3, dx_r, dtype)
+    part = targets(0.0, False)
+    part[0] = (None, part[0][1], part[0][2], part[0][3], False, False)
+    ops.linear_fused_bwd(dy, x, Wt, t_ref, A16T, BpT, part, 4, need_dx=False)
+    _check('fused_bwd.up_grad (no dx, down frozen)', part[0][1], tr[0][1] - 0.25, dtype, ulps=2.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_lora_pack_all_equals_per_group_pack(ops, emu, dtype):
+    """mos_lora_pack_all (descriptor table in device memory, all groups in one launch) == mos_lora_pack per group;
+    the registry repacks after an in-place parameter update and only then."""
+    from mixofshow.hip import functional as F
+    dev = torch.device('cuda', 0)
+    specs = [([320, 320, 320], 320), ([320], 320), ([640, 640], 768), ([1280], 1280), ([768], 768)]
+    reg = F.LoraPackRegistry(dev, dtype)
+    groups = []
+    for i, (sites, K) in enumerate(specs):
+        downs, ups = _lora_factors(sites, 4, K, dev, 10 + i)
+        groups.append((downs, ups, [1.0, 0.5, 0.25][:len(sites)], K))
+    for downs, ups, alphas, K in groups:
+        reg.get(downs, ups, alphas, K)
+    for downs, ups, alphas, K in groups:
+        got = reg.get(downs, ups, alphas, K)
+        ref = ops.lora_pack(downs, ups, alphas, K, dtype, dev)
+        for a, b, n in zip(got, ref, ('A16', 'A16T', 'Bp16', 'BpT')):
+            assert torch.equal(a, b), n
+    e0 = reg.epoch
+    reg.get(*groups[0])
+    assert reg.epoch == e0                                  # nothing changed: no repack
+    groups[3][0][0].mul_(2.0)                               # optimiser-style in-place update of one down factor
+    got = reg.get(*groups[3])
+    assert reg.epoch == e0 + 1
+    assert torch.equal(got[0], ops.lora_pack(*groups[3][:3], groups[3][3], dtype, dev)[0])
+    assert torch.equal(reg.get(*groups[1])[2], ops.lora_pack(*groups[1][:3], groups[1][3], dtype, dev)[2])
+
+
 def _qkv(B, Nq, Nkv, C, dtype, seed, fused):
     g = torch.Generator(device='cpu').manual_seed(seed)
     if fused and Nq == Nkv:

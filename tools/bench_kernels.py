@@ -36,7 +36,7 @@ def attn_case(B, H, Nq, Nkv, d, dtype, iters, bwd=True, pcols=False):
             ops.attn_bwd(q, k, v, o, lse, dO, H, scale, dq, dk, dv, tok_idx=tok, pcols=pc, dpcols=dpc)
 
 
-def gemm_case(M, N, K, dtype, iters, lora=True):
+def gemm_case(M, N, K, dtype, iters, legacy=False):
     x = torch.randn(M, K, device='cuda', dtype=dtype)
     W = torch.randn(N, K, device='cuda', dtype=dtype) / math.sqrt(K)
     Wt = W.t().contiguous()
@@ -44,10 +44,16 @@ def gemm_case(M, N, K, dtype, iters, lora=True):
     ups = [torch.randn(N, 4, device='cuda') * 0.05]
     A16, A16T, Bp16, BpT = ops.lora_pack(downs, ups, [1.0], K, dtype, 'cuda')
     dy = torch.randn(M, N, device='cuda', dtype=dtype)
+    tg = [(torch.zeros_like(downs[0]), torch.zeros_like(ups[0]), 1.0, N, True, True)]
     for _ in range(iters):
-        t = ops.lora_down(x, A16)
-        ops.linear_fwd(x, W, t, Bp16)
-        ops.linear_bwd(dy, x, Wt, t, A16T, BpT, lora_cols=4)
+        y, t = ops.linear_fused_fwd(x, W, A16, Bp16)                   # product path: 1 launch forward
+        ops.linear_fused_bwd(dy, x, Wt, t, A16T, BpT, tg, 4)           # 2 launches backward
+        ops.linear_fwd(x, W)                                           # plain GEMM (no LoRA) for reference
+    if legacy:
+        for _ in range(iters):
+            t = ops.lora_down(x, A16)
+            ops.linear_fwd(x, W, t, Bp16)
+            ops.linear_bwd(dy, x, Wt, t, A16T, BpT, lora_cols=4)
 
 
 def region_case(fh, fw, d, dtype, iters):
@@ -79,6 +85,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--only', default='')
     ap.add_argument('--dtype', default='f16')
+    ap.add_argument('--legacy', type=int, default=0, help='gemm: also time the round-1 multi-launch LoRA path')
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
     cases = []
@@ -91,9 +98,10 @@ def main():
                   lambda: attn_case(2, 8, 6144, 6144, 40, dt, args.iters, bwd=False),
                   lambda: attn_case(2, 8, 1536, 1536, 80, dt, args.iters, bwd=False)]
     if args.only in ('', 'gemm'):
-        cases += [lambda: gemm_case(16384, 960, 320, dt, args.iters), lambda: gemm_case(16384, 320, 320, dt, args.iters),
-                  lambda: gemm_case(4096, 1920, 640, dt, args.iters), lambda: gemm_case(1024, 3840, 1280, dt, args.iters),
-                  lambda: gemm_case(4928, 768, 768, dt, args.iters), lambda: gemm_case(308, 640, 768, dt, args.iters)]
+        for shp in ((16384, 960, 320), (16384, 320, 320), (4096, 1920, 640), (4096, 640, 640), (1024, 3840, 1280),
+                    (1024, 1280, 1280), (256, 1280, 1280), (4928, 768, 768), (4928, 2304, 768), (4928, 768, 2304),
+                    (308, 640, 768)):
+            cases.append(lambda shp=shp: gemm_case(*shp, dt, args.iters, legacy=args.legacy))
     if args.only in ('', 'region'):
         cases += [lambda: region_case(64, 96, 40, dt, args.iters), lambda: region_case(32, 48, 80, dt, args.iters),
                   lambda: region_case(16, 24, 160, dt, args.iters)]

@@ -16,8 +16,8 @@ VARIANTS=(
   "lsum|mos_attn|-DMOS_FWD_LSUM=1|attn"                      # forward d<=80: row sums from the P.V MFMA (ones row in V^T padding)
   "dq8|mos_attn|-DMOS_DQ_NW=8|attn"                          # 8-wave dQ blocks
   "noslp|mos_attn|-fno-slp-vectorize|attn"                   # no v_pk_{mul,add}_f32 (the guide: packed f32 VALU is an anti-lever beside MFMAs)
-  "tnu|mos_gemm|-DMOS_TN_REDUCE_UNROLL=1|step"               # LoRA-gradient reduce kernel with 4 loads in flight per thread
-  "tn256|mos_gemm|-DMOS_TN_TARGET_WG=256 -DMOS_TN_REDUCE_UNROLL=1|step"   # fewer, longer chunks
+  "g512|mos_gemm|-DMOS_GRAD_TARGET_WG=512|step"              # fused LoRA-gradient kernel: fewer, longer token chunks
+  "g2048|mos_gemm|-DMOS_GRAD_TARGET_WG=2048|step"            # ... more, shorter chunks
 )
 SHAPES="Nq4096 Nkv4096\|d80 B4 H8 Nq1024 Nkv1024\|B2 H8"
 case "${1:-}" in
