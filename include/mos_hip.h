@@ -122,13 +122,12 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
                         void* dt, void* dx, int64_t lddx, float* dA16, float* dBpT,
                         void* ws, int M, int N, int K, int lora_cols, int dtype, void* stream);
 
-/* Fused backward: launch 1 = dx (with dt = dy . BpT^T produced in the same kernel, written to dt); launch 2 = both
- * factor gradients, reduced over tokens and written STRAIGHT into the fp32 parameter gradients:
+/* Fused backward: launch 1 = dx (with dt = dy . BpT^T produced in the same kernel, written to dt); launches 2+3 = both
+ * factor gradients, reduced over tokens (one launch for both) and summed in chunk order (deterministic) STRAIGHT into
+ * the fp32 parameter gradients:
  *   down_grad[g][r, K]      (+)= (dt^T x)[g*r .. g*r+r-1, :]
  *   up_grad[g][n_rows, r]   (+)= alpha_g * (t^T dy)[g*r .. , n_begin .. n_begin+n_rows)^T
  * (NULL pointers are skipped; accumulate_* = 1 adds to what is there — gradient buckets, micro-batches).
- * The final sum over token chunks is done in chunk order by the last block of each column block: deterministic.
- * counters: >= 128 int32, zeroed ONCE by the caller (self-resetting), not shared between concurrent streams.
  * ws: mos_lora_bwd_workspace_bytes(M,N,K) bytes. dx may be NULL; grads_host may be NULL (only dt / dx wanted). */
 typedef struct {
     int n_sites, rank;
@@ -144,7 +143,7 @@ int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64
                               const void* Wt, int64_t ldwt, const void* t,
                               const void* A16T, const void* BpT,
                               void* dt, void* dx, int64_t lddx,
-                              const mos_lora_grad_out* grads_host, void* ws, int* counters,
+                              const mos_lora_grad_out* grads_host, void* ws,
                               int M, int N, int K, int lora_cols, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -24,27 +24,12 @@
 #include <type_traits>
 #include "mos_common.h"
 
-// tuning knobs of the backward kernels (tools/build_variant.sh overrides them for experiments)
+// Tuning history (measured on MI355X, profiles/r02_attention_variants.txt): the forward takes its softmax row sums from
+// the P.V MFMA (ones row in the V^T padding, -8 % at d = 40); software-pipelined dK/dV drafts (+37..+44 %), statistics folded
+// into the pad columns (+-0), 8-wave dQ blocks (+47 %), wave-slot staggering and -fno-slp-vectorize (+-0) were measured and
+// removed. MOS_DQ_OCC stays a knob (tools/build_variant.sh).
 #ifndef MOS_DQ_OCC
 #define MOS_DQ_OCC 2
-#endif
-#ifndef MOS_DQ_NW
-#define MOS_DQ_NW 4
-#endif
-#ifndef MOS_STAGGER
-#define MOS_STAGGER 0   // 1: odd wave slots run at priority 1; 2: odd wave slots start ~half a tile late
-#endif
-#ifndef MOS_FWD_LSUM
-#define MOS_FWD_LSUM 0    // 1 (experimental, d <= 80): softmax row sums come out of the P.V MFMA (ones row in V^T's padding)
-#endif
-#ifndef MOS_DKDV_FOLD
-#define MOS_DKDV_FOLD 0   // 1 (experimental, d = 40): -lse/scale and -D ride in the free pad columns 40..42 of the Q / dO tiles
-#endif
-#ifndef MOS_DKDV_LDS_PAD
-#define MOS_DKDV_LDS_PAD 0   // experiment: extra dynamic LDS per block (forces one block per CU)
-#endif
-#ifndef MOS_DKDV_NW
-#define MOS_DKDV_NW 4
 #endif
 
 namespace {
@@ -143,20 +128,6 @@ __device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r 
 // issues about one instruction per 4 cycles, so this bookkeeping is paid in MFMA issue slots). A plain
 // `cond ? load : 0` would also make hipcc branch around the load and wait vmcnt(0) right after it, serialising
 // the prefetch behind the MFMAs it is supposed to overlap (cdna guide, ".s-level traps" (c)).
-// Two workgroups share a CU (two waves per SIMD) and run the same MFMA-run / VALU-run program: started together
-// and arbitrated round-robin they stay in lockstep, both asking for the MFMA pipe, then both for the VALU, and
-// the pipes never overlap. Breaking the symmetry between the two wave slots of a SIMD lets one wave's MFMA run
-// cover the other's exp/convert phase.
-__device__ __forceinline__ void desync_wave_slots() {
-#if MOS_STAGGER
-    const uint32_t slot = __builtin_amdgcn_s_getreg(0x1804) ;   // HW_ID[3:0] = wave slot within the SIMD
-#if MOS_STAGGER == 1
-    if (slot & 1) __builtin_amdgcn_s_setprio(1);
-#else
-    if (slot & 1) { __builtin_amdgcn_s_sleep(16); }   // 16 x 64 clk
-#endif
-#endif
-}
 // bytes of a token-major slice: n rows of D contiguous elements, row stride rs elements (other heads in between)
 template <typename T, int D>
 __device__ __forceinline__ uint32_t slice_bytes(int n, int64_t rs) {
@@ -410,7 +381,7 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
 
     zero_row_pads<T, D>(Ks, tid); zero_row_pads<T, D>(Ks + HD<D>::ROW_TILE_ELEMS, tid);
     zero_tr_pads<T, D>(Vt, tid); zero_tr_pads<T, D>(Vt + HD<D>::TR_TILE_ELEMS, tid);
-    constexpr bool LSUM = (MOS_FWD_LSUM != 0) && HD<D>::DV > D;
+    constexpr bool LSUM = HD<D>::DV > D;    // d = 40, 80: a free padding row exists
     if constexpr (LSUM) {      // row D of both V^T buffers = 1 for every key (keys past Nkv have p = 0 anyway)
         __syncthreads();       // after the zero fill of the padding rows (other threads' words)
         if (tid < KV_TILE) {
@@ -573,7 +544,6 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, int64_t o_bs, int6
 template <typename T, int D, bool PCOLS, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MOS_DQ_OCC : D <= 80 ? 2 : 1))) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     constexpr int NT = 64 * NW;
-    desync_wave_slots();
     constexpr bool PIN = D <= 80 && NW == 4;   // explicit fragment prefetch where the registers allow it
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
@@ -718,7 +688,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MO
 template <typename T, int D, bool PCOLS, int NW>
 __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 : 1))) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
     constexpr int NT = 64 * NW;
-    desync_wave_slots();
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -751,16 +720,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
     load_row_frags<T, D>(kf, (const T*)a.k + (int64_t)b * a.k_bs + (int64_t)kc * a.k_rs + h * D, kvalid, hh);
     load_row_frags<T, D>(vf, (const T*)a.v + (int64_t)b * a.v_bs + (int64_t)kc * a.v_rs + h * D, kvalid, hh);
     const float c = a.scale * LOG2E;
-    // FOLD (d = 40: the contraction is padded 40 -> 48): the query side carries -lse/scale (resp. -D) split over three
-    // half-precision pad columns 40..42, the key side carries 1 there, so the MFMA itself delivers q.k - lse/scale and
-    // dO.v - D: no per-tile statistics reads from LDS, one VALU op less per pair, 32 registers less.
-    constexpr bool FOLD = (MOS_DKDV_FOLD != 0) && D == 40;
-    if constexpr (FOLD) {
-        if (hh == 1) {                       // lanes with hh = 1 hold columns 40..47 in fragment ks = 2
-#pragma unroll
-            for (int e = 0; e < 3; ++e) { kf[KS - 1][e] = (T)1.0f; vf[KS - 1][e] = (T)1.0f; }
-        }
-    }
     int mytok = -1;  // index t of the exported column this lane's key corresponds to, if any
     if constexpr (PCOLS) {
 #pragma unroll
@@ -810,20 +769,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
         if (tid < KV_TILE) {
             float* sb = stat_ + bf * ST;
             const bool ok = tid < st_nv;
-            if constexpr (FOLD) {
-                auto split3 = [](float x, T* dst) {     // x = hi + mid + lo in T (24 significant bits), 4th = 0
-                    const T hi = (T)x;
-                    const float r1 = x - (float)hi;
-                    const T mid = (T)r1;
-                    const T lo = (T)(r1 - (float)mid);
-                    dst[0] = hi; dst[1] = mid; dst[2] = lo; dst[3] = (T)0.0f;
-                };
-                split3(ok ? -st_lse / a.scale : 0.f, Qs_ + bf * RT + tid * RS + D);
-                split3(ok ? -st_D : 0.f, dOs_ + bf * RT + tid * RS + D);
-            } else {
-                sb[tid] = ok ? st_lse * LOG2E : 0.f;
-                sb[KV_TILE + tid] = ok ? st_D : 0.f;
-            }
+            sb[tid] = ok ? st_lse * LOG2E : 0.f;
+            sb[KV_TILE + tid] = ok ? st_D : 0.f;
             if constexpr (PCOLS) {
 #pragma unroll
                 for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
@@ -865,13 +812,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
                 aq[ks] = as_v8<T>(ld16(Qs + off));
                 ado[ks] = as_v8<T>(ld16(dOs + off));
             }
-            if constexpr (!FOLD) {
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int ql = 32 * t + 8 * r4 + 4 * hh;
-                    l4[r4] = *reinterpret_cast<const f32x4*>(lse_s + ql);
-                    d4[r4] = *reinterpret_cast<const f32x4*>(D_s + ql);
-                }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int ql = 32 * t + 8 * r4 + 4 * hh;
+                l4[r4] = *reinterpret_cast<const f32x4*>(lse_s + ql);
+                d4[r4] = *reinterpret_cast<const f32x4*>(D_s + ql);
             }
         };
         read_rows(0);
@@ -904,14 +849,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
                     // keys past Nkv (lanes of the last key block) need no masking: each lane's key is one column of
                     // dK^T / dV^T, columns never mix, and the store skips invalid keys
                     float p, g = dp[r];
-                    if constexpr (FOLD) p = __builtin_amdgcn_exp2f(s[r] * c);       // s already holds q.k - lse/scale
-                    else p = __builtin_amdgcn_exp2f(s[r] * c - l4[r4][rr]);
+                    p = __builtin_amdgcn_exp2f(s[r] * c - l4[r4][rr]);
                     if constexpr (PCOLS) {
                         if (mytok >= 0) g += dpc_s[(32 * t + 8 * r4 + 4 * hh + rr) * MOS_MAX_PCOLS + mytok];
                     }
                     s[r] = p;
-                    if constexpr (FOLD) dp[r] = p * g;                              // dp already holds dO.v - D
-                    else dp[r] = p * (g - d4[r4][rr]);
+                    dp[r] = p * (g - d4[r4][rr]);
                 }
             }
             v8 pf[2], dsf[2];
@@ -982,16 +925,6 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part, int nspli
 
 // ---- host dispatch -----------------------------------------------------------------------------
 template <int D> constexpr int fwd_qw() { return D <= 80 ? 64 : 32; }
-
-#ifndef MOS_DKDV_V2
-#define MOS_DKDV_V2 0   // 1: dispatch the experimental software-pipelined dK/dV kernel at d = 40 (mos_attn_dkdv_v2.inc)
-#endif
-#ifndef MOS_DKDV_V2_NK
-#define MOS_DKDV_V2_NK 1
-#endif
-#if MOS_DKDV_V2
-#include "mos_attn_dkdv_v2.inc"
-#endif
 
 template <int D> constexpr size_t fwd_lds(size_t es) { return 2 * (HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
 template <int D> constexpr size_t dq_lds(size_t es) { return 2 * (2 * HD<D>::ROW_TILE_ELEMS + HD<D>::TR_TILE_ELEMS) * es; }
@@ -1098,8 +1031,8 @@ int launch_region(const void* q, const void* k, const void* v, void* o, const mo
     return mos_check_launch("region_attn");
 }
 
-constexpr int DQ_NW = MOS_DQ_NW, DKDV_NW = MOS_DKDV_NW;   // waves per block of the wide d = 40 variants
-struct BwdPlan { int nw_q, nw_k, nqb, nkb, nsplit, q_per_split; bool v2; };
+constexpr int DQ_NW = 4, DKDV_NW = 4;   // waves per block (8-wave dQ blocks measured +47 % slower at d = 40)
+struct BwdPlan { int nw_q, nw_k, nqb, nkb, nsplit, q_per_split; };
 // waves per block of the backward kernels: 8 where the register budget allows four waves per SIMD (d = 40) and the
 // grid still holds >= 512 blocks of 256 rows; 4 otherwise
 BwdPlan plan_bwd(const mos_attn_shape* s) {
@@ -1109,15 +1042,6 @@ BwdPlan plan_bwd(const mos_attn_shape* s) {
     p.nw_k = (s->d == 40 && bh * ((s->Nkv + 32 * DKDV_NW - 1) / (32 * DKDV_NW)) >= 512) ? DKDV_NW : 4;
     p.nqb = (s->Nq + 32 * p.nw_q - 1) / (32 * p.nw_q);
     p.nkb = (s->Nkv + 32 * p.nw_k - 1) / (32 * p.nw_k);
-    p.v2 = false;
-#if MOS_DKDV_V2 == 1 || MOS_DKDV_V2 == 2
-    constexpr int V2_KEYS = 128 * MOS_DKDV_V2_NK;           // keys per 4-wave block
-    if (s->d == 40 && bh * ((s->Nkv + V2_KEYS - 1) / V2_KEYS) >= 256) {
-        p.v2 = true;
-        p.nw_k = 4;
-        p.nkb = (s->Nkv + V2_KEYS - 1) / V2_KEYS;
-    }
-#endif
     const int64_t base = (int64_t)p.nkb * s->B * s->H;
     const int qtiles = (s->Nq + KV_TILE - 1) / KV_TILE;
     int ns = (int)((512 + base - 1) / base);
@@ -1184,33 +1108,10 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     }
     {
         const dim3 grid((unsigned)(a.H * a.nkb * a.B), (unsigned)a.nsplit);
-        const size_t lds = dkdv_lds<D>(sizeof(T)) + MOS_DKDV_LDS_PAD;
+        const size_t lds = dkdv_lds<D>(sizeof(T));
         AttnKey key(tname<T>(), s, 4.0);
         MosProfScope prof(st, "attn_bwd_dkdv", key.s, key.flops, key.bytes * 1.5);
         constexpr int NWMAX = (D == 40) ? DKDV_NW : 4;
-#if MOS_DKDV_V2 == 3
-        if (D == 40 && (int64_t)a.H * a.nkb * a.B >= 256 && p.nw_k == 4) {      // one block per CU, 128 keys per block
-            const size_t lds3 = 3 * ((2 * HD<D>::ROW_TILE_ELEMS + 2 * HD<D>::TR_TILE_ELEMS) * sizeof(T) +
-                                     KV_TILE * (2 + MOS_MAX_PCOLS) * sizeof(float));
-            if (pc) {
-                set_lds(&attn_bwd_dkdv_v3_kernel<T, true>, lds3);
-                hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<T, true>), grid, dim3(256), lds3, st, a);
-            } else {
-                set_lds(&attn_bwd_dkdv_v3_kernel<T, false>, lds3);
-                hipLaunchKernelGGL((attn_bwd_dkdv_v3_kernel<T, false>), grid, dim3(256), lds3, st, a);
-            }
-        } else
-#elif MOS_DKDV_V2
-        if (p.v2 && D == 40) {
-            if (pc) {
-                set_lds(&attn_bwd_dkdv_v2_kernel<T, true, DKDV_V2_NK>, lds);
-                hipLaunchKernelGGL((attn_bwd_dkdv_v2_kernel<T, true, DKDV_V2_NK>), grid, dim3(256), lds, st, a);
-            } else {
-                set_lds(&attn_bwd_dkdv_v2_kernel<T, false, DKDV_V2_NK>, lds);
-                hipLaunchKernelGGL((attn_bwd_dkdv_v2_kernel<T, false, DKDV_V2_NK>), grid, dim3(256), lds, st, a);
-            }
-        } else
-#endif
         if (p.nw_k > 4 && NWMAX > 4) {
             if (pc) {
                 set_lds(&attn_bwd_dkdv_kernel<T, D, true, NWMAX>, lds);

@@ -9,9 +9,9 @@
 //             the rank-16 epilogue MFMA (same lane layout), so t never leaves registers; the n-tile-0 blocks also store
 //             it for the backward.
 //   backward: dx = dy.Wt^T + (dy.BpT^T).A16T^T with dt = dy.BpT^T produced the same way (W frozen: no dW), then
-//   lora_grad: dA = dt^T x and dB = t^T dy in ONE launch (token reduction, deterministic in-kernel final sum by the last
-//             block of every column block), written straight into the fp32 parameter gradients (alpha folded,
-//             per-site slices, optional accumulate) — no per-parameter glue kernels on the host side.
+//   lora_grad: dA = dt^T x and dB = t^T dy, both in ONE token-reduction launch + one ordered (deterministic) final sum that
+//             writes straight into the fp32 parameter gradients (alpha folded, per-site slices, optional accumulate) —
+//             no per-parameter glue kernels on the host side.
 //
 // MFMA conventions (v_mfma_f32_16x16x32_{f16,bf16}; D[i][j] = sum_k A[i][k] B[k][j]):
 //   lane l supplies A[i = l&15][k = 8*(l>>4) .. +8] and B[k = 8*(l>>4) .. +8][j = l&15];
@@ -435,9 +435,8 @@ int launch_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, const vo
 
 // ---- fused LoRA factor gradients -------------------------------------------------------------------------------------
 // job 0: dA[j][c] = sum_m dt[m][j] x[m][c]   (c < K)      job 1: dB[j][n] = sum_m t[m][j] dy[m][n]   (n < N)
-// grid (nchunk, cbK + cbN): a block reduces `rpc` tokens of one 64-column block into partial[chunk]; the LAST block to
-// finish a column block (atomic ticket) sums the partials in chunk order — deterministic regardless of arrival order —
-// and writes the result either as raw 16 x C matrices (legacy API) or straight into the per-site fp32 parameter gradients.
+// grid (nchunk, cbK + cbN): a block reduces `rpc` tokens of one 64-column block into partial[chunk] (both jobs in ONE
+// launch); lora_grad_final_kernel then sums the partials in chunk order.
 // The token reduction is HBM-bound (x and dy are read once); arithmetic is NJ FMAs per loaded element on the VALU.
 struct LoraGradArgs {
     const void* P[2]; const void* Z[2];
@@ -445,7 +444,6 @@ struct LoraGradArgs {
     int C[2], cb[2];
     float* partial[2];
     float* raw[2];
-    int* counters;
     int M, rpc, nchunk;
     mos_lora_grad_out out;
 };
@@ -455,7 +453,6 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const LoraGradArgs a) {
     typedef typename MT<T>::v8 v8;
     typedef typename MT<T>::v4 v4;
     __shared__ float red[4][NJ][64];
-    __shared__ int s_last;
     const int tid = threadIdx.x;
     const int job = (int)blockIdx.y >= a.cb[0] ? 1 : 0;
     const int colblk = (int)blockIdx.y - (job ? a.cb[0] : 0);
@@ -530,16 +527,21 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const LoraGradArgs a) {
         const int col = colblk * 64 + c;
         if (col < C) part[((int64_t)blockIdx.x * NJ + j) * C + col] = red[0][j][c] + red[1][j][c] + red[2][j][c] + red[3][j][c];
     }
-    // ---- last block of this column block: ordered final sum -------------------------------------------------------------
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&a.counters[blockIdx.y], 1) == a.nchunk - 1) ? 1 : 0;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (tid == 0) a.counters[blockIdx.y] = 0;        // self-resetting: the caller zeroes the counters once, ever
+}
+
+// Final, ORDERED sum over token chunks (deterministic) of both jobs, written as raw 16 x C matrices (legacy API) or straight
+// into the per-site fp32 parameter gradients (alpha folded into the up factor, optional accumulate). A separate launch
+// on purpose: a kernel boundary makes the partials visible across the 8 XCD-private L2s for free, whereas the
+// "last block reduces" idiom needs an agent-scope release/acquire per block = an L2 write-back each (measured: 64-100 us
+// per launch instead of ~10).
+template <int NJ>
+__global__ __launch_bounds__(256) void lora_grad_final_kernel(const LoraGradArgs a) {
+    const int job = (int)blockIdx.x >= a.cb[0] ? 1 : 0;
+    const int colblk = (int)blockIdx.x - (job ? a.cb[0] : 0);
+    const int C = a.C[job];
+    const float* part = a.partial[job];
     const int r = a.out.rank;
-    for (int idx = tid; idx < MOS_LORA_PAD * 64; idx += 256) {
+    for (int idx = threadIdx.x; idx < MOS_LORA_PAD * 64; idx += 256) {
         const int j = idx >> 6, c = idx & 63;
         const int col = colblk * 64 + c;
         if (col >= C) continue;
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const LoraGradArgs a) {
             const float* pp = part + (int64_t)j * C + col;
             const int64_t cs = (int64_t)NJ * C;
             int ch = 0;
-            for (; ch + 4 <= a.nchunk; ch += 4) {
+            for (; ch + 4 <= a.nchunk; ch += 4) {   // four independent chains: the loads of a thread are in flight together
                 s0 += pp[(ch + 0) * cs];
                 s1 += pp[(ch + 1) * cs];
                 s2 += pp[(ch + 2) * cs];
@@ -596,13 +598,13 @@ inline void lora_grad_plan(int M, int N, int K, int* rpc, int* nchunk) {
 
 template <typename T>
 int launch_lora_grad(const void* dt, const void* x, int64_t ldx, const void* t, const void* dy, int64_t lddy, float* rawA,
-                     float* rawB, const mos_lora_grad_out* out, float* ws, int* counters, int M, int N, int K, int cols,
+                     float* rawB, const mos_lora_grad_out* out, float* ws, int M, int N, int K, int cols,
                      hipStream_t st) {
     LoraGradArgs a;
     a.P[0] = dt; a.Z[0] = x; a.ldz[0] = ldx; a.C[0] = K; a.cb[0] = (K + 63) / 64;
     a.P[1] = t; a.Z[1] = dy; a.ldz[1] = lddy; a.C[1] = N; a.cb[1] = (N + 63) / 64;
     a.raw[0] = rawA; a.raw[1] = rawB;
-    a.counters = counters; a.M = M;
+    a.M = M;
     lora_grad_plan(M, N, K, &a.rpc, &a.nchunk);
     const int nj = cols <= 4 ? 4 : cols <= 8 ? 8 : cols <= 12 ? 12 : 16;
     a.partial[0] = ws;
@@ -612,11 +614,16 @@ int launch_lora_grad(const void* dt, const void* x, int64_t ldx, const void* t, 
     snprintf(key, sizeof(key), "M%d K%d N%d r%d", M, K, N, nj);
     MosProfScope prof(st, "lora_grad", key, 2.0 * M * (double)nj * ((double)K + N), 2.0 * ((double)M * ((double)K + N) + 32.0 * M));
     dim3 grid(a.nchunk, a.cb[0] + a.cb[1]);
+    dim3 fgrid(a.cb[0] + a.cb[1]);
     switch (nj) {
-        case 4: hipLaunchKernelGGL((lora_grad_kernel<T, 4>), grid, dim3(256), 0, st, a); break;
-        case 8: hipLaunchKernelGGL((lora_grad_kernel<T, 8>), grid, dim3(256), 0, st, a); break;
-        case 12: hipLaunchKernelGGL((lora_grad_kernel<T, 12>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((lora_grad_kernel<T, 16>), grid, dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL((lora_grad_kernel<T, 4>), grid, dim3(256), 0, st, a);
+                hipLaunchKernelGGL((lora_grad_final_kernel<4>), fgrid, dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL((lora_grad_kernel<T, 8>), grid, dim3(256), 0, st, a);
+                hipLaunchKernelGGL((lora_grad_final_kernel<8>), fgrid, dim3(256), 0, st, a); break;
+        case 12: hipLaunchKernelGGL((lora_grad_kernel<T, 12>), grid, dim3(256), 0, st, a);
+                 hipLaunchKernelGGL((lora_grad_final_kernel<12>), fgrid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((lora_grad_kernel<T, 16>), grid, dim3(256), 0, st, a);
+                 hipLaunchKernelGGL((lora_grad_final_kernel<16>), fgrid, dim3(256), 0, st, a); break;
     }
     return mos_check_launch("lora_grad");
 }
@@ -837,13 +844,13 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
 
 int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
                               const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
-                              const mos_lora_grad_out* grads_host, void* ws, int* counters, int M, int N, int K,
+                              const mos_lora_grad_out* grads_host, void* ws, int M, int N, int K,
                               int lora_cols, int dtype, void* stream) {
     MOS_REQUIRE(dy && x && t && A16T && BpT && dt, "mos_lora_linear_fused_bwd: NULL argument");
     MOS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0,
                 "mos_lora_linear_fused_bwd: M=%d N=%d K=%d lddy=%lld ldx=%lld", M, N, K, (long long)lddy, (long long)ldx);
     MOS_REQUIRE(dx == nullptr || (Wt && lddx % 4 == 0 && ldwt % 8 == 0), "mos_lora_linear_fused_bwd: dx needs Wt");
-    MOS_REQUIRE(grads_host == nullptr || (ws && counters), "mos_lora_linear_fused_bwd: gradients need ws and counters");
+    MOS_REQUIRE(grads_host == nullptr || ws, "mos_lora_linear_fused_bwd: gradients need ws");
     MOS_REQUIRE(grads_host == nullptr || (grads_host->n_sites >= 1 && grads_host->n_sites <= 4 && grads_host->rank >= 1 &&
                                           grads_host->n_sites * grads_host->rank <= MOS_LORA_PAD &&
                                           lora_cols == grads_host->n_sites * grads_host->rank),
@@ -862,8 +869,8 @@ int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64
     }
     if (rc) return rc;
     if (grads_host == nullptr) return MOS_OK;
-    return h ? launch_lora_grad<f16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, counters, M, N, K, lora_cols, st)
-             : launch_lora_grad<bf16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, counters, M, N, K, lora_cols, st);
+    return h ? launch_lora_grad<f16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st)
+             : launch_lora_grad<bf16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st);
 }
 
 }  // extern "C"

@@ -103,7 +103,7 @@ SIGNATURES = {
     'mos_lora_pack_all': (_i, [_vp, _i, _i, _i, _vp]),
     'mos_lora_linear_fused_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     'mos_lora_linear_fused_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
-                                       ctypes.POINTER(LoraGradOut), _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+                                       ctypes.POINTER(LoraGradOut), _vp, _i, _i, _i, _i, _i, _vp]),
     'mos_lora_down': (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
     'mos_lora_linear_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     'mos_lora_bwd_workspace_bytes': (_i64, [_i, _i, _i]),

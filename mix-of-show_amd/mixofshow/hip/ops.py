@@ -120,17 +120,6 @@ def lora_pack_all(groups_dev, n_groups, max_elems, dtype):
                'mos_lora_pack_all')
 
 
-_grad_counters = {}
-
-
-def _counters(device):
-    c = _grad_counters.get(device)
-    if c is None:
-        c = torch.zeros(256, dtype=torch.int32, device=device)     # zeroed once; the kernel resets what it uses
-        _grad_counters[device] = c
-    return c
-
-
 def linear_fused_fwd(x, W, A16, Bp16, bias=None, need_t=True):
     """y[M,N] = x . W^T + (x . A16^T) . Bp16^T (+ bias) in ONE kernel; returns (y, t[M,16] | None)."""
     _dev(x, W, A16, Bp16, bias)
@@ -148,7 +137,7 @@ def linear_fused_fwd(x, W, A16, Bp16, bias=None, need_t=True):
 
 
 def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True):
-    """Backward of linear_fused_fwd in two launches. grad_targets: None (LoRA factors frozen) or a list with one
+    """Backward of linear_fused_fwd in three launches (dx+dt; token reduction of both factor gradients; ordered final sum). grad_targets: None (LoRA factors frozen) or a list with one
     (down_grad, up_grad, alpha, n_rows, accumulate_down, accumulate_up) per site — fp32 contiguous tensors shaped like the parameters (either
     may be None); the kernel writes / accumulates into them directly. Returns dx | None."""
     _dev(dy, x, Wt, t, A16T, BpT)
@@ -182,9 +171,8 @@ def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True):
         ws = torch.empty((L.mos_lora_bwd_workspace_bytes(M, N, K) + 3) // 4, dtype=torch.float32, device=dev)
     _lib.check(L.mos_lora_linear_fused_bwd(_p(dy), _rows(dy), _p(x), _rows(x), _p(Wt), _rows(Wt) if Wt is not None else 0,
                                            _p(t), _p(A16T), _p(BpT), _p(dt), _p(dx), _rows(dx) if dx is not None else 0,
-                                           ctypes.byref(g) if g is not None else None, _p(ws),
-                                           _p(_counters(dev)) if g is not None else None, M, N, K, int(cols), _dt(dy),
-                                           _stream()), 'mos_lora_linear_fused_bwd')
+                                           ctypes.byref(g) if g is not None else None, _p(ws), M, N, K, int(cols),
+                                           _dt(dy), _stream()), 'mos_lora_linear_fused_bwd')
     return dx
 
 

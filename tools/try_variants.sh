@@ -9,13 +9,7 @@
 set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 VARIANTS=(
-  "v3|mos_attn|-DMOS_DKDV_V2=3|attn"                         # three-stage NK=1 pipelined dK/dV (mos_attn_dkdv_v2.inc)
-  "v2nk1|mos_attn|-DMOS_DKDV_V2=1 -DMOS_DKDV_V2_NK=1|attn"   # two-stage pipelined dK/dV, one key group
-  "v2nk2|mos_attn|-DMOS_DKDV_V2=1 -DMOS_DKDV_V2_NK=2|attn"   # two-stage, two key groups (spills today)
-  "fold|mos_attn|-DMOS_DKDV_FOLD=1|attn"                     # dK/dV d=40: -lse/scale and -D folded into the pad columns
-  "lsum|mos_attn|-DMOS_FWD_LSUM=1|attn"                      # forward d<=80: row sums from the P.V MFMA (ones row in V^T padding)
-  "dq8|mos_attn|-DMOS_DQ_NW=8|attn"                          # 8-wave dQ blocks
-  "noslp|mos_attn|-fno-slp-vectorize|attn"                   # no v_pk_{mul,add}_f32 (the guide: packed f32 VALU is an anti-lever beside MFMAs)
+  "occ1|mos_attn|-DMOS_DQ_OCC=1|attn"                        # dQ d=40 at one block per CU
   "g512|mos_gemm|-DMOS_GRAD_TARGET_WG=512|step"              # fused LoRA-gradient kernel: fewer, longer token chunks
   "g2048|mos_gemm|-DMOS_GRAD_TARGET_WG=2048|step"            # ... more, shorter chunks
 )
