@@ -305,7 +305,8 @@ def run_train(args, rank, world, device):
                              f'(random init, calibrated), {size}x{size}, LoRA rank 4 on Attention+CLIPAttention, '
                              f'attn_reg on, batch {B}/GPU', global_batch=B * world, per_gpu_batch=B, image_size=size,
                     parallelism=f'dp{world}', grad_bucket_bytes=engine.bucket.nbytes, preset=args.preset,
-                    hipgraph=graphed, host_cores=os.cpu_count(), kernel_source_sha16=kernel_source_fingerprint()),
+                    hipgraph=graphed, channels_last=bool(args.channels_last), host_cores=os.cpu_count(),
+                    kernel_source_sha16=kernel_source_fingerprint()),
         roofline=roofline_from_profile(recs) if recs else None,
         attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_TRAINED_IMAGE, B, lib_ms) if recs else None,
         kernels=_kernel_table(recs, 2), library_kernel_ms_per_step=round(lib_ms, 3))
@@ -351,6 +352,8 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
     pipe = build_regional_pipe(args.preset, device)
+    if args.channels_last:
+        pipe.unet.to(memory_format=torch.channels_last)
     prompt, neg = regional_prompt(H, W)
     latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14))
     graph = args.regional_graph
@@ -379,7 +382,7 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
                config=dict(workload='BASELINE.json configs[4]: 3-region (potter/hermione/thanos) 512x768, 50 '
                                     'DPM-Solver++(2M) steps, CFG 7.5, batch 1, SD-1.5 random init (calibrated), no adapter',
                            replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all()),
-                           hipgraph=graphed, host_cores=os.cpu_count()),
+                           hipgraph=graphed, channels_last=bool(args.channels_last), host_cores=os.cpu_count()),
                roofline=roofline_from_profile(recs) if recs else None,
                attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_REGIONAL_CALL, 50, lib_ms) if recs else None,
                kernels=_kernel_table(recs, 1), library_kernel_ms_per_sample=round(lib_ms, 3))

@@ -257,6 +257,32 @@ int mos_groupnorm_silu_bwd(const void* dy, const void* x, const float* gamma, co
                            const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu,
                            int dtype, void* stream);
 
+/* Same operator on channels-last activations: x, y, dy, dx are (B, HW, C) contiguous — the layout of the token-major
+ * attention path and of MIOpen's fp16 NHWC implicit-GEMM convolutions, so a UNet kept in channels_last needs no
+ * NCHW<->NHWC transposes around convolutions and no permute copies around the transformer blocks. C % 8 == 0,
+ * C <= 4096, G <= 64. ws: mos_groupnorm_nhwc_workspace_bytes() bytes. */
+int64_t mos_groupnorm_nhwc_workspace_bytes(int B, int C, int HW, int G);
+int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* beta, void* y, float* stats,
+                                void* ws, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
+int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamma, const float* beta,
+                                const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu,
+                                int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row-wise operators of the transformer blocks around the attention layers:
+ *   LayerNorm: y = (x - mean) * rstd * gamma + beta over the last dim; x, y (rows, C) contiguous in `dtype`, gamma/beta
+ *     fp32 (frozen: no affine gradients), stats (rows, 2) fp32 = mean, rstd (may be NULL forward-only). C % 8 == 0, C <= 2048.
+ *     (BasicTransformerBlock.norm1/2/3 and CLIP's layer norms, which autocast runs as fp32 layer_norm between casts.)
+ *   GEGLU: y[rows, F] = h[:, :F] * gelu(h[:, F:]) for h (rows, 2F) contiguous (exact erf GELU; diffusers GEGLU), and
+ *     dh from dy.
+ * ------------------------------------------------------------------------------------------ */
+int mos_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
+                      float eps, int dtype, void* stream);
+int mos_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, int rows, int C,
+                      int dtype, void* stream);
+int mos_geglu_fwd(const void* h, void* y, int64_t rows, int F, int dtype, void* stream);
+int mos_geglu_bwd(const void* dy, const void* h, void* dh, int64_t rows, int F, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

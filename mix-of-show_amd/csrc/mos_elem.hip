@@ -1,0 +1,250 @@
+// mos_elem.hip — fused row-wise operators of the transformer blocks that CALL the attention path:
+//   LayerNorm  (BasicTransformerBlock.norm1/2/3, CLIP layer_norm1/2/final): half in, half out, fp32 statistics. Under
+//              autocast the reference stack runs it as cast-to-fp32 + fp32 layer_norm + cast back at the next GEMM
+//              (3 passes forward, 4 backward); here one pass each way. The affine parameters are frozen in ED-LoRA
+//              training: no dgamma / dbeta.
+//   GEGLU      (FeedForward.net[0]): y = h[:, :F] * gelu(h[:, F:]) (exact erf GELU) and its backward, one pass each
+//              instead of chunk + gelu + mul (+ 4 kernels backward).
+// HBM-bound by construction: bytes = 2 x rows x C x 2 B forward (LayerNorm), 3 x backward.
+#include <cstdio>
+#include <type_traits>
+#include "mos_common.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 4;     // 16 B chunks per lane: C <= 64 * 8 * 4 = 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// one wave per row; the row stays in registers between the statistics and the normalisation
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ stats, int rows, int C, float eps) {
+    typedef typename MT<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = C >> 3;
+    const T* xr = x + (int64_t)row * C;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < nch) {
+            const v8 t = as_v8<T>(ld16(xr + ch * 8));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[k][i] = (float)t[i]; s += v[k][i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (lane + 64 * k < nch) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+    if (stats != nullptr && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    T* yr = y + (int64_t)row * C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < nch) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(beta + ch * 8 + 4);
+            v8 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i] = (T)((v[k][i] - mean) * rstd * g0[i] + b0[i]);
+                o[i + 4] = (T)((v[k][i + 4] - mean) * rstd * g1[i] + b1[i]);
+            }
+            st16(yr + ch * 8, from_v8<T>(o));
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                            T* __restrict__ dx, int rows, int C) {
+    typedef typename MT<T>::v8 v8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = C >> 3;
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const T* xr = x + (int64_t)row * C;
+    const T* dr = dy + (int64_t)row * C;
+    float g[NCH][8], xh[NCH][8];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < nch) {
+            const v8 xv = as_v8<T>(ld16(xr + ch * 8)), dv = as_v8<T>(ld16(dr + ch * 8));
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xh[k][i] = ((float)xv[i] - mean) * rstd;
+                g[k][i] = (float)dv[i] * (i < 4 ? g0[i & 3] : g1[i & 3]);
+                sg += g[k][i];
+                sgx += g[k][i] * xh[k][i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { g[k][i] = 0.f; xh[k][i] = 0.f; }
+        }
+    }
+    const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+    T* or_ = dx + (int64_t)row * C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < nch) {
+            v8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (T)(rstd * (g[k][i] - mg - xh[k][i] * mgx));
+            st16(or_ + ch * 8, from_v8<T>(o));
+        }
+    }
+}
+
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+// d/dz [z * Phi(z)] = Phi(z) + z * phi(z)
+__device__ __forceinline__ float gelu_grad_f(float z) {
+    const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+    return cdf + z * pdf;
+}
+
+// h (rows, 2F): value | gate. One thread = 8 outputs.
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, int64_t nvec, int F) {
+    typedef typename MT<T>::v8 v8;
+    const int fv = F >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / fv;
+        const int c = (int)(i - row * fv) * 8;
+        const T* hr = h + row * 2 * (int64_t)F;
+        const v8 a = as_v8<T>(ld16(hr + c)), gt = as_v8<T>(ld16(hr + F + c));
+        v8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (T)((float)a[e] * gelu_f((float)gt[e]));
+        st16(y + row * (int64_t)F + c, from_v8<T>(o));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ h, T* __restrict__ dh,
+                                                        int64_t nvec, int F) {
+    typedef typename MT<T>::v8 v8;
+    const int fv = F >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / fv;
+        const int c = (int)(i - row * fv) * 8;
+        const T* hr = h + row * 2 * (int64_t)F;
+        const v8 a = as_v8<T>(ld16(hr + c)), gt = as_v8<T>(ld16(hr + F + c)), d = as_v8<T>(ld16(dy + row * (int64_t)F + c));
+        v8 da, dg;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float z = (float)gt[e], dd = (float)d[e];
+            da[e] = (T)(dd * gelu_f(z));
+            dg[e] = (T)(dd * (float)a[e] * gelu_grad_f(z));
+        }
+        T* dr = dh + row * 2 * (int64_t)F;
+        st16(dr + c, from_v8<T>(da));
+        st16(dr + F + c, from_v8<T>(dg));
+    }
+}
+
+template <typename T>
+int ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C, float eps,
+           hipStream_t st) {
+    const int nch = (C / 8 + 63) / 64;
+    const dim3 grid((rows + 3) / 4);
+    char key[64];
+    snprintf(key, sizeof(key), "rows%d C%d", rows, C);
+    MosProfScope prof(st, "layernorm_fwd", key, 8.0 * rows * C, 4.0 * rows * (double)C);
+#define LN_F(N) hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, eps)
+    switch (nch) { case 1: LN_F(1); break; case 2: LN_F(2); break; case 3: LN_F(3); break; default: LN_F(4); break; }
+#undef LN_F
+    return mos_check_launch("layernorm_fwd");
+}
+
+template <typename T>
+int ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, int rows, int C, hipStream_t st) {
+    const int nch = (C / 8 + 63) / 64;
+    const dim3 grid((rows + 3) / 4);
+    char key[64];
+    snprintf(key, sizeof(key), "rows%d C%d", rows, C);
+    MosProfScope prof(st, "layernorm_bwd", key, 12.0 * rows * C, 6.0 * rows * (double)C);
+#define LN_B(N) hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, stats, (T*)dx, rows, C)
+    switch (nch) { case 1: LN_B(1); break; case 2: LN_B(2); break; case 3: LN_B(3); break; default: LN_B(4); break; }
+#undef LN_B
+    return mos_check_launch("layernorm_bwd");
+}
+
+}  // namespace
+
+extern "C" {
+
+int mos_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C,
+                      float eps, int dtype, void* stream) {
+    MOS_REQUIRE(x && gamma && beta && y, "mos_layernorm_fwd: NULL argument");
+    MOS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAX_CHUNKS, "mos_layernorm_fwd: rows=%d C=%d (C %% 8 == 0, C <= %d)",
+                rows, C, 64 * 8 * LN_MAX_CHUNKS);
+    if (dtype == MOS_F16) return ln_fwd<f16_t>(x, gamma, beta, y, stats, rows, C, eps, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return ln_fwd<bf16_t>(x, gamma, beta, y, stats, rows, C, eps, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_layernorm_fwd: dtype %d", dtype);
+}
+
+int mos_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, int rows, int C,
+                      int dtype, void* stream) {
+    MOS_REQUIRE(dy && x && gamma && stats && dx, "mos_layernorm_bwd: NULL argument");
+    MOS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAX_CHUNKS, "mos_layernorm_bwd: rows=%d C=%d", rows, C);
+    if (dtype == MOS_F16) return ln_bwd<f16_t>(dy, x, gamma, stats, dx, rows, C, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return ln_bwd<bf16_t>(dy, x, gamma, stats, dx, rows, C, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_layernorm_bwd: dtype %d", dtype);
+}
+
+int mos_geglu_fwd(const void* h, void* y, int64_t rows, int F, int dtype, void* stream) {
+    MOS_REQUIRE(h && y && rows > 0 && F > 0 && F % 8 == 0, "mos_geglu_fwd: rows=%lld F=%d", (long long)rows, F);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nvec = rows * (F / 8);
+    const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
+    char key[64];
+    snprintf(key, sizeof(key), "rows%lld F%d", (long long)rows, F);
+    MosProfScope prof(st, "geglu_fwd", key, 20.0 * rows * F, 6.0 * rows * (double)F);
+    if (dtype == MOS_F16) hipLaunchKernelGGL((geglu_fwd_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, (const f16_t*)h, (f16_t*)y, nvec, F);
+    else if (dtype == MOS_BF16) hipLaunchKernelGGL((geglu_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, (bf16_t*)y, nvec, F);
+    else return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_geglu_fwd: dtype %d", dtype);
+    return mos_check_launch("geglu_fwd");
+}
+
+int mos_geglu_bwd(const void* dy, const void* h, void* dh, int64_t rows, int F, int dtype, void* stream) {
+    MOS_REQUIRE(dy && h && dh && rows > 0 && F > 0 && F % 8 == 0, "mos_geglu_bwd: rows=%lld F=%d", (long long)rows, F);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nvec = rows * (F / 8);
+    const int blocks = (int)((nvec + 255) / 256 > 16384 ? 16384 : (nvec + 255) / 256);
+    char key[64];
+    snprintf(key, sizeof(key), "rows%lld F%d", (long long)rows, F);
+    MosProfScope prof(st, "geglu_bwd", key, 40.0 * rows * F, 10.0 * rows * (double)F);
+    if (dtype == MOS_F16) hipLaunchKernelGGL((geglu_bwd_kernel<f16_t>), dim3(blocks), dim3(256), 0, st, (const f16_t*)dy, (const f16_t*)h, (f16_t*)dh, nvec, F);
+    else if (dtype == MOS_BF16) hipLaunchKernelGGL((geglu_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)h, (bf16_t*)dh, nvec, F);
+    else return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_geglu_bwd: dtype %d", dtype);
+    return mos_check_launch("geglu_bwd");
+}
+
+}  // extern "C"

@@ -1,4 +1,4 @@
-// mos_norm.hip — fused GroupNorm (+ SiLU) forward / backward on half-precision NCHW activations (gfx950).
+// mos_norm.hip — fused GroupNorm (+ SiLU) forward / backward on half-precision NCHW and NHWC activations (gfx950).
 //
 // Not one of the attention-path kernels of SURVEY.md §8(a); it is the first item of §8(f) "next": the ResnetBlock2D /
 // Transformer2DModel / VAE GroupNorm->SiLU pairs that CALL the attention path. Under autocast the reference stack runs
@@ -243,6 +243,235 @@ int gn_bwd(GnArgs a, int silu, hipStream_t st) {
     return mos_check_launch("gn_bwd_apply");
 }
 
+
+// ---- channels-last (NHWC) variants ----------------------------------------------------------------------------------
+// x[b][p][c], c contiguous: the layout of the token-major attention path and of MIOpen's fp16 implicit-GEMM convolutions
+// (which otherwise transpose NCHW <-> NHWC around every call). A thread owns a FIXED set of 8-channel vectors (so the
+// per-channel affine / statistics constants live in registers) and strides over pixels; per-channel partial sums are
+// folded to per-group sums through LDS. grid (B, nsplit pixel slices); second-stage combine in double, as above.
+struct GnNhwcArgs {
+    const void* x; const void* dy; void* out;
+    const float* gamma; const float* beta;
+    float* stats;                                  // [B*G][2] = mean, rstd
+    float* partial;                                // [B][nsplit][G][2]
+    int B, C, HW, G, cpg, nsplit, V, TP, R, ppb;   // V = C/8 vectors per pixel, TP threads per pixel, R pixel rows per block
+    float eps;
+};
+
+template <typename T, int VT, bool BWD, bool SILU>
+__global__ __launch_bounds__(256) void gn_nhwc_reduce_kernel(GnNhwcArgs a) {
+    typedef typename MT<T>::v8 v8;
+    extern __shared__ float gn_lds[];               // [C][2] per-channel sums, then reused
+    float* red = gn_lds;
+    __shared__ float mean_s[64], rstd_s[64];
+    const int tid = threadIdx.x;
+    const int r = tid / a.TP, tp = tid - r * a.TP;
+    const int b = blockIdx.x, sp = blockIdx.y;
+    const int p0 = sp * a.ppb, p1 = min(p0 + a.ppb, a.HW);
+    for (int i = tid; i < 2 * a.C; i += blockDim.x) red[i] = 0.f;
+    if (BWD && tid < a.G) { mean_s[tid] = a.stats[(b * a.G + tid) * 2]; rstd_s[tid] = a.stats[(b * a.G + tid) * 2 + 1]; }
+    __syncthreads();
+    float s0[VT][8], s1[VT][8];
+    float cm[VT][8], cr[VT][8], cg[VT][8], cb[VT][8];
+#pragma unroll
+    for (int k = 0; k < VT; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s0[k][i] = 0.f; s1[k][i] = 0.f;
+            if (BWD) {
+                const int c = min((tp + a.TP * k) * 8 + i, a.C - 1);
+                const int g = c / a.cpg;
+                cm[k][i] = mean_s[g]; cr[k][i] = rstd_s[g]; cg[k][i] = a.gamma[c]; cb[k][i] = a.beta[c];
+            }
+        }
+    const T* xb = (const T*)a.x + (int64_t)b * a.HW * a.C;
+    const T* db = BWD ? (const T*)a.dy + (int64_t)b * a.HW * a.C : nullptr;
+    for (int p = p0 + r; p < p1; p += a.R) {
+#pragma unroll
+        for (int k = 0; k < VT; ++k) {
+            const int v = tp + a.TP * k;
+            if (v < a.V) {
+                const v8 xv = as_v8<T>(ld16(xb + (int64_t)p * a.C + v * 8));
+                if (!BWD) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float f = (float)xv[i]; s0[k][i] += f; s1[k][i] += f * f; }
+                } else {
+                    const v8 dv = as_v8<T>(ld16(db + (int64_t)p * a.C + v * 8));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float xh = ((float)xv[i] - cm[k][i]) * cr[k][i];
+                        float dz = (float)dv[i];
+                        if (SILU) {
+                            const float z = xh * cg[k][i] + cb[k][i];
+                            const float sig = 1.f / (1.f + __expf(-z));
+                            dz *= sig * (1.f + z * (1.f - sig));
+                        }
+                        const float gg = dz * cg[k][i];
+                        s0[k][i] += gg; s1[k][i] += gg * xh;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VT; ++k) {
+        const int v = tp + a.TP * k;
+        if (v < a.V) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                atomicAdd(&red[(v * 8 + i) * 2], s0[k][i]);
+                atomicAdd(&red[(v * 8 + i) * 2 + 1], s1[k][i]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < a.G) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int c = tid * a.cpg; c < (tid + 1) * a.cpg; ++c) { t0 += red[c * 2]; t1 += red[c * 2 + 1]; }
+        float* pp = a.partial + (((int64_t)b * a.nsplit + sp) * a.G + tid) * 2;
+        pp[0] = t0; pp[1] = t1;
+    }
+}
+
+template <typename T, int VT, bool BWD, bool SILU>
+__global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
+    typedef typename MT<T>::v8 v8;
+    __shared__ float u_s[64], w_s[64], m_s[64], r_s[64];   // fwd: mean, rstd ; bwd: mean(g), mean(g xhat), mean, rstd
+    const int tid = threadIdx.x;
+    const int r = tid / a.TP, tp = tid - r * a.TP;
+    const int b = blockIdx.x, sp = blockIdx.y;
+    const int p0 = sp * a.ppb, p1 = min(p0 + a.ppb, a.HW);
+    if (tid < a.G) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int i = 0; i < a.nsplit; ++i) {
+            const float* pp = a.partial + (((int64_t)b * a.nsplit + i) * a.G + tid) * 2;
+            t0 += (double)pp[0]; t1 += (double)pp[1];
+        }
+        const double n = (double)a.cpg * a.HW;
+        if (!BWD) {
+            const double m = t0 / n;
+            double var = t1 / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            u_s[tid] = mean; w_s[tid] = rstd;
+            if (sp == 0 && a.stats != nullptr) { a.stats[(b * a.G + tid) * 2] = mean; a.stats[(b * a.G + tid) * 2 + 1] = rstd; }
+        } else {
+            u_s[tid] = (float)(t0 / n); w_s[tid] = (float)(t1 / n);
+            m_s[tid] = a.stats[(b * a.G + tid) * 2]; r_s[tid] = a.stats[(b * a.G + tid) * 2 + 1];
+        }
+    }
+    __syncthreads();
+    // per-channel constants of this thread's vectors
+    float c0[VT][8], c1[VT][8], c2[VT][8], c3[VT][8], c4[VT][8], c5[VT][8];
+#pragma unroll
+    for (int k = 0; k < VT; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = min((tp + a.TP * k) * 8 + i, a.C - 1);
+            const int g = c / a.cpg;
+            const float gam = a.gamma[c], bet = a.beta[c];
+            if (!BWD) {
+                c0[k][i] = gam * w_s[g];                       // y = c0 * x + c1
+                c1[k][i] = bet - u_s[g] * gam * w_s[g];
+            } else {
+                c0[k][i] = m_s[g]; c1[k][i] = r_s[g]; c2[k][i] = gam; c3[k][i] = bet; c4[k][i] = u_s[g]; c5[k][i] = w_s[g];
+            }
+        }
+    const T* xb = (const T*)a.x + (int64_t)b * a.HW * a.C;
+    const T* db = BWD ? (const T*)a.dy + (int64_t)b * a.HW * a.C : nullptr;
+    T* ob = (T*)a.out + (int64_t)b * a.HW * a.C;
+    for (int p = p0 + r; p < p1; p += a.R) {
+#pragma unroll
+        for (int k = 0; k < VT; ++k) {
+            const int v = tp + a.TP * k;
+            if (v < a.V) {
+                const int64_t off = (int64_t)p * a.C + v * 8;
+                const v8 xv = as_v8<T>(ld16(xb + off));
+                v8 o;
+                if (!BWD) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float z = (float)xv[i] * c0[k][i] + c1[k][i];
+                        if (SILU) z = silu_f(z);
+                        o[i] = (T)z;
+                    }
+                } else {
+                    const v8 dv = as_v8<T>(ld16(db + off));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float xh = ((float)xv[i] - c0[k][i]) * c1[k][i];
+                        float dz = (float)dv[i];
+                        if (SILU) {
+                            const float z = xh * c2[k][i] + c3[k][i];
+                            const float sig = 1.f / (1.f + __expf(-z));
+                            dz *= sig * (1.f + z * (1.f - sig));
+                        }
+                        o[i] = (T)(c1[k][i] * (dz * c2[k][i] - c4[k][i] - xh * c5[k][i]));
+                    }
+                }
+                st16(ob + off, from_v8<T>(o));
+            }
+        }
+    }
+}
+
+bool gn_nhwc_plan(GnNhwcArgs& a) {
+    a.V = a.C / 8;
+    const int vt = (a.V + 255) / 256;
+    if (vt > 2 || a.G > 64) return false;
+    a.TP = (a.V + vt - 1) / vt;
+    a.R = 256 / a.TP < 1 ? 1 : 256 / a.TP;
+    int ns = (512 + a.B - 1) / a.B;                  // aim at >= 512 workgroups
+    const int maxs = (a.HW + 2 * a.R - 1) / (2 * a.R);   // at least two pixel rows per thread
+    if (ns > maxs) ns = maxs;
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    a.ppb = (a.HW + ns - 1) / ns;
+    a.nsplit = (a.HW + a.ppb - 1) / a.ppb;
+    return true;
+}
+
+template <typename T, bool BWD>
+int gn_nhwc_run(GnNhwcArgs a, int silu, hipStream_t st) {
+    const int vt = (a.V + 255) / 256;
+    const dim3 grid(a.B, a.nsplit), block(a.TP * a.R);
+    const size_t lds = (size_t)2 * a.C * sizeof(float);
+    char key[96];
+    snprintf(key, sizeof(key), "nhwc B%d C%d HW%d%s", a.B, a.C, a.HW, silu ? " +silu" : "");
+    const double n = (double)a.B * a.C * a.HW;
+    {
+        MosProfScope prof(st, BWD ? "groupnorm_bwd_stats" : "groupnorm_stats", key, (BWD ? 12.0 : 3.0) * n, (BWD ? 4.0 : 2.0) * n);
+        if (vt == 1) {
+            if (silu) hipLaunchKernelGGL((gn_nhwc_reduce_kernel<T, 1, BWD, true>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((gn_nhwc_reduce_kernel<T, 1, BWD, false>), grid, block, lds, st, a);
+        } else {
+            if (silu) hipLaunchKernelGGL((gn_nhwc_reduce_kernel<T, 2, BWD, true>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((gn_nhwc_reduce_kernel<T, 2, BWD, false>), grid, block, lds, st, a);
+        }
+    }
+    int rc = mos_check_launch("gn_nhwc_reduce");
+    if (rc) return rc;
+    MosProfScope prof(st, BWD ? "groupnorm_bwd_apply" : "groupnorm_apply", key, (BWD ? 14.0 : 8.0) * n, (BWD ? 6.0 : 4.0) * n);
+    if (vt == 1) {
+        if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, BWD, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, BWD, false>), grid, block, 0, st, a);
+    } else {
+        if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 2, BWD, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 2, BWD, false>), grid, block, 0, st, a);
+    }
+    return mos_check_launch("gn_nhwc_apply");
+}
+
+int gn_nhwc_check(const void* x, const void* out, const float* gamma, const float* beta, void* ws, GnNhwcArgs& a,
+                  const char* who) {
+    if (!x || !out || !gamma || !beta || !ws) return mos_set_error(MOS_ERR_BAD_ARG, "%s: NULL argument", who);
+    if (a.B <= 0 || a.C <= 0 || a.HW <= 0 || a.G <= 0 || a.C % a.G != 0 || a.C % 8 != 0)
+        return mos_set_error(MOS_ERR_BAD_ARG, "%s: B=%d C=%d HW=%d G=%d (need C %% G == 0, C %% 8 == 0)", who, a.B, a.C, a.HW, a.G);
+    a.cpg = a.C / a.G;
+    if (!gn_nhwc_plan(a)) return mos_set_error(MOS_ERR_UNSUPPORTED, "%s: C=%d G=%d exceeds C <= 4096, G <= 64", who, a.C, a.G);
+    return MOS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -271,6 +500,40 @@ int mos_groupnorm_silu_bwd(const void* dy, const void* x, const float* gamma, co
     if (dtype == MOS_F16) return gn_bwd<f16_t>(a, silu, (hipStream_t)stream);
     if (dtype == MOS_BF16) return gn_bwd<bf16_t>(a, silu, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_bwd: dtype %d", dtype);
+}
+
+int64_t mos_groupnorm_nhwc_workspace_bytes(int B, int C, int HW, int G) {
+    GnNhwcArgs a = {};
+    a.B = B; a.C = C; a.HW = HW; a.G = G;
+    if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G || C % 8) return 0;
+    a.cpg = C / G;
+    if (!gn_nhwc_plan(a)) return 0;
+    return (int64_t)B * a.nsplit * G * 2 * (int64_t)sizeof(float);
+}
+
+int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* beta, void* y, float* stats, void* ws,
+                                int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
+    GnNhwcArgs a = {};
+    a.x = x; a.out = y; a.gamma = gamma; a.beta = beta; a.stats = stats; a.partial = (float*)ws;
+    a.B = B; a.C = C; a.HW = HW; a.G = G; a.eps = eps;
+    int rc = gn_nhwc_check(x, y, gamma, beta, ws, a, "mos_groupnorm_silu_fwd_nhwc");
+    if (rc) return rc;
+    if (dtype == MOS_F16) return gn_nhwc_run<f16_t, false>(a, silu, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return gn_nhwc_run<bf16_t, false>(a, silu, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_fwd_nhwc: dtype %d", dtype);
+}
+
+int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,
+                                void* dx, void* ws, int B, int C, int HW, int G, int silu, int dtype, void* stream) {
+    GnNhwcArgs a = {};
+    a.x = x; a.dy = dy; a.out = dx; a.gamma = gamma; a.beta = beta; a.stats = const_cast<float*>(stats); a.partial = (float*)ws;
+    a.B = B; a.C = C; a.HW = HW; a.G = G; a.eps = 0.f;
+    int rc = gn_nhwc_check(x, dx, gamma, beta, ws, a, "mos_groupnorm_silu_bwd_nhwc");
+    if (rc) return rc;
+    MOS_REQUIRE(dy && stats, "mos_groupnorm_silu_bwd_nhwc: NULL dy / stats");
+    if (dtype == MOS_F16) return gn_nhwc_run<f16_t, true>(a, silu, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return gn_nhwc_run<bf16_t, true>(a, silu, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_bwd_nhwc: dtype %d", dtype);
 }
 
 }  // extern "C"

@@ -338,12 +338,19 @@ def attention(q, k, v, heads, scale, tok_idx=None):
     return o, (pcols if tok_idx is not None else None)
 
 
+def _dense_format(x):
+    """x as is if it is NCHW-contiguous or channels_last-contiguous (the kernels take both), else an NCHW copy."""
+    if x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return x
+    return x.contiguous()
+
+
 class _GroupNormSiLU(torch.autograd.Function):
-    """Fused GroupNorm (+ SiLU) on half NCHW activations; affine parameters are treated as frozen constants."""
+    """Fused GroupNorm (+ SiLU) on half NCHW or channels_last activations; affine parameters are frozen constants."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps, silu):
-        xc = x if x.is_contiguous() else x.contiguous()
+        xc = _dense_format(x)
         y, stats = ops.groupnorm_silu_fwd(xc, gamma, beta, groups, eps, silu)
         ctx.save_for_backward(xc, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
@@ -352,8 +359,10 @@ class _GroupNormSiLU(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, stats = ctx.saved_tensors
-        if dy.dtype != x.dtype or not dy.is_contiguous():
-            dy = dy.to(x.dtype).contiguous()
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if dy.stride() != x.stride():
+            dy = dy.contiguous(memory_format=torch.channels_last) if ops._is_nhwc(x) else dy.contiguous()
         return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
 
 
@@ -364,9 +373,79 @@ def group_norm_act(norm, x, silu):
     instead of autocast's cast / fp32 group_norm / fp32 silu / cast chain. Anything else (CPU oracle runs, fp32
     inference, trainable norms) takes the plain torch ops: this is plumbing around the hot path, not part of it."""
     hw = x.numel() // max(1, x.shape[0] * x.shape[1])
-    use_hip = (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and hw % 8 == 0
+    nhwc = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+    use_hip = (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and (hw % 8 == 0 or (nhwc and x.shape[1] % 8 == 0))
                and not norm.weight.requires_grad and not norm.bias.requires_grad and norm.weight.dtype == torch.float32)
     if use_hip:
         return _GroupNormSiLU.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, bool(silu))
     y = norm(x)
     return torch.nn.functional.silu(y) if silu else y
+
+
+class _LayerNorm(torch.autograd.Function):
+    """LayerNorm over the last dim, half in / half out, fp32 statistics; affine parameters are frozen constants."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need = ctx.needs_input_grad[0]
+        y, stats = ops.layernorm_fwd(x2, gamma, beta, eps, need_stats=need)
+        if need:
+            ctx.save_for_backward(x2, gamma, stats)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, gamma, stats = ctx.saved_tensors
+        d2 = dy.reshape(x2.shape)
+        if d2.dtype != x2.dtype or not d2.is_contiguous():
+            d2 = d2.to(x2.dtype).contiguous()
+        return ops.layernorm_bwd(d2, x2, gamma, stats).view(dy.shape), None, None, None
+
+
+def layer_norm(norm, x):
+    """`norm(x)` for an nn.LayerNorm over the last dim. HIP path: device tensors, half activations (or an fp32 stream under
+    half autocast), frozen fp32 affine parameters — one kernel instead of autocast's cast / fp32 layer_norm / cast chain.
+    Anything else takes the plain torch op (CPU oracle runs, fp32 inference, trainable norms): plumbing, not hot path."""
+    C = x.shape[-1]
+    half = x.dtype in (torch.float16, torch.bfloat16)
+    ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
+    use_hip = (x.is_cuda and (half or ac) and len(norm.normalized_shape) == 1 and norm.weight is not None
+               and norm.bias is not None and not norm.weight.requires_grad and not norm.bias.requires_grad
+               and norm.weight.dtype == torch.float32 and C % 8 == 0 and C <= 2048)
+    if not use_hip:
+        return norm(x)
+    if not half:
+        x = x.to(torch.get_autocast_dtype('cuda'))
+    return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+
+
+class _GEGLU(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, h):
+        h2 = h.reshape(-1, h.shape[-1])
+        if not h2.is_contiguous():
+            h2 = h2.contiguous()
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(h2)
+        return ops.geglu_fwd(h2).view(*h.shape[:-1], h.shape[-1] // 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h2, ) = ctx.saved_tensors
+        d2 = dy.reshape(h2.shape[0], -1)
+        if d2.dtype != h2.dtype or not d2.is_contiguous():
+            d2 = d2.to(h2.dtype).contiguous()
+        return ops.geglu_bwd(d2, h2).view(*dy.shape[:-1], h2.shape[-1])
+
+
+def geglu(h):
+    """value * gelu(gate) for h = [value | gate] along the last dim (diffusers GEGLU). HIP path for half device tensors."""
+    if h.is_cuda and h.dtype in (torch.float16, torch.bfloat16) and h.shape[-1] % 16 == 0:
+        return _GEGLU.apply(h)
+    a, g = h.chunk(2, dim=-1)
+    return a * torch.nn.functional.gelu(g)

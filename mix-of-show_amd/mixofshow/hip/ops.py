@@ -345,14 +345,25 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
 # ------------------------------------------------------------------------------------------------
 # fused GroupNorm (+ SiLU) — caller-side plumbing kernel
 # ------------------------------------------------------------------------------------------------
+def _is_nhwc(x):
+    return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+
+
 def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
-    """x (B, C, *spatial) contiguous half; gamma/beta fp32. Returns (y like x, stats (B*G, 2) fp32)."""
+    """x (B, C, *spatial) half, contiguous (NCHW) or channels_last (NHWC); gamma/beta fp32.
+    Returns (y like x, same memory format; stats (B*G, 2) fp32)."""
     _dev(x, gamma, beta)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     y = torch.empty_like(x)
     stats = torch.empty((B * groups, 2), dtype=torch.float32, device=x.device)
     L = _lib.load()
+    if _is_nhwc(x):
+        ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
+        _lib.check(L.mos_groupnorm_silu_fwd_nhwc(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, C, HW, groups,
+                                                 float(eps), int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_fwd_nhwc')
+        return y, stats
+    assert x.is_contiguous(), 'groupnorm_silu_fwd needs a contiguous (NCHW) or channels_last (NHWC) tensor'
     ws = torch.empty((L.mos_groupnorm_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
     _lib.check(L.mos_groupnorm_silu_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, C, HW, groups,
                                         float(eps), int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_fwd')
@@ -360,12 +371,67 @@ def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
 
 
 def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu):
+    """dy must have x's memory format."""
     _dev(dy, x, gamma, beta, stats)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     dx = torch.empty_like(x)
     L = _lib.load()
+    if _is_nhwc(x):
+        assert dy.stride() == x.stride()
+        ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
+        _lib.check(L.mos_groupnorm_silu_bwd_nhwc(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, C, HW,
+                                                 groups, int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_bwd_nhwc')
+        return dx
+    assert x.is_contiguous() and dy.is_contiguous()
     ws = torch.empty((L.mos_groupnorm_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
     _lib.check(L.mos_groupnorm_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, C, HW, groups,
                                         int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_bwd')
     return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# row-wise operators of the transformer blocks (SURVEY.md 8(f).1): LayerNorm, GEGLU
+# ------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, need_stats=True):
+    """x (rows, C) half contiguous; gamma/beta fp32. Returns (y, stats (rows, 2) fp32 | None)."""
+    _dev(x, gamma, beta)
+    rows, C = x.shape
+    assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    y = torch.empty_like(x)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if need_stats else None
+    L = _lib.load()
+    _lib.check(L.mos_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), rows, C, float(eps), _dt(x), _stream()),
+               'mos_layernorm_fwd')
+    return y, stats
+
+
+def layernorm_bwd(dy, x, gamma, stats):
+    _dev(dy, x, gamma, stats)
+    rows, C = x.shape
+    assert x.is_contiguous() and dy.is_contiguous() and dy.dtype == x.dtype
+    dx = torch.empty_like(x)
+    L = _lib.load()
+    _lib.check(L.mos_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(stats), _p(dx), rows, C, _dt(x), _stream()), 'mos_layernorm_bwd')
+    return dx
+
+
+def geglu_fwd(h):
+    """h (rows, 2F) half contiguous -> (rows, F) = h[:, :F] * gelu(h[:, F:])."""
+    _dev(h)
+    rows, F2 = h.shape
+    assert h.is_contiguous() and F2 % 16 == 0
+    y = torch.empty((rows, F2 // 2), dtype=h.dtype, device=h.device)
+    L = _lib.load()
+    _lib.check(L.mos_geglu_fwd(_p(h), _p(y), rows, F2 // 2, _dt(h), _stream()), 'mos_geglu_fwd')
+    return y
+
+
+def geglu_bwd(dy, h):
+    _dev(dy, h)
+    rows, F2 = h.shape
+    assert h.is_contiguous() and dy.is_contiguous() and dy.shape == (rows, F2 // 2) and dy.dtype == h.dtype
+    dh = torch.empty_like(h)
+    L = _lib.load()
+    _lib.check(L.mos_geglu_bwd(_p(dy), _p(h), _p(dh), rows, F2 // 2, _dt(h), _stream()), 'mos_geglu_bwd')
+    return dh

@@ -12,6 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from mixofshow.hip.functional import layer_norm
+
 
 class CLIPTextEmbeddings(nn.Module):
 
@@ -90,8 +92,8 @@ class CLIPEncoderLayer(nn.Module):
         self.layer_norm2 = nn.LayerNorm(hidden)
 
     def forward(self, x):
-        x = x + self.self_attn(self.layer_norm1(x))
-        return x + self.mlp(self.layer_norm2(x))
+        x = x + self.self_attn(layer_norm(self.layer_norm1, x))
+        return x + self.mlp(layer_norm(self.layer_norm2, x))
 
 
 class CLIPEncoder(nn.Module):
@@ -115,7 +117,7 @@ class CLIPTextTransformer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(hidden)
 
     def forward(self, input_ids):
-        return self.final_layer_norm(self.encoder(self.embeddings(input_ids)))
+        return layer_norm(self.final_layer_norm, self.encoder(self.embeddings(input_ids)))
 
 
 SD15_CLIP_CONFIG = dict(vocab_size=49408, hidden_size=768, num_attention_heads=12, intermediate_size=3072,

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mixofshow.hip.functional import group_norm_act
+from mixofshow.hip.functional import geglu, group_norm_act, layer_norm
 from mixofshow.models.attention import Attention
 
 
@@ -99,8 +99,7 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        x, gate = self.proj(x).chunk(2, dim=-1)
-        return x * F.gelu(gate)
+        return geglu(self.proj(x))          # value * gelu(gate): one fused kernel each way on the HIP device
 
 
 class FeedForward(nn.Module):
@@ -128,9 +127,9 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, encoder_hidden_states=None, cross_attention_kwargs=None):
         cak = cross_attention_kwargs if cross_attention_kwargs is not None else {}
-        x = self.attn1(self.norm1(x), encoder_hidden_states=None, **cak) + x
-        x = self.attn2(self.norm2(x), encoder_hidden_states=encoder_hidden_states, **cak) + x
-        return self.ff(self.norm3(x)) + x
+        x = self.attn1(layer_norm(self.norm1, x), encoder_hidden_states=None, **cak) + x
+        x = self.attn2(layer_norm(self.norm2, x), encoder_hidden_states=encoder_hidden_states, **cak) + x
+        return self.ff(layer_norm(self.norm3, x)) + x
 
 
 class Transformer2DModel(nn.Module):
@@ -315,6 +314,17 @@ class UNet2DConditionModel(nn.Module):
         self.conv_act = nn.SiLU()
         self.conv_out = nn.Conv2d(ch[0], out_channels, 3, padding=1)
         self.gradient_checkpointing = False
+        self.channels_last = False
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        # `.to(memory_format=torch.channels_last)` converts the conv weights; remember it so that forward() puts the input
+        # latents into the same layout: NHWC end to end = no NCHW<->NHWC transposes around MIOpen's convolutions and no
+        # permute copies around the transformer blocks (token-major IS channels-last)
+        w = self.conv_in.weight
+        self.channels_last = bool(w.dim() == 4 and w.shape[1] > 1 and not w.is_contiguous()
+                                  and w.is_contiguous(memory_format=torch.channels_last))
+        return out
 
     def enable_gradient_checkpointing(self):
         self.gradient_checkpointing = True
@@ -333,6 +343,8 @@ class UNet2DConditionModel(nn.Module):
         t_emb = get_timestep_embedding(timestep, self._time_dim).to(dtype=sample.dtype)
         emb = self.time_embedding(t_emb)
 
+        if getattr(self, 'channels_last', False):
+            sample = sample.contiguous(memory_format=torch.channels_last)
         sample = self.conv_in(sample)
         res = (sample, )
         is_adapter = down_block_additional_residuals is not None

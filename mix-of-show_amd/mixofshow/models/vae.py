@@ -24,11 +24,12 @@ class VaeAttention(nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
-        y = group_norm_act(self.group_norm, x, False).view(b, c, h * w).transpose(1, 2)
+        # token-major view: free for channels_last activations, one copy for NCHW
+        y = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(b, h * w, c)
         q, k, v = self.to_q(y), self.to_k(y), self.to_v(y)
         o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
         o = self.to_out[0](o)
-        return o.transpose(1, 2).reshape(b, c, h, w) + x
+        return o.reshape(b, h, w, c).permute(0, 3, 1, 2) + x
 
 
 class _Mid(nn.Module):

@@ -8,7 +8,8 @@ Emulations compute in fp32 from the (possibly half) inputs and round the result 
 import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
-            'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd')
+            'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd',
+            'geglu_fwd', 'geglu_bwd')
 PAD = 16
 
 
@@ -197,3 +198,33 @@ def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu):
     xg = xh.reshape(B, groups, -1)
     dx = rstd * (g - g.mean(-1, keepdim=True) - xg * (g * xg).mean(-1, keepdim=True))
     return dx.reshape(x.shape).to(x.dtype)
+
+
+def layernorm_fwd(x, gamma, beta, eps, need_stats=True):
+    xf = x.float()
+    mean = xf.mean(-1, keepdim=True)
+    var = ((xf - mean) ** 2).mean(-1, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    y = ((xf - mean) * rstd * gamma + beta).to(x.dtype)
+    return y, (torch.cat([mean, rstd], -1) if need_stats else None)
+
+
+def layernorm_bwd(dy, x, gamma, stats):
+    """dx = rstd * (g - mean(g) - xhat * mean(g xhat)), g = dy * gamma (closed form the HIP kernel implements)."""
+    mean, rstd = stats[:, :1].float(), stats[:, 1:].float()
+    xh = (x.float() - mean) * rstd
+    g = dy.float() * gamma
+    return (rstd * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))).to(x.dtype)
+
+
+def geglu_fwd(h):
+    a, g = h.float().chunk(2, dim=-1)
+    return (a * torch.nn.functional.gelu(g)).to(h.dtype)
+
+
+def geglu_bwd(dy, h):
+    a, g = h.float().chunk(2, dim=-1)
+    cdf = 0.5 * (1 + torch.erf(g * 0.7071067811865476))
+    pdf = 0.3989422804014327 * torch.exp(-0.5 * g * g)
+    d = dy.float()
+    return torch.cat([d * g * cdf, d * a * (cdf + g * pdf)], -1).to(h.dtype)

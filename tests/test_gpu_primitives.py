@@ -356,3 +356,76 @@ def test_groupnorm_silu(ops, emu, dtype, silu, B, C, H, W, G):
     out = torch.nn.functional.silu(out) if silu else out
     (dx_ref, ) = torch.autograd.grad(out, xf, dy.float())
     _check('groupnorm.dx', dx, dx_ref, dtype, ulps=3.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('silu', [True, False])
+@pytest.mark.parametrize('B,C,H,W,G', [
+    (4, 320, 64, 64, 32),      # level 0 (10 channels per group: 8-channel vectors straddle groups)
+    (2, 640, 32, 32, 32),
+    (2, 1280, 16, 16, 32),
+    (2, 1280, 8, 8, 32),
+    (2, 2560, 8, 8, 32),       # up-block concatenation: two vectors per thread
+    (1, 1920, 16, 24, 32),     # 512x768 regional sample, skip concat
+    (2, 960, 64, 64, 32),
+    (1, 32, 8, 12, 8),         # tiny preset (4 channels per group)
+    (4, 128, 128, 128, 32),    # VAE encoder stage (reduced)
+])
+def test_groupnorm_silu_channels_last(ops, emu, dtype, silu, B, C, H, W, G):
+    """The NHWC kernels (channels_last tensors) vs torch fp32 group_norm/silu: forward, statistics, input gradient;
+    the output keeps the channels_last format."""
+    g = torch.Generator(device='cpu').manual_seed(8)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to('cuda', dtype).contiguous(memory_format=torch.channels_last)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    y, stats = ops.groupnorm_silu_fwd(x, gamma, beta, G, 1e-5, silu)
+    assert y.stride() == x.stride()
+    y_ref, stats_ref = emu.groupnorm_silu_fwd(x, gamma, beta, G, 1e-5, silu)
+    _check(f'groupnorm_nhwc.y[{B}x{C}x{H}x{W}]', y, y_ref, dtype, ulps=2.0)
+    _check('groupnorm_nhwc.stats', stats, stats_ref, torch.float16, ulps=0.05)
+    dy = torch.randn(B, C, H, W, generator=g).to('cuda', dtype).contiguous(memory_format=torch.channels_last)
+    dx = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats_ref, G, silu)
+    assert dx.stride() == x.stride()
+    xf = x.float().contiguous().requires_grad_(True)
+    out = torch.nn.functional.group_norm(xf, G, gamma, beta, 1e-5)
+    out = torch.nn.functional.silu(out) if silu else out
+    (dx_ref, ) = torch.autograd.grad(out, xf, dy.float().contiguous())
+    _check('groupnorm_nhwc.dx', dx, dx_ref, dtype, ulps=3.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,C', [(16384, 320), (4096, 640), (1024, 1280), (256, 1280), (4928, 768), (77, 768), (6144, 320)])
+def test_layernorm(ops, emu, dtype, rows, C):
+    """Fused LayerNorm (half in/out, fp32 statistics) vs torch fp32 layer_norm on the same half inputs, fwd + dx."""
+    g = torch.Generator(device='cpu').manual_seed(9)
+    x = (torch.randn(rows, C, generator=g) * 2.0 + 0.5).to('cuda', dtype)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    y, stats = ops.layernorm_fwd(x, gamma, beta, 1e-5)
+    y_ref, stats_ref = emu.layernorm_fwd(x, gamma, beta, 1e-5)
+    _check(f'layernorm.y[{rows}x{C}]', y, y_ref, dtype, ulps=2.0)
+    _check('layernorm.stats', stats, stats_ref, torch.float16, ulps=0.05)
+    dy = torch.randn(rows, C, generator=g).to('cuda', dtype)
+    dx = ops.layernorm_bwd(dy, x, gamma, stats_ref)
+    xf = x.float().requires_grad_(True)
+    (dx_ref, ) = torch.autograd.grad(torch.nn.functional.layer_norm(xf, (C, ), gamma, beta, 1e-5), xf, dy.float())
+    _check('layernorm.dx', dx, dx_ref, dtype, ulps=3.0)
+    _check('layernorm.dx (emulation formula)', emu.layernorm_bwd(dy, x, gamma, stats_ref), dx_ref, dtype, ulps=3.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,F', [(16384, 1280), (4096, 2560), (1024, 5120), (256, 5120), (100, 1280)])
+def test_geglu(ops, emu, dtype, rows, F):
+    """value * gelu(gate) (exact erf GELU, diffusers GEGLU) and its backward vs torch fp32 autograd."""
+    g = torch.Generator(device='cpu').manual_seed(10)
+    h = (torch.randn(rows, 2 * F, generator=g) * 1.5).to('cuda', dtype)
+    y = ops.geglu_fwd(h)
+    hf = h.float().requires_grad_(True)
+    a, gate = hf.chunk(2, dim=-1)
+    y_ref = a * torch.nn.functional.gelu(gate)
+    _check(f'geglu.y[{rows}x{F}]', y, y_ref.detach(), dtype, ulps=2.0)
+    dy = torch.randn(rows, F, generator=g).to('cuda', dtype)
+    dh = ops.geglu_bwd(dy, h)
+    (dh_ref, ) = torch.autograd.grad(y_ref, hf, dy.float())
+    _check('geglu.dh', dh, dh_ref, dtype, ulps=2.0)
+    _check('geglu.dh (emulation formula)', emu.geglu_bwd(dy, h), dh_ref, dtype, ulps=2.0)
