@@ -511,7 +511,7 @@ def main():
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-regional', action='store_true', help='train mode: skip the regional-sample half of the metric')
-    ap.add_argument('--channels-last', type=int, default=0)
+    ap.add_argument('--channels-last', type=int, default=1, help='NHWC UNet/VAE (the product default)')
     ap.add_argument('--graph', type=int, default=1, help='train: forward+backward replayed from a hipGraph (the product '
                     'default, train_edlora.py); 0 = eager')
     ap.add_argument('--regional-graph', type=int, default=0, help='regional: replay the UNet call from a hipGraph (opt-in '

@@ -160,7 +160,8 @@ int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64
  *   pcols [B, H, Nq, n_pcols] fp32 (optional, cross-attention training): softmax probability
  *         of key index tok_idx[b*n_pcols + t] — all that cal_attn_reg (trainer_edlora.py:263-313)
  *         consumes of the maps AttentionStore keeps (ptp_util.py:79-98).
- * Supported head dims: 40, 80, 160 (SD-1.5, 8 heads at C = 320/640/1280).
+ * Supported head dims: 40, 80, 160 (SD-1.5 UNet, 8 heads at C = 320/640/1280) and 64 (CLIP ViT-L/14 text tower, 12 heads,
+ * causal, 77 tokens: CLIPAttention of the text encoder the ED-LoRA tune trains, trainer_edlora.py:97-115,224-232).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int B, H, Nq, Nkv, d;
@@ -169,6 +170,7 @@ typedef struct {
     int64_t v_bs, v_rs;
     int64_t o_bs, o_rs;
     float scale;
+    int causal;           /* 1: keys with index > the query's index are masked (CLIP text tower; needs Nq == Nkv) */
 } mos_attn_shape;
 
 int mos_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
@@ -281,6 +283,9 @@ int mos_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
 int mos_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, int rows, int C,
                       int dtype, void* stream);
 int mos_geglu_fwd(const void* h, void* y, int64_t rows, int F, int dtype, void* stream);
+/* y[r, :] = softmax(scale * x[r, :]), x / y (rows, N) contiguous in `dtype` (may alias), N % 8 == 0, N <= 8192: the VAE
+ * mid-block attention (single head, d = 512, N = 4096) as scores GEMM -> this -> values GEMM on the library's GEMM. */
+int mos_softmax_rows(const void* x, void* y, int rows, int N, float scale, int dtype, void* stream);
 int mos_geglu_bwd(const void* dy, const void* h, void* dh, int64_t rows, int F, int dtype, void* stream);
 
 #ifdef __cplusplus

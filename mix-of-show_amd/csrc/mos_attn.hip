@@ -1,4 +1,5 @@
-// mos_attn.hip — fused attention for the SD-1.5 UNet on gfx950 (head dims 40 / 80 / 160, 8 heads).
+// mos_attn.hip — fused attention for the SD-1.5 UNet (head dims 40 / 80 / 160, 8 heads) and its CLIP text tower
+// (head dim 64, 12 heads, causal) on gfx950.
 //
 // Replaces, in one kernel per direction, what the reference does with baddbmm + softmax + bmm on a
 // materialised (B*H, N, Nkv) probability tensor, or with xformers (reference
@@ -67,6 +68,7 @@ struct AttnArgs {
     int B, H, Nq, Nkv, nqb;
     int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
     float scale;
+    int causal;      // 1: key index > query index is masked (CLIP text tower)
 };
 
 struct AttnBwdArgs {
@@ -76,6 +78,7 @@ struct AttnBwdArgs {
     int B, H, Nq, Nkv, nqb, nkb, nsplit, q_per_split;
     int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     float scale;
+    int causal;
 };
 
 // ---- LDS tiles ----------------------------------------------------------------------------------
@@ -227,7 +230,8 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
                                        const typename MT<T>::v8 (&qf)[NQ][HD<D>::KS],
                                        f32x16 (&o)[NQ][HD<D>::DT], float (&m)[NQ], float (&l)[NQ],
                                        const int (&tok)[MOS_MAX_PCOLS], int n_pcols,
-                                       float (&cap)[NQ][MOS_MAX_PCOLS], int tid, int l31, int hh) {
+                                       float (&cap)[NQ][MOS_MAX_PCOLS], int tid, int l31, int hh,
+                                       bool causal = false, int qfirst = 0) {
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
 #pragma unroll
@@ -289,6 +293,14 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         if (kv0 + 32 * t + acc_row(r, hh) >= Nkv) s[iq][t][r] = NEG_BIG;
+            }
+            if (causal) {       // wave-uniform flag; this lane's query of sub-tile iq is qfirst + 32*iq + l31
+                const int qidx = qfirst + 32 * iq + l31;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + 32 * t + acc_row(r, hh) > qidx) s[iq][t][r] = NEG_BIG;
             }
             if constexpr (PCOLS) {
 #pragma unroll
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
     float m[NQ], l[NQ];
     const float c = a.scale * LOG2E;
     attend<T, D, NQ, PCOLS, LSUM>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, a.n_pcols, cap, tid, l31,
-                                  hh);
+                                  hh, a.causal != 0, q0);
 
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
@@ -650,6 +662,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MO
                 for (int r = 0; r < 16; ++r)
                     if (kv0 + 32 * t + acc_row(r, hh) >= a.Nkv) s[r] = NEG_BIG;
             }
+            if (a.causal) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kv0 + 32 * t + acc_row(r, hh) > qi) s[r] = NEG_BIG;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
@@ -850,6 +867,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
                     // dK^T / dV^T, columns never mix, and the store skips invalid keys
                     float p, g = dp[r];
                     p = __builtin_amdgcn_exp2f(s[r] * c - l4[r4][rr]);
+                    if (a.causal && kvi > q0 + 32 * t + 8 * r4 + 4 * hh + rr) p = 0.f;   // this lane's key vs the row's query
                     if constexpr (PCOLS) {
                         if (mytok >= 0) g += dpc_s[(32 * t + 8 * r4 + 4 * hh + rr) * MOS_MAX_PCOLS + mytok];
                     }
@@ -943,8 +961,10 @@ int check_shape(const mos_attn_shape* s, const char* who) {
     if (!s) return mos_set_error(MOS_ERR_BAD_ARG, "%s: NULL shape", who);
     if (s->B <= 0 || s->H <= 0 || s->Nq <= 0 || s->Nkv <= 0)
         return mos_set_error(MOS_ERR_BAD_ARG, "%s: B=%d H=%d Nq=%d Nkv=%d", who, s->B, s->H, s->Nq, s->Nkv);
-    if (s->d != 40 && s->d != 80 && s->d != 160)
-        return mos_set_error(MOS_ERR_UNSUPPORTED, "%s: head dim %d not in {40, 80, 160}", who, s->d);
+    if (s->d != 40 && s->d != 64 && s->d != 80 && s->d != 160)
+        return mos_set_error(MOS_ERR_UNSUPPORTED, "%s: head dim %d not in {40, 64, 80, 160}", who, s->d);
+    if (s->causal && s->Nq != s->Nkv)
+        return mos_set_error(MOS_ERR_BAD_ARG, "%s: causal masking needs Nq == Nkv (got %d, %d)", who, s->Nq, s->Nkv);
     if (s->q_rs % 8 || s->k_rs % 8 || s->v_rs % 8 || s->o_rs % 4 || s->q_bs % 8 || s->k_bs % 8 || s->v_bs % 8 || s->o_bs % 4)
         return mos_set_error(MOS_ERR_BAD_ARG, "%s: strides must be multiples of 8 elements", who);
     return MOS_OK;
@@ -957,6 +977,7 @@ AttnArgs make_args(const void* q, const void* k, const void* v, void* o, float* 
     a.B = s->B; a.H = s->H; a.Nq = s->Nq; a.Nkv = s->Nkv; a.nqb = (s->Nq + q_tile - 1) / q_tile;
     a.q_bs = s->q_bs; a.q_rs = s->q_rs; a.k_bs = s->k_bs; a.k_rs = s->k_rs;
     a.v_bs = s->v_bs; a.v_rs = s->v_rs; a.o_bs = s->o_bs; a.o_rs = s->o_rs; a.scale = s->scale;
+    a.causal = s->causal;
     return a;
 }
 
@@ -1081,6 +1102,7 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     a.q_bs = s->q_bs; a.q_rs = s->q_rs; a.k_bs = s->k_bs; a.k_rs = s->k_rs; a.v_bs = s->v_bs; a.v_rs = s->v_rs;
     a.do_bs = g->do_bs; a.do_rs = g->do_rs; a.dq_bs = g->dq_bs; a.dq_rs = g->dq_rs;
     a.dk_bs = g->dk_bs; a.dk_rs = g->dk_rs; a.dv_bs = g->dv_bs; a.dv_rs = g->dv_rs; a.scale = s->scale;
+    a.causal = s->causal;
     const bool pc = a.n_pcols > 0;
     {
         const dim3 grid((unsigned)(a.H * a.nqb * a.B));
@@ -1144,11 +1166,13 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         if ((dtype) == MOS_F16) {                                                           \
             typedef f16_t TT;                                                               \
             if ((d) == 40) { constexpr int DD = 40; return CALL; }                          \
+            if ((d) == 64) { constexpr int DD = 64; return CALL; }                          \
             if ((d) == 80) { constexpr int DD = 80; return CALL; }                          \
             if ((d) == 160) { constexpr int DD = 160; return CALL; }                        \
         } else if ((dtype) == MOS_BF16) {                                                   \
             typedef bf16_t TT;                                                              \
             if ((d) == 40) { constexpr int DD = 40; return CALL; }                          \
+            if ((d) == 64) { constexpr int DD = 64; return CALL; }                          \
             if ((d) == 80) { constexpr int DD = 80; return CALL; }                          \
             if ((d) == 160) { constexpr int DD = 160; return CALL; }                        \
         }                                                                                   \

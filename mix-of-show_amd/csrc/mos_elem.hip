@@ -169,6 +169,69 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ dy
     }
 }
 
+// y[r, :] = softmax(scale * x[r, :]) for half rows of up to 8192 elements; one 256-thread block per row, the row stays
+// in registers (VAE mid-block attention: 4096 x 4096 single-head scores between two library GEMMs).
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int N, float scale_log2e) {
+    typedef typename MT<T>::v8 v8;
+    __shared__ float red[8];
+    const int tid = threadIdx.x;
+    const int nch = N >> 3;
+    const T* xr = x + (int64_t)blockIdx.x * N;
+    T* yr = y + (int64_t)blockIdx.x * N;
+    float v[NCH][8];
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = tid + 256 * k;
+        if (ch < nch) {
+            const v8 t = as_v8<T>(ld16(xr + ch * 8));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[k][i] = (float)t[i] * scale_log2e; mx = fmaxf(mx, v[k][i]); }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[k][i] = -1.0e30f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[k][i] = __builtin_amdgcn_exp2f(v[k][i] - mx); sum += v[k][i]; }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = tid + 256 * k;
+        if (ch < nch) {
+            v8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (T)(v[k][i] * inv);
+            st16(yr + ch * 8, from_v8<T>(o));
+        }
+    }
+}
+
+template <typename T>
+int softmax_rows(const void* x, void* y, int rows, int N, float scale, hipStream_t st) {
+    const int nch = (N / 8 + 255) / 256;
+    char key[64];
+    snprintf(key, sizeof(key), "rows%d N%d", rows, N);
+    MosProfScope prof(st, "softmax_rows", key, 5.0 * rows * N, 4.0 * rows * (double)N);
+    const float sl = scale * 1.4426950408889634f;
+#define SM_K(NC) hipLaunchKernelGGL((softmax_rows_kernel<T, NC>), dim3(rows), dim3(256), 0, st, (const T*)x, (T*)y, N, sl)
+    switch (nch) { case 1: SM_K(1); break; case 2: SM_K(2); break; case 3: SM_K(3); break; default: SM_K(4); break; }
+#undef SM_K
+    return mos_check_launch("softmax_rows");
+}
+
 template <typename T>
 int ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, int rows, int C, float eps,
            hipStream_t st) {
@@ -217,6 +280,13 @@ int mos_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
     if (dtype == MOS_F16) return ln_bwd<f16_t>(dy, x, gamma, stats, dx, rows, C, (hipStream_t)stream);
     if (dtype == MOS_BF16) return ln_bwd<bf16_t>(dy, x, gamma, stats, dx, rows, C, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_layernorm_bwd: dtype %d", dtype);
+}
+
+int mos_softmax_rows(const void* x, void* y, int rows, int N, float scale, int dtype, void* stream) {
+    MOS_REQUIRE(x && y && rows > 0 && N > 0 && N % 8 == 0 && N <= 8192, "mos_softmax_rows: rows=%d N=%d (N %% 8 == 0, N <= 8192)", rows, N);
+    if (dtype == MOS_F16) return softmax_rows<f16_t>(x, y, rows, N, scale, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return softmax_rows<bf16_t>(x, y, rows, N, scale, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_softmax_rows: dtype %d", dtype);
 }
 
 int mos_geglu_fwd(const void* h, void* y, int64_t rows, int F, int dtype, void* stream) {

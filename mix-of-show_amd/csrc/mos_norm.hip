@@ -286,17 +286,30 @@ __global__ __launch_bounds__(256) void gn_nhwc_reduce_kernel(GnNhwcArgs a) {
         }
     const T* xb = (const T*)a.x + (int64_t)b * a.HW * a.C;
     const T* db = BWD ? (const T*)a.dy + (int64_t)b * a.HW * a.C : nullptr;
-    for (int p = p0 + r; p < p1; p += a.R) {
+    constexpr int U = 4;                         // pixel rows in flight per thread (independent 16 B loads)
+    for (int p = p0 + r; p < p1; p += U * a.R) {
+        u32x4 xr[U][VT], dr[U][VT];
 #pragma unroll
-        for (int k = 0; k < VT; ++k) {
-            const int v = tp + a.TP * k;
-            if (v < a.V) {
-                const v8 xv = as_v8<T>(ld16(xb + (int64_t)p * a.C + v * 8));
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < VT; ++k) {
+                const int v = min(tp + a.TP * k, a.V - 1);
+                const int64_t off = (int64_t)min(p + u * a.R, p1 - 1) * a.C + v * 8;
+                xr[u][k] = ld16(xb + off);
+                if (BWD) dr[u][k] = ld16(db + off);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u * a.R >= p1) continue;
+#pragma unroll
+            for (int k = 0; k < VT; ++k) {
+                if (tp + a.TP * k >= a.V) continue;
+                const v8 xv = as_v8<T>(xr[u][k]);
                 if (!BWD) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { const float f = (float)xv[i]; s0[k][i] += f; s1[k][i] += f * f; }
                 } else {
-                    const v8 dv = as_v8<T>(ld16(db + (int64_t)p * a.C + v * 8));
+                    const v8 dv = as_v8<T>(dr[u][k]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float xh = ((float)xv[i] - cm[k][i]) * cr[k][i];
@@ -341,12 +354,28 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     const int r = tid / a.TP, tp = tid - r * a.TP;
     const int b = blockIdx.x, sp = blockIdx.y;
     const int p0 = sp * a.ppb, p1 = min(p0 + a.ppb, a.HW);
-    if (tid < a.G) {
-        double t0 = 0.0, t1 = 0.0;
-        for (int i = 0; i < a.nsplit; ++i) {
-            const float* pp = a.partial + (((int64_t)b * a.nsplit + i) * a.G + tid) * 2;
-            t0 += (double)pp[0]; t1 += (double)pp[1];
+    // second-stage combine of the nsplit slice partials, by ALL threads (a single thread per group walking nsplit
+    // dependent loads cost 40 us at nsplit = 128): coalesced loads, double accumulation in LDS
+    __shared__ double acc_s[128];
+    for (int i = tid; i < 2 * a.G; i += blockDim.x) acc_s[i] = 0.0;
+    __syncthreads();
+    {
+        const int tot = a.nsplit * a.G * 2;
+        const float* pb = a.partial + (int64_t)b * tot;
+        for (int e0 = tid; e0 < tot; e0 += 8 * blockDim.x) {
+            float pv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int e = e0 + q * blockDim.x; pv[q] = e < tot ? pb[e] : 0.f; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q * blockDim.x;
+                if (e < tot) atomicAdd(&acc_s[e % (2 * a.G)], (double)pv[q]);
+            }
         }
+    }
+    __syncthreads();
+    if (tid < a.G) {
+        const double t0 = acc_s[tid * 2], t1 = acc_s[tid * 2 + 1];
         const double n = (double)a.cpg * a.HW;
         if (!BWD) {
             const double m = t0 / n;
@@ -380,13 +409,27 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     const T* xb = (const T*)a.x + (int64_t)b * a.HW * a.C;
     const T* db = BWD ? (const T*)a.dy + (int64_t)b * a.HW * a.C : nullptr;
     T* ob = (T*)a.out + (int64_t)b * a.HW * a.C;
-    for (int p = p0 + r; p < p1; p += a.R) {
+    constexpr int U = 4;
+    for (int p = p0 + r; p < p1; p += U * a.R) {
+        u32x4 xr[U][VT], dr[U][VT];
 #pragma unroll
-        for (int k = 0; k < VT; ++k) {
-            const int v = tp + a.TP * k;
-            if (v < a.V) {
-                const int64_t off = (int64_t)p * a.C + v * 8;
-                const v8 xv = as_v8<T>(ld16(xb + off));
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < VT; ++k) {
+                const int v = min(tp + a.TP * k, a.V - 1);
+                const int64_t off = (int64_t)min(p + u * a.R, p1 - 1) * a.C + v * 8;
+                xr[u][k] = ld16(xb + off);
+                if (BWD) dr[u][k] = ld16(db + off);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u * a.R >= p1) continue;
+#pragma unroll
+            for (int k = 0; k < VT; ++k) {
+                const int v = tp + a.TP * k;
+                if (v >= a.V) continue;
+                const int64_t off = (int64_t)(p + u * a.R) * a.C + v * 8;
+                const v8 xv = as_v8<T>(xr[u][k]);
                 v8 o;
                 if (!BWD) {
 #pragma unroll
@@ -396,7 +439,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
                         o[i] = (T)z;
                     }
                 } else {
-                    const v8 dv = as_v8<T>(ld16(db + off));
+                    const v8 dv = as_v8<T>(dr[u][k]);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float xh = ((float)xv[i] - c0[k][i]) * c1[k][i];
@@ -421,10 +464,10 @@ bool gn_nhwc_plan(GnNhwcArgs& a) {
     if (vt > 2 || a.G > 64) return false;
     a.TP = (a.V + vt - 1) / vt;
     a.R = 256 / a.TP < 1 ? 1 : 256 / a.TP;
-    int ns = (512 + a.B - 1) / a.B;                  // aim at >= 512 workgroups
-    const int maxs = (a.HW + 2 * a.R - 1) / (2 * a.R);   // at least two pixel rows per thread
+    int ns = (1024 + a.B - 1) / a.B;                 // aim at ~1024 workgroups, at most 128 slices per image
+    const int maxs = (a.HW + 4 * a.R - 1) / (4 * a.R);   // at least one unrolled group (4 pixel rows) per thread
     if (ns > maxs) ns = maxs;
-    if (ns > 256) ns = 256;
+    if (ns > 128) ns = 128;
     if (ns < 1) ns = 1;
     a.ppb = (a.HW + ns - 1) / ns;
     a.nsplit = (a.HW + a.ppb - 1) / a.ppb;

@@ -265,7 +265,7 @@ class _Attention(torch.autograd.Function):
     """mode 'qkv': a = (B,N,3C) fused projection; mode 'q_kv': a = q (B,N,C), b = (B,M,2C); mode 'sep': a,b,c."""
 
     @staticmethod
-    def forward(ctx, mode, heads, scale, tok_idx, a, b, c):
+    def forward(ctx, mode, heads, scale, tok_idx, a, b, c, causal=False):
         if mode == 'qkv':
             C = a.shape[-1] // 3
             q, k, v = a[..., :C], a[..., C:2 * C], a[..., 2 * C:]
@@ -274,9 +274,9 @@ class _Attention(torch.autograd.Function):
             q, k, v = a, b[..., :C], b[..., C:]
         else:
             q, k, v = a, b, c
-        need_grad = any(ctx.needs_input_grad[4:])
-        o, lse, pcols = ops.attn_fwd(q, k, v, heads, scale, tok_idx=tok_idx, need_lse=need_grad)
-        ctx.mode, ctx.heads, ctx.scale = mode, heads, scale
+        need_grad = any(ctx.needs_input_grad[4:7])
+        o, lse, pcols = ops.attn_fwd(q, k, v, heads, scale, tok_idx=tok_idx, need_lse=need_grad, causal=causal)
+        ctx.mode, ctx.heads, ctx.scale, ctx.causal = mode, heads, scale, causal
         ctx.has_pcols = pcols is not None
         if need_grad:
             ctx.save_for_backward(a, b, c, o, lse, tok_idx, pcols)
@@ -310,8 +310,8 @@ class _Attention(torch.autograd.Function):
         else:
             dpc = None
         ops.attn_bwd(q, k, v, o, lse, dO, ctx.heads, ctx.scale, dq, dk, dv, tok_idx=tok_idx if dpc is not None else None,
-                     pcols=pcols if dpc is not None else None, dpcols=dpc)
-        return None, None, None, None, da, db, dc
+                     pcols=pcols if dpc is not None else None, dpcols=dpc, causal=ctx.causal)
+        return None, None, None, None, da, db, dc, None
 
 
 def _check_half(*ts):
@@ -320,9 +320,9 @@ def _check_half(*ts):
             raise TypeError(f'mixofshow.hip.attention needs float16/bfloat16 activations, got {t.dtype}')
 
 
-def attention_qkv(qkv, heads, scale):
+def attention_qkv(qkv, heads, scale, causal=False):
     _check_half(qkv)
-    return _Attention.apply('qkv', heads, scale, None, qkv, None, None)[0]
+    return _Attention.apply('qkv', heads, scale, None, qkv, None, None, causal)[0]
 
 
 def attention_q_kv(q, kv, heads, scale, tok_idx=None):
@@ -332,9 +332,9 @@ def attention_q_kv(q, kv, heads, scale, tok_idx=None):
     return o, (pcols if tok_idx is not None else None)
 
 
-def attention(q, k, v, heads, scale, tok_idx=None):
+def attention(q, k, v, heads, scale, tok_idx=None, causal=False):
     _check_half(q, k, v)
-    o, pcols = _Attention.apply('sep', heads, scale, tok_idx, q, k, v)
+    o, pcols = _Attention.apply('sep', heads, scale, tok_idx, q, k, v, causal)
     return o, (pcols if tok_idx is not None else None)
 
 

@@ -67,6 +67,7 @@ class AttnShape(ctypes.Structure):
         ('v_bs', ctypes.c_int64), ('v_rs', ctypes.c_int64),
         ('o_bs', ctypes.c_int64), ('o_rs', ctypes.c_int64),
         ('scale', ctypes.c_float),
+        ('causal', ctypes.c_int),
     ]
 
 
@@ -128,6 +129,7 @@ SIGNATURES = {
     'mos_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     'mos_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mos_geglu_fwd': (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    'mos_softmax_rows': (_i, [_vp, _vp, _i, _i, _f, _i, _vp]),
     'mos_geglu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     'mos_lsq_workspace_bytes': (_i64, [_i, _i]),
     'mos_lsq_loss_grad_gram': (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),

@@ -232,7 +232,7 @@ def _attn_view(t):
     return t.stride(0), t.stride(1)
 
 
-def _shape(q, k, v, o, heads, scale):
+def _shape(q, k, v, o, heads, scale, causal=False):
     B, Nq, C = q.shape
     s = _lib.AttnShape()
     s.B, s.H, s.Nq, s.Nkv, s.d = B, heads, Nq, k.shape[1], C // heads
@@ -241,10 +241,11 @@ def _shape(q, k, v, o, heads, scale):
     s.v_bs, s.v_rs = _attn_view(v)
     s.o_bs, s.o_rs = _attn_view(o)
     s.scale = float(scale)
+    s.causal = int(bool(causal))
     return s
 
 
-def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True):
+def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True, causal=False):
     """softmax(scale q k^T) v per head. q (B,Nq,C), k/v (B,Nkv,C) views (may be slices of fused buffers).
 
     Returns (o (B,Nq,C), lse (B,H,Nq) fp32 | None, pcols (B,H,Nq,T) fp32 | None).
@@ -252,7 +253,7 @@ def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True):
     _dev(q, k, v, tok_idx)
     B, Nq, C = q.shape
     o = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
-    s = _shape(q, k, v, o, heads, scale)
+    s = _shape(q, k, v, o, heads, scale, causal)
     lse = torch.empty((B, heads, Nq), dtype=torch.float32, device=q.device) if need_lse else None
     T = 0
     pcols = None
@@ -267,10 +268,10 @@ def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True):
     return o, lse, pcols
 
 
-def attn_bwd(q, k, v, o, lse, dO, heads, scale, dq, dk, dv, tok_idx=None, pcols=None, dpcols=None):
+def attn_bwd(q, k, v, o, lse, dO, heads, scale, dq, dk, dv, tok_idx=None, pcols=None, dpcols=None, causal=False):
     """Backward of attn_fwd; dq/dk/dv are preallocated (B,N,C) views (e.g. slices of one fused buffer)."""
     _dev(q, k, v, o, lse, dO, dq, dk, dv, tok_idx, pcols, dpcols)
-    s = _shape(q, k, v, o, heads, scale)
+    s = _shape(q, k, v, o, heads, scale, causal)
     g = _lib.AttnGradStrides()
     g.do_bs, g.do_rs = _attn_view(dO)
     g.dq_bs, g.dq_rs = _attn_view(dq)
@@ -435,3 +436,28 @@ def geglu_bwd(dy, h):
     L = _lib.load()
     _lib.check(L.mos_geglu_bwd(_p(dy), _p(h), _p(dh), rows, F2 // 2, _dt(h), _stream()), 'mos_geglu_bwd')
     return dh
+
+
+def softmax_rows(x, scale, out=None):
+    """softmax(scale * x) over the last dim of a contiguous half (rows, N) tensor (in place when out is x)."""
+    _dev(x)
+    rows, N = x.shape
+    assert x.is_contiguous()
+    y = out if out is not None else torch.empty_like(x)
+    L = _lib.load()
+    _lib.check(L.mos_softmax_rows(_p(x), _p(y), rows, N, float(scale), _dt(x), _stream()), 'mos_softmax_rows')
+    return y
+
+
+def single_head_attention_nograd(q, k, v, scale):
+    """softmax(scale q k^T) v for ONE head of large dim (VAE mid-block: d = 512, N = 4096), forward only: scores GEMM,
+    row softmax, values GEMM per batch element on the library kernels (the (N, N) scores are materialised, 34 MB)."""
+    _dev(q, k, v)
+    B, N, d = q.shape
+    o = torch.empty_like(q)
+    S = torch.empty((N, k.shape[1]), dtype=q.dtype, device=q.device)
+    for i in range(B):
+        linear_fwd(q[i], k[i], out=S)
+        softmax_rows(S, scale, out=S)
+        linear_fwd(S, v[i].t().contiguous(), out=o[i])
+    return o

@@ -3,8 +3,9 @@ transformers version the reference was written against (`text_model.encoder.laye
 ...): ED-LoRA checkpoints name their text-encoder LoRA weights by `named_modules()` path
 (reference trainer_edlora.py:106-112), and the `where:` option matches the class names
 `CLIPAttention` / `CLIPEncoderLayer`. transformers 5.x renamed those paths, so the tower is restated here.
-The 77-token causal self-attention is plumbing (torch SDPA); the q/k/v/out_proj Linear layers are LoRA sites
-and run through the HIP LoRA-linear kernel once wrapped by LoRALinearLayer.
+The 77-token causal self-attention (head dim 64) runs on the library's attention kernels on the device (torch SDPA on
+the CPU / for fp32 inference); the q/k/v/out_proj Linear layers are LoRA sites and run through the HIP LoRA-linear
+kernel once wrapped by LoRALinearLayer.
 """
 from types import SimpleNamespace
 
@@ -64,6 +65,14 @@ class CLIPAttention(nn.Module):
             q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
         else:
             q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        if x.is_cuda and self.head_dim in (40, 64, 80, 160) and (
+                q.dtype in (torch.float16, torch.bfloat16) or torch.is_autocast_enabled('cuda')):
+            # causal 77-token attention on the library kernels (token-major q/k/v, no head permutes, no aotriton)
+            from mixofshow.hip import functional as F_hip
+            cd = F_hip.compute_dtype_for(q)
+            q, k, v = (t if t.dtype == cd else t.to(cd) for t in (q, k, v))
+            o, _ = F_hip.attention(q, k, v, self.num_heads, self.head_dim**-0.5, causal=True)
+            return self.out_proj(o)
         shape = (b, s, self.num_heads, self.head_dim)
         q, k, v = (t.view(shape).transpose(1, 2) for t in (q, k, v))
         o = F.scaled_dot_product_attention(q, k, v, is_causal=True)

@@ -1,7 +1,8 @@
 """AutoencoderKL (SD-1.5 VAE) — plumbing around the hot path: images -> latents for the training step
 (reference trainer_edlora.py:203-204) and latents -> images for validation. Plain PyTorch-ROCm modules with
-diffusers-compatible state-dict keys (0.19 naming: `mid_block.attentions.0.to_q` ...). Out of scope for
-hand-written kernels (SURVEY.md 2.1 last row): its single-head d=512 attention runs through torch SDPA."""
+diffusers-compatible state-dict keys (0.19 naming: `mid_block.attentions.0.to_q` ...). Its single-head d=512 mid-block attention runs as
+scores GEMM -> row softmax -> values GEMM on the library kernels when no gradient is needed (training: frozen encoder),
+torch SDPA otherwise."""
 from types import SimpleNamespace
 
 import torch
@@ -27,7 +28,13 @@ class VaeAttention(nn.Module):
         # token-major view: free for channels_last activations, one copy for NCHW
         y = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(b, h * w, c)
         q, k, v = self.to_q(y), self.to_k(y), self.to_v(y)
-        o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+        half = q.is_cuda and q.dtype in (torch.float16, torch.bfloat16)
+        no_grad = not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad))
+        if half and no_grad and c % 8 == 0 and (h * w) % 8 == 0 and h * w <= 8192:
+            from mixofshow.hip import ops            # frozen VAE (training encodes under no grad): library kernels
+            o = ops.single_head_attention_nograd(q.contiguous(), k.contiguous(), v.contiguous(), c**-0.5)
+        else:
+            o = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
         o = self.to_out[0](o)
         return o.reshape(b, h, w, c).permute(0, 3, 1, 2) + x
 

@@ -87,6 +87,9 @@ class StableDiffusionPipeline:
                 m.to(device)
             if dtype is not None:
                 m.to(dtype)
+        if device is not None and torch.device(device).type == 'cuda':
+            # NHWC on the device: the token-major attention path and MIOpen's fp16 convolutions are channels-last
+            self.unet.to(memory_format=torch.channels_last)
         for extra in ('keypose_adapter', 'sketch_adapter'):
             m = getattr(self, extra, None)
             if m is not None:

@@ -9,7 +9,7 @@ import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
             'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd',
-            'geglu_fwd', 'geglu_bwd')
+            'geglu_fwd', 'geglu_bwd', 'softmax_rows', 'single_head_attention_nograd')
 PAD = 16
 
 
@@ -97,10 +97,17 @@ def _heads(t, H):
     return t.float().reshape(B, N, H, C // H).permute(0, 2, 1, 3)
 
 
-def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True):
+def _causal_mask(s):
+    n, m = s.shape[-2], s.shape[-1]
+    return torch.ones(n, m, dtype=torch.bool, device=s.device).triu(1)        # key index > query index
+
+
+def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True, causal=False):
     B, Nq, C = q.shape
     qh, kh, vh = _heads(q, heads), _heads(k, heads), _heads(v, heads)
     s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        s = s.masked_fill(_causal_mask(s), float('-inf'))
     lse = torch.logsumexp(s, dim=-1)
     p = torch.exp(s - lse[..., None])
     o = (p @ vh).permute(0, 2, 1, 3).reshape(B, Nq, C).to(q.dtype)
@@ -111,10 +118,12 @@ def attn_fwd(q, k, v, heads, scale, tok_idx=None, need_lse=True):
     return o, (lse.contiguous() if need_lse else None), pcols
 
 
-def attn_bwd(q, k, v, o, lse, dO, heads, scale, dq, dk, dv, tok_idx=None, pcols=None, dpcols=None):
+def attn_bwd(q, k, v, o, lse, dO, heads, scale, dq, dk, dv, tok_idx=None, pcols=None, dpcols=None, causal=False):
     B, Nq, C = q.shape
     qh, kh, vh, doh = _heads(q, heads), _heads(k, heads), _heads(v, heads), _heads(dO, heads)
     s = (qh @ kh.transpose(-1, -2)) * scale
+    if causal:
+        s = s.masked_fill(_causal_mask(s), float('-inf'))
     p = torch.exp(s - lse[..., None])
     dvh = p.transpose(-1, -2) @ doh
     dp = doh @ vh.transpose(-1, -2)
@@ -228,3 +237,18 @@ def geglu_bwd(dy, h):
     pdf = 0.3989422804014327 * torch.exp(-0.5 * g * g)
     d = dy.float()
     return torch.cat([d * g * cdf, d * a * (cdf + g * pdf)], -1).to(h.dtype)
+
+
+def softmax_rows(x, scale, out=None):
+    y = torch.softmax(x.float() * scale, -1).to(x.dtype)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def single_head_attention_nograd(q, k, v, scale):
+    """scores and probabilities are rounded to the half type between the GEMMs, like the kernel sequence."""
+    s = (q.float() @ k.float().transpose(-1, -2)).to(q.dtype)
+    p = torch.softmax(s.float() * scale, -1).to(q.dtype)
+    return (p.float() @ v.float()).to(q.dtype)

@@ -429,3 +429,47 @@ def test_geglu(ops, emu, dtype, rows, F):
     (dh_ref, ) = torch.autograd.grad(y_ref, hf, dy.float())
     _check('geglu.dh', dh, dh_ref, dtype, ulps=2.0)
     _check('geglu.dh (emulation formula)', emu.geglu_bwd(dy, h), dh_ref, dtype, ulps=2.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,N,d', [(64, 12, 77, 64), (3, 12, 77, 64), (2, 12, 200, 64), (2, 8, 130, 40)])
+def test_causal_attention_head_dim_64(ops, emu, dtype, B, H, N, d):
+    """CLIP text tower: 12 heads x d = 64, 77 tokens, causal (key index > query index masked), forward + backward vs the
+    emulation; q/k/v are column slices of one fused projection buffer, like the product path."""
+    g = torch.Generator(device='cpu').manual_seed(12)
+    C = H * d
+    buf = torch.randn(B, N, 3 * C, generator=g).to('cuda', dtype)
+    q, k, v = buf[..., :C], buf[..., C:2 * C], buf[..., 2 * C:]
+    scale = d**-0.5
+    o, lse, _ = ops.attn_fwd(q, k, v, H, scale, causal=True)
+    o_r, lse_r, _ = emu.attn_fwd(q, k, v, H, scale, causal=True)
+    _check(f'causal attn.o[{B}x{H}x{N}x{d}]', o, o_r, dtype)
+    _check('causal attn.lse', lse, lse_r, torch.float16, ulps=0.5)
+    # first token attends to itself only: its output is exactly v[0]
+    _check('causal attn.o[token 0] == v[0]', o[:, 0], v[:, 0], dtype, ulps=1.0)
+    dO = torch.randn(B, N, C, generator=g).to('cuda', dtype)
+    dbuf, dref = torch.empty_like(buf), torch.empty_like(buf)
+    ops.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dbuf[..., :C], dbuf[..., C:2 * C], dbuf[..., 2 * C:], causal=True)
+    emu.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dref[..., :C], dref[..., C:2 * C], dref[..., 2 * C:], causal=True)
+    for name, sl in (('dq', slice(0, C)), ('dk', slice(C, 2 * C)), ('dv', slice(2 * C, 3 * C))):
+        _check(f'causal attn.{name}', dbuf[..., sl], dref[..., sl], dtype)
+    # and the non-causal path at d = 64 (a head dim the UNet never uses)
+    o2, _, _ = ops.attn_fwd(q, k, v, H, scale)
+    _check('attn d64 non-causal', o2, emu.attn_fwd(q, k, v, H, scale)[0], dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
+    """VAE mid-block attention (one head, d = 512) as scores GEMM -> row softmax -> values GEMM on the library kernels vs
+    the emulation and vs exact fp32 attention."""
+    g = torch.Generator(device='cpu').manual_seed(13)
+    x = (torch.randn(300, 4096, generator=g) * 3).to('cuda', dtype)
+    _check('softmax_rows', ops.softmax_rows(x, 0.7), emu.softmax_rows(x, 0.7), dtype, ulps=2.0)
+    x2 = (torch.randn(50, 1000, generator=g) * 3).to('cuda', dtype)
+    _check('softmax_rows (ragged chunk count)', ops.softmax_rows(x2, 1.3), emu.softmax_rows(x2, 1.3), dtype, ulps=2.0)
+    B, N, d = 2, 1024, 512
+    q, k, v = ((torch.randn(B, N, d, generator=g) * 0.5).to('cuda', dtype) for _ in range(3))
+    o = ops.single_head_attention_nograd(q, k, v, d**-0.5)
+    _check('vae attention vs emulation', o, emu.single_head_attention_nograd(q, k, v, d**-0.5), dtype)
+    exact = torch.softmax(q.float() @ k.float().transpose(-1, -2) * d**-0.5, -1) @ v.float()
+    _check('vae attention vs exact fp32', o, exact, dtype, ulps=6.0)

@@ -51,7 +51,8 @@ def train(root_path, args):
     total_batch = trainset_cfg['batch_size_per_gpu'] * world * accum
     total_iter = len(train_dataset) / total_batch       # a float, like the reference (:74)
     opt['train']['total_iter'] = total_iter
-    engine = TrainEngine(trainer, opt['train'], total_iter, opt.get('mixed_precision', 'fp16'), accum)
+    engine = TrainEngine(trainer, opt['train'], total_iter, opt.get('mixed_precision', 'fp16'), accum,
+                         channels_last=bool(opt['train'].get('channels_last', True)))
     logger.info(f'***** Running training *****  examples={len(train_dataset)} per-device batch='
                 f"{trainset_cfg['batch_size_per_gpu']} total batch={total_batch} steps={total_iter} "
                 f'grad bucket={engine.bucket.nbytes / 1e6:.2f} MB world={world}')
