@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', default='train')
     ap.add_argument('--precision', default='fp16')
-    ap.add_argument('--rows', type=int, default=45)
+    ap.add_argument('--rows', type=int, default=70)
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     if args.mode == 'train':
@@ -49,16 +49,53 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         fn()
         torch.cuda.synchronize()
-    ka = prof.key_averages()
-    dev_attr = 'self_device_time_total' if hasattr(ka[0], 'self_device_time_total') else 'self_cuda_time_total'
-    rows = [(getattr(k, dev_attr), k.count, k.key) for k in ka if getattr(k, dev_attr) > 0]
-    rows.sort(reverse=True)
+    # device-side kernel records only (operator rows double count their kernels)
+    from torch.autograd import DeviceType
+    agg = {}
+    for e in prof.events():
+        if e.device_type == DeviceType.CUDA:
+            t = getattr(e, 'device_time_total', None)
+            if t is None:
+                t = e.cuda_time_total
+            a = agg.setdefault(e.name, [0.0, 0])
+            a[0] += t
+            a[1] += 1
+    rows = sorted(((t, c, k) for k, (t, c) in agg.items()), reverse=True)
     busy = sum(r[0] for r in rows)
     launches = sum(r[1] for r in rows)
-    print(f'mode={args.mode} wall per call = {wall * 1e3:.2f} ms ; GPU busy (sum of kernel time) = {busy / 1e3:.2f} ms ; '
+
+    def cat(k):
+        kl = k.lower()
+        if 'igemm' in kl or 'conv' in kl and 'ck' in kl or 'miopen' in kl or 'naive_conv' in kl:
+            return 'MIOpen convolution'
+        if 'batched_transpose' in kl or 'subtensorop' in kl:
+            return 'MIOpen layout / tensor ops'
+        if kl.startswith('cijk_') or 'custom_cijk' in kl:
+            return 'hipBLASLt / rocBLAS GEMM'
+        if '_global__n_1' in kl or 'anonymous namespace' in kl and ('lora' in kl or 'gn_' in kl):
+            return 'libmos_hip (this library)'
+        if 'attn_fwd' == kl or 'bwd_kernel' in kl:
+            return 'aotriton attention'
+        if 'copy' in kl or 'cat' in kl:
+            return 'ATen copies / cat'
+        if 'elementwise' in kl or 'reduce' in kl or 'fill' in kl.lower():
+            return 'ATen elementwise / reduce / fill'
+        if 'multi_tensor' in kl or 'adam' in kl:
+            return 'optimizer'
+        return 'other'
+
+    cats = {}
+    for t, c, k in rows:
+        a = cats.setdefault(cat(k), [0.0, 0])
+        a[0] += t
+        a[1] += c
+    print(f'mode={args.mode} wall per call = {wall * 1e3:.2f} ms (eager launch) ; GPU busy (sum of kernel time) = {busy / 1e3:.2f} ms ; '
           f'kernel launches = {launches}')
+    for name, (t, c) in sorted(cats.items(), key=lambda kv: -kv[1][0]):
+        print(f'  {t / 1e3:9.3f} ms {100 * t / busy:5.1f}%  x{c:<5d} {name}')
+    print()
     for t, c, k in rows[:args.rows]:
-        print(f'{t / 1e3:9.3f} ms {100 * t / busy:5.1f}%  x{c:<5d} {k[:130]}')
+        print(f'{t / 1e3:9.3f} ms {100 * t / busy:5.1f}%  x{c:<5d} {k[:150]}')
 
 
 if __name__ == '__main__':
