@@ -290,10 +290,52 @@ def main():
     out['merge'] = dict(sd=sd, lora=lora_sd, alpha=0.6, merged=merged, te_sd=te_sd, te_lora=te_lora, te_alpha=0.8,
                         merged_te=merged_te)
 
+    out['adapter'] = adapter_region_weight_golden()
     path = os.path.join(HERE, 'reference_golden.pt')
     torch.save(out, path)
     print(f'wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
 
 
+def adapter_region_weight_golden():
+    """G7: the region-weighted T2I-Adapter feature rule. The reference has it inline in the pipeline's __call__
+    (mixofshow/pipelines/pipeline_regionally_t2iadapter.py:484-542: `num_states = ...` up to `adapter_state.append`), so
+    the golden is produced by executing exactly those source lines, dedented, on seeded stand-ins for the adapter outputs."""
+    import math
+    import textwrap
+    src = open(os.path.join(REF, 'mixofshow/pipelines/pipeline_regionally_t2iadapter.py')).read().splitlines()
+    first = next(i for i, l in enumerate(src) if l.strip().startswith('num_states = len(keypose_adapter_state)'))
+    last = next(i for i, l in enumerate(src) if i > first and l.strip() == 'adapter_state.append(feat_keypose + feat_sketch)')
+    code = textwrap.dedent('\n'.join(src[first:last + 1]))
+    cases = {}
+    height, width = 512, 768
+    g = torch.Generator().manual_seed(40)
+    shapes = [(1, 8, 64, 96), (1, 8, 32, 48), (1, 8, 16, 24), (1, 8, 8, 12)]
+    kp = [torch.randn(s, generator=g) for s in shapes]
+    sk = [torch.randn(s, generator=g) for s in shapes]
+    specs = dict(
+        keypose_only=dict(kp=True, sk=False, kw=1.0, sw=1.0, rk='', rs=''),
+        both=dict(kp=True, sk=True, kw=0.8, sw=0.5, rk='', rs=''),
+        region_keypose=dict(kp=True, sk=False, kw=1.0, sw=1.0, rk='[2, 2, 512, 184]-0.0|[7, 184, 512, 345]-0.5', rs=''),
+        region_both=dict(kp=True, sk=True, kw=1.0, sw=0.7, rk='[1, 488, 512, 747]-0.25', rs='[100, 150, 400, 300]-1.5|[0, 0, 511, 767]-0.1'),
+        sketch_only=dict(kp=False, sk=True, kw=1.0, sw=0.9, rk='', rs='[33, 17, 301, 500]-0.0'),
+    )
+    for name, c in specs.items():
+        ns = dict(math=math, torch=torch, height=height, width=width,
+                  keypose_adapter_state=[t.clone() for t in kp] if c['kp'] else None,
+                  sketch_adapter_state=[t.clone() for t in sk] if c['sk'] else None,
+                  keypose_adaptor_weight=c['kw'], sketch_adaptor_weight=c['sw'],
+                  region_keypose_adaptor_weight=c['rk'], region_sketch_adaptor_weight=c['rs'])
+        exec(code, ns)                                      # the reference's own lines
+        cases[name] = dict(spec=c, out=[t.clone() for t in ns['adapter_state']])
+    return dict(height=height, width=width, keypose=kp, sketch=sk, cases=cases, source_lines=(first + 1, last + 1))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'adapter':      # add G7 to the existing fixture without touching the rest
+        path = os.path.join(HERE, 'reference_golden.pt')
+        out = torch.load(path, weights_only=False)
+        out['adapter'] = adapter_region_weight_golden()
+        torch.save(out, path)
+        print('added adapter golden; reference source lines', out['adapter']['source_lines'])
+    else:
+        main()

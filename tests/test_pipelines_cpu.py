@@ -146,3 +146,38 @@ def test_region_kv_cache_is_dropped_at_every_call(emulated_hip):
         p._kv_key = _AlwaysEqual()
     b = run('a <potter1> <potter2>')
     torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_adapter_region_weighting_vs_reference_golden(golden):
+    """(f2) T2I-Adapter region-weight rule: the product's `_adapter_states` + keypose/sketch sum against the outputs of the
+    reference's own source lines (pipeline_regionally_t2iadapter.py:484-542, executed by tests/golden/make_golden.py)."""
+    from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionallyT2IAdapterPipeline
+    a = golden['adapter']
+    H, W = a['height'], a['width']
+
+    class _Fixed(torch.nn.Module):          # an "adapter" that returns the seeded features the golden was made with
+        def __init__(self, feats):
+            super().__init__()
+            self.feats = feats
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        @property
+        def dtype(self):
+            return torch.float32
+
+        def forward(self, x):
+            return [f.clone() for f in self.feats]
+
+    pipe = RegionallyT2IAdapterPipeline.from_pretrained('synthetic://tiny?seed=0', torch_dtype=torch.float32)
+    dummy = torch.zeros(1, 3, H, W)
+    for name, case in a['cases'].items():
+        c = case['spec']
+        kp = pipe._adapter_states(_Fixed(a['keypose']) if c['kp'] else None, dummy if c['kp'] else None, c['kw'], c['rk'], H, W)
+        sk = pipe._adapter_states(_Fixed(a['sketch']) if c['sk'] else None, dummy if c['sk'] else None, c['sw'], c['rs'], H, W)
+        if kp is not None and sk is not None:
+            got = [x + y for x, y in zip(kp, sk)]
+        else:
+            got = kp if kp is not None else sk
+        assert len(got) == len(case['out']) == 4
+        for g, r in zip(got, case['out']):
+            torch.testing.assert_close(g, r, rtol=1e-6, atol=1e-6, msg=name)
