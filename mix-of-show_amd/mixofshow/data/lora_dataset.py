@@ -1,15 +1,14 @@
 """Training data for the ED-LoRA tune.
 
-The reference's LoraDataset (mixofshow/data/lora_dataset.py:13-102 + pil_transform.py) is CPU data preparation
-built on torchvision / cv2 (neither is installed here) and is OUT OF SCOPE of the hot path. Two
-datasets are provided behind the same `datasets.train` option block:
+The reference's LoraDataset (mixofshow/data/lora_dataset.py:13-102 + pil_transform.py) is CPU data preparation built on
+torchvision / cv2 (neither is installed here); it is a CALLER of the hot path. Two datasets are provided
+behind the same `datasets.train` option block:
   * `SyntheticLoraDataset` (name: SyntheticLoraDataset, or concept_list: synthetic://...): seeded
     tensors of the shapes the trainer consumes — images U(-1,1) (3,512,512), masks = centred box of ones in
     (1,64,64), img_masks ones, captions with the concept tokens. Used by bench.py and the tests.
-  * `LoraDataset`: a PIL-only loader for real concept folders supporting resize + centre-crop to `size`, ToTensor,
-    Normalize, caption files, mask folders and `replace_mapping`. The reference's augmentation transforms
-    (HumanResizeCropFinalV3, ShuffleCaption, EnhanceText, ...) are accepted in the option list and mapped to the
-    deterministic centre-crop pipeline; their random behaviour is not reproduced.
+  * `LoraDataset`: the reference's dataset on a PIL + numpy restatement of its transforms (mixofshow.data.pil_transform:
+    HumanResizeCropFinalV3, ResizeFillMaskNew, ShuffleCaption, EnhanceText, ToTensor, Normalize, ...), consuming Python's
+    `random` and torch's RNG in the reference order.
 """
 import json
 import os
@@ -45,66 +44,64 @@ class SyntheticLoraDataset(Dataset):
 
 
 class LoraDataset(Dataset):
+    """Concept images + captions + masks for the ED-LoRA tune (reference mixofshow/data/lora_dataset.py:13-102): every
+    file of each `instance_data_dir` (except .DS_Store), caption = first line of `<caption_dir>/<stem>.txt` when
+    `use_caption`, mask = `<mask_dir>/<stem>.png` when `use_mask`; `replace_mapping` applied, runs of spaces squeezed; the
+    list is shuffled once with Python's `random`; samples go through the `instance_transform` chain
+    (mixofshow.data.pil_transform). Items: images (3,S,S), img_masks (1,S/8,S/8), prompts, and masks (1,S/8,S/8) only
+    when a mask file is configured — without it the training loop falls back to img_masks, like the reference."""
 
     def __init__(self, opt):
-        from PIL import Image  # noqa: F401
+        from mixofshow.data.pil_transform import PairCompose, build_transform
         self.opt = opt
         with open(opt['concept_list'], 'r') as f:
             concept_list = json.load(f)
-        self.size = 512
-        for t in opt.get('instance_transform', []):
-            if 'size' in t:
-                self.size = int(t['size'])
-        self.use_caption = opt.get('use_caption', False)
-        self.use_mask = opt.get('use_mask', False)
-        self.mapping = opt.get('replace_mapping', {}) or {}
+        mapping = opt.get('replace_mapping', {}) or {}
+        use_caption = opt.get('use_caption', False)
+        use_mask = opt.get('use_mask', False)
         self.items = []
         for concept in concept_list:
-            d = concept['instance_data_dir']
-            for fn in sorted(os.listdir(d)):
-                if not fn.lower().endswith(('.png', '.jpg', '.jpeg', '.webp')):
+            prompt = self.process_text(concept['instance_prompt'], mapping)
+            caption_dir, mask_dir = concept.get('caption_dir'), concept.get('mask_dir')
+            for fn in sorted(os.listdir(concept['instance_data_dir'])):       # sorted: a deterministic pre-shuffle order
+                path = os.path.join(concept['instance_data_dir'], fn)
+                if not os.path.isfile(path) or fn == '.DS_Store':
                     continue
                 stem = os.path.splitext(fn)[0]
-                cap = concept['instance_prompt']
-                if self.use_caption and concept.get('caption_dir'):
-                    cp = os.path.join(concept['caption_dir'], stem + '.txt')
+                cap = prompt
+                if use_caption and caption_dir is not None:
+                    cp = os.path.join(caption_dir, stem + '.txt')
                     if os.path.exists(cp):
-                        cap = open(cp).read().strip()
-                mask = None
-                if self.use_mask and concept.get('mask_dir'):
-                    mp = os.path.join(concept['mask_dir'], stem + '.png')
-                    mask = mp if os.path.exists(mp) else None
-                self.items.append((os.path.join(d, fn), cap, mask))
+                        with open(cp, 'r') as fr:
+                            cap = self.process_text(fr.readlines()[0], mapping)
+                mask = os.path.join(mask_dir, stem + '.png') if (use_mask and mask_dir is not None) else None
+                self.items.append((path, cap, mask))
         random.shuffle(self.items)
         self.enlarge = int(opt.get('dataset_enlarge_ratio', 1))
+        self.instance_transform = PairCompose([build_transform(t) for t in opt['instance_transform']])
+
+    @staticmethod
+    def process_text(text, mapping):
+        for k, v in mapping.items():
+            text = text.replace(k, v)
+        return re.sub(' +', ' ', text.strip())
 
     def __len__(self):
         return len(self.items) * self.enlarge
 
-    def _load(self, path, mode, size, nearest=False):
-        import numpy as np
-        from PIL import Image
-        im = Image.open(path).convert(mode)
-        w, h = im.size
-        s = size / min(w, h)
-        im = im.resize((max(size, round(w * s)), max(size, round(h * s))), Image.NEAREST if nearest else Image.BICUBIC)
-        w, h = im.size
-        l, t = (w - size) // 2, (h - size) // 2
-        im = im.crop((l, t, l + size, t + size))
-        return torch.from_numpy(np.array(im)).float() / 255.0
-
     def __getitem__(self, index):
+        from PIL import Image
         path, cap, mask = self.items[index % len(self.items)]
-        img = self._load(path, 'RGB', self.size).permute(2, 0, 1) * 2 - 1
-        for k, v in self.mapping.items():
-            cap = cap.replace(k, v)
-        cap = re.sub(' +', ' ', cap.strip())
-        m = self.size // 8
-        out = {'images': img, 'prompts': cap, 'img_masks': torch.ones(1, m, m)}
+        extra = {'prompts': cap}
         if mask is not None:
-            mk = self._load(mask, 'L', self.size, nearest=True)[None]
-            out['masks'] = torch.nn.functional.interpolate(mk[None], size=(m, m), mode='nearest')[0]
-        # no mask file: the key is omitted (reference lora_dataset.py:90-94) and the loop falls back to img_masks
+            extra['mask'] = Image.open(mask).convert('L')
+        img, extra = self.instance_transform(Image.open(path).convert('RGB'), **extra)
+        if 'img_mask' not in extra:
+            raise NotImplementedError('the instance_transform chain must produce `img_mask` '
+                                      '(HumanResizeCropFinalV3 / ResizeFillMaskNew; reference lora_dataset.py:96-99)')
+        out = {'images': img, 'img_masks': extra['img_mask'].unsqueeze(0).float(), 'prompts': extra['prompts']}
+        if 'mask' in extra:
+            out['masks'] = extra['mask'].unsqueeze(0).float()
         return out
 
 

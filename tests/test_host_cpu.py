@@ -430,9 +430,11 @@ def test_engine_gradient_accumulation(emulated_hip):
 
 
 def test_lora_dataset_from_image_folders(tmp_path):
-    """The PIL loader behind `datasets.train` for real concept folders: concept_list json, caption files, mask
-    folder, <TOK> replacement, resize + centre crop to `size`, [-1, 1] normalisation, 1/8-resolution masks."""
+    """LoraDataset on real concept folders through the restated transform chain (reference lora_dataset.py + pil_transform.py):
+    concept_list json, caption files, mask folder, <TOK> replacement, HumanResizeCropFinalV3 geometry (placement on the
+    canvas, img_mask, 1/8-resolution masks), ShuffleCaption / EnhanceText, determinism under seeding."""
     import json
+    import random
     import numpy as np
     from PIL import Image
     from mixofshow.data.lora_dataset import LoraDataset, SyntheticLoraDataset, build_train_dataset
@@ -441,8 +443,8 @@ def test_lora_dataset_from_image_folders(tmp_path):
         d.mkdir()
     rng = np.random.default_rng(0)
     for i, (w, h) in enumerate([(96, 64), (64, 128)]):                        # landscape and portrait
-        Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8), 'RGB').save(img_dir / f'{i}.png')
-        (cap_dir / f'{i}.txt').write_text(f'a  <TOK> number {i} ')
+        Image.fromarray(rng.integers(1, 255, (h, w, 3), dtype=np.uint8), 'RGB').save(img_dir / f'{i}.png')
+        (cap_dir / f'{i}.txt').write_text(f'a  <TOK> number {i}, smiling, outdoors \nsecond line ignored')
         m = np.zeros((h, w), dtype=np.uint8)
         m[h // 4:3 * h // 4, w // 4:3 * w // 4] = 255
         Image.fromarray(m, 'L').save(mask_dir / f'{i}.png')
@@ -450,19 +452,34 @@ def test_lora_dataset_from_image_folders(tmp_path):
     clist.write_text(json.dumps([dict(instance_prompt='<TOK>', instance_data_dir=str(img_dir),
                                       caption_dir=str(cap_dir), mask_dir=str(mask_dir))]))
     opt = dict(name='LoraDataset', concept_list=str(clist), use_caption=True, use_mask=True,
-               instance_transform=[dict(type='HumanResizeCropFinalV3', size=64, crop_p=0.5), dict(type='ToTensor')],
+               instance_transform=[dict(type='HumanResizeCropFinalV3', size=64, crop_p=0.5), dict(type='ToTensor'),
+                                   dict(type='Normalize', mean=[0.5], std=[0.5]), dict(type='ShuffleCaption', keep_token_num=1)],
                replace_mapping={'<TOK>': '<potter1> <potter2>'}, dataset_enlarge_ratio=3)
-    ds = build_train_dataset(opt)
+
+    def draw(seed):
+        random.seed(seed); torch.manual_seed(seed)
+        ds = build_train_dataset(opt)
+        return ds, [ds[i] for i in range(len(ds))]
+
+    ds, items = draw(0)
     assert isinstance(ds, LoraDataset) and len(ds) == 6
-    seen = set()
-    for i in range(len(ds)):
-        it = ds[i]
+    for it in items:
         assert it['images'].shape == (3, 64, 64) and -1.0 <= it['images'].min() and it['images'].max() <= 1.0
         assert it['masks'].shape == (1, 8, 8) and it['img_masks'].shape == (1, 8, 8)
-        assert set(it['masks'].unique().tolist()) <= {0.0, 1.0} and 0 < it['masks'].sum() < 64
-        assert it['masks'][0, 4, 4] == 1 and it['masks'][0, 0, 0] == 0                   # centred box survives the crop
-        seen.add(it['prompts'])
-    assert seen == {'a <potter1> <potter2> number 0', 'a <potter1> <potter2> number 1'}  # replaced, spaces squeezed
+        im, mk = it['img_masks'][0], it['masks'][0]
+        assert set(im.unique().tolist()) <= {0.0, 0.5, 0.25, 0.75, 1.0} and im.sum() > 0
+        assert 0 < mk.sum() <= im.sum() and bool((mk <= im + 1e-6).all())        # the object mask lies inside the image area
+        # the placed image is one rectangle of non-black pixels on a black (-1 after Normalize) canvas
+        nz = (it['images'] != -1).any(0).nonzero()
+        (y0, x0), (y1, x1) = nz.min(0).values.tolist(), nz.max(0).values.tolist()
+        assert (y1 - y0 + 1) * (x1 - x0 + 1) == nz.shape[0] and max(y1 - y0, x1 - x0) + 1 in (63, 64)
+        first, *rest = it['prompts'].split(', ')
+        assert first.startswith('a <potter1> <potter2> number') and sorted(rest) == ['outdoors', 'smiling']
+    _, again = draw(0)
+    for a, b in zip(items, again):                                              # seeded -> identical samples
+        assert torch.equal(a['images'], b['images']) and a['prompts'] == b['prompts'] and torch.equal(a['masks'], b['masks'])
+    _, other = draw(1)
+    assert any(not torch.equal(a['images'], b['images']) for a, b in zip(items, other))
     # without captions / masks: the instance prompt, and NO 'masks' key (reference lora_dataset.py:90-94: the loop
     # falls back to img_masks)
     plain = LoraDataset(dict(opt, use_caption=False, use_mask=False))
@@ -472,6 +489,30 @@ def test_lora_dataset_from_image_folders(tmp_path):
         build_train_dataset(dict(opt, concept_list=str(tmp_path / 'nope.json')))
     assert isinstance(build_train_dataset(dict(opt, concept_list='synthetic://potter')), SyntheticLoraDataset)
     assert isinstance(build_train_dataset(dict(opt, name='SyntheticLoraDataset')), SyntheticLoraDataset)
+
+
+def test_pil_transform_geometry_rules():
+    """The size rules the reference inherits from torchvision / cv2, pinned as known answers."""
+    import numpy as np
+    from PIL import Image
+    from mixofshow.data import pil_transform as T
+    assert T._resized_size(768, 512, 512) == (768, 512) and T._resized_size(400, 900, 512) == (512, 1152)
+    assert T._resized_size(900, 400, 511, 512) == (512, 227)           # long edge capped by max_size
+    assert T._resized_size(512, 512, 511, 512) == (511, 511)           # square inputs end up 511 px (reference quirk)
+    a = np.arange(64 * 64, dtype=np.float64).reshape(64, 64)
+    r = T._cv2_resize_linear(a, 8, 8)                                   # 8x reduction: mean of the central 2x2 of each cell
+    assert r.shape == (8, 8) and abs(r[0, 0] - a[3:5, 3:5].mean()) < 1e-9 and abs(r[7, 7] - a[59:61, 59:61].mean()) < 1e-9
+    up = T._cv2_resize_linear(np.array([[0.0, 1.0]]), 4, 1)             # upsampling: half-pixel centres, edge replicate
+    assert np.allclose(up, [[0.0, 0.25, 0.75, 1.0]])
+    img = Image.fromarray(np.zeros((40, 60, 3), np.uint8))
+    assert T.CenterCrop(20).forward(img).size == (20, 20) and T.Resize(20).forward(img).size == (30, 20)
+    torch.manual_seed(0)
+    assert T.RandomCrop(40).forward(Image.fromarray(np.zeros((40, 40, 3), np.uint8))).size == (40, 40)
+    t = T.ToTensor().forward(Image.fromarray(np.full((4, 6, 3), 255, np.uint8)))
+    assert t.shape == (3, 4, 6) and float(t.max()) == 1.0
+    assert float(T.Normalize([0.5], [0.5]).forward(t).max()) == 1.0
+    with pytest.raises(KeyError):
+        T.build_transform(dict(type='NoSuchTransform'))
 
 
 def test_plain_lora_mode_train_convert_sample(emulated_hip):
