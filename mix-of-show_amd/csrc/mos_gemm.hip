@@ -32,11 +32,14 @@
 #ifndef MOS_GRAD_TARGET_WG
 #define MOS_GRAD_TARGET_WG 1024   // workgroups the fused LoRA-gradient kernel aims at
 #endif
+#ifndef MOS_GEMM_DEEP_MAX_WG
+#define MOS_GEMM_DEEP_MAX_WG 96   // GEMMs with at most this many workgroups use the deep-stage variants (measured: a win only
+#endif                            // for M = 256; at 160+ workgroups the larger LDS footprint costs more than it hides); 0 = off
+
 
 namespace {
 
-constexpr int GEMM_BK = 64;
-constexpr int GEMM_LDS_STRIDE = GEMM_BK + 8;  // 144 B rows: 16B-slot index r*9 mod 16 is a bijection
+constexpr int GEMM_BK = 64;                   // default K depth of a stage
 
 struct GemmArgs {
     const void* X; const void* W; const void* Taug; const void* Adown; const void* Baug; const float* bias;
@@ -46,24 +49,33 @@ struct GemmArgs {
 };
 
 // Y[M,N] = X[M,K].W[N,K]^T (+ t.Baug^T) (+ bias), t = X.Adown^T computed in the same K loop (FUSED) or read from Taug.
-// Tiles are fetched with buffer loads whose descriptors end at the last valid row: rows past M / N read as zeros in
-// hardware (no clamps, no selects in the prefetch); KTAIL (K % 64 != 0, not an SD-1.5 shape) adds a column select.
-// Block -> tile map is XCD-aware: the nt blocks that share one X row-tile get consecutive slots on ONE XCD (workgroup
-// id % 8), so X is pulled into a single L2 once instead of being re-fetched by up to nt XCDs.
-template <typename T, int BM, int BN, bool FUSED, bool KTAIL>
+//   * Tiles are fetched with buffer loads whose descriptors end at the last valid row: rows past M / N read as zeros in
+//     hardware (no clamps, no selects in the prefetch); KTAIL (K % 64 != 0, not an SD-1.5 shape) adds a column select.
+//   * Block -> tile map is XCD-aware: the nt blocks that share one X row-tile get consecutive slots on ONE XCD (workgroup
+//     id % 8), so X is pulled into a single L2 once instead of being re-fetched by up to nt XCDs.
+//   * BK = K depth of one pipeline stage. The MFMA work of a 64-deep stage is ~80 ns per wave against ~0.7 us of memory
+//     latency, so with few workgroups the K loop is a chain of exposed latencies. Deeper stages (BK 256 / 128: 4x / 2x the
+//     bytes in flight per block) were measured: +30 % SLOWER at 160-460 workgroups (one block per CU left), a win only
+//     below ~100 workgroups (M = 256). hipBLASLt sits at the same level on these shapes (profiles/r02_kernel_bench_gemm_vs_hipblaslt.txt).
+//   * The output tile goes through LDS so that every store instruction writes whole 16 B chunks of consecutive features
+//     (a lane's accumulators are 4 features of one token: written directly, a wave's store touches 16 rows x 32 B).
+template <typename T, int BM, int BN, int BK, bool FUSED, bool KTAIL>
 __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
     typedef typename MT<T>::v8 v8;
     typedef typename MT<T>::v4 v4;
     constexpr int MI = BM / 32;             // 16-row m sub-tiles per wave (wave tile = BM/2 x BN/2)
     constexpr int NJ = BN / 32;             // 16-wide n sub-tiles per wave
-    constexpr int XCH = BM * 8 / 256;       // 16 B chunks of the X tile per thread
-    constexpr int WCH = BN * 8 / 256;
-    constexpr int LS = GEMM_LDS_STRIDE;
+    constexpr int CPR = BK / 8;             // 16 B chunks per tile row
+    constexpr int XCH = BM * CPR / 256;     // chunks of the X tile per thread
+    constexpr int WCH = BN * CPR / 256;
+    constexpr int ACH = (16 * CPR + 255) / 256;
+    constexpr int LS = BK + 8;              // LDS row stride: (BK/8 + 1) 16-byte slots, odd -> conflict-free b128 reads
+    constexpr int CS = BN + 8;              // output staging stride
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Xs = reinterpret_cast<T*>(smem_raw);                       // [2][BM][72]
-    T* Ws = Xs + 2 * BM * LS;                                     // [2][BN][72]
-    T* As = Ws + 2 * BN * LS;                                     // [2][16][72]   (FUSED)
+    T* Xs = reinterpret_cast<T*>(smem_raw);                       // [2][BM][LS]
+    T* Ws = Xs + 2 * BM * LS;                                     // [2][BN][LS]
+    T* As = Ws + 2 * BN * LS;                                     // [2][16][LS]   (FUSED)
 
     const int w = blockIdx.x;
     const int slot = w >> 3;
@@ -84,18 +96,22 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
     const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * a.ldw + K) * (int64_t)sizeof(T)));
     const rsrc_t asrc = make_rsrc(FUSED ? a.Adown : a.W, (uint32_t)(FUSED ? 16 * (int64_t)K * sizeof(T) : 16));
 
-    int xoff[XCH], woff[WCH];
+    int xoff[XCH], woff[WCH], aoff[ACH];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int c = tid + 256 * i;
-        xoff[i] = (int)((((int64_t)(m0 + (c >> 3))) * a.ldx + (c & 7) * 8) * (int64_t)sizeof(T));
+        xoff[i] = (int)((((int64_t)(m0 + c / CPR)) * a.ldx + (c % CPR) * 8) * (int64_t)sizeof(T));
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
         const int c = tid + 256 * i;
-        woff[i] = (int)((((int64_t)(n0 + (c >> 3))) * a.ldw + (c & 7) * 8) * (int64_t)sizeof(T));
+        woff[i] = (int)((((int64_t)(n0 + c / CPR)) * a.ldw + (c % CPR) * 8) * (int64_t)sizeof(T));
     }
-    const int aoff = (int)(((int64_t)(tid >> 3) * K + (tid & 7) * 8) * (int64_t)sizeof(T));   // tid < 128
+#pragma unroll
+    for (int i = 0; i < ACH; ++i) {
+        const int c = min(tid + 256 * i, 16 * CPR - 1);
+        aoff[i] = (int)(((int64_t)(c / CPR) * K + (c % CPR) * 8) * (int64_t)sizeof(T));
+    }
 
     f32x4 acc[NJ][MI];
     f32x4 acct[MI];
@@ -106,26 +122,29 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
         for (int j = 0; j < NJ; ++j) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    u32x4 xr[XCH], wr[WCH], ar;
-    const int nk = (K + GEMM_BK - 1) / GEMM_BK;
+    u32x4 xr[XCH], wr[WCH], ar[ACH];
+    const int nk = (K + BK - 1) / BK;
 
     auto load_tile = [&](int kt) {
-        const int kb = kt * GEMM_BK * (int)sizeof(T);
+        const int kb = kt * BK * (int)sizeof(T);
 #pragma unroll
         for (int i = 0; i < XCH; ++i) xr[i] = ldbuf16(xsrc, xoff[i] + kb);
 #pragma unroll
         for (int i = 0; i < WCH; ++i) wr[i] = ldbuf16(wsrc, woff[i] + kb);
         if constexpr (FUSED) {
-            if (tid < 128) ar = ldbuf16(asrc, aoff + kb);
+#pragma unroll
+            for (int i = 0; i < ACH; ++i)
+                if (tid + 256 * i < 16 * CPR) ar[i] = ldbuf16(asrc, aoff[i] + kb);
         }
-        if constexpr (KTAIL) {      // columns past K inside a valid row belong to the next row: mask them
-            const bool ok = (kt * GEMM_BK + (tid & 7) * 8) < K;
+        if constexpr (KTAIL) {      // columns past K inside a valid row belong to the next row: mask them (BK = 64 here)
+            const bool ok = (kt * BK + (tid % CPR) * 8) < K;
             if (!ok) {
 #pragma unroll
                 for (int i = 0; i < XCH; ++i) xr[i] = u32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < WCH; ++i) wr[i] = u32x4{0, 0, 0, 0};
-                ar = u32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < ACH; ++i) ar[i] = u32x4{0, 0, 0, 0};
             }
         }
     };
@@ -135,15 +154,19 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int c = tid + 256 * i;
-            st16(xs + (c >> 3) * LS + (c & 7) * 8, xr[i]);
+            st16(xs + (c / CPR) * LS + (c % CPR) * 8, xr[i]);
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
             const int c = tid + 256 * i;
-            st16(ws + (c >> 3) * LS + (c & 7) * 8, wr[i]);
+            st16(ws + (c / CPR) * LS + (c % CPR) * 8, wr[i]);
         }
         if constexpr (FUSED) {
-            if (tid < 128) st16(As + buf * 16 * LS + (tid >> 3) * LS + (tid & 7) * 8, ar);
+#pragma unroll
+            for (int i = 0; i < ACH; ++i) {
+                const int c = tid + 256 * i;
+                if (c < 16 * CPR) st16(As + buf * 16 * LS + (c / CPR) * LS + (c % CPR) * 8, ar[i]);
+            }
         }
     };
 
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
         const T* ws = Ws + cur * BN * LS + (wn * (BN / 2) + l15) * LS + lg * 8;
         const T* as = As + cur * 16 * LS + l15 * LS + lg * 8;
 #pragma unroll
-        for (int kk = 0; kk < GEMM_BK / 32; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             v8 bfrag[MI], afrag[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) bfrag[i] = as_v8<T>(ld16(xs + i * 16 * LS + kk * 32));
@@ -207,24 +230,33 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
             for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16k16(ba[j], tb[i], acc[j][i]);
     }
 
-    // Epilogue: lane holds features nb..nb+3 of token m.
-    T* Y = reinterpret_cast<T*>(a.Y);
+    // Epilogue: bias, round, stage the BM x BN tile in LDS (the K loop's final barrier has retired every tile read), then
+    // row-major 16 B stores.
+    T* Cs = reinterpret_cast<T*>(smem_raw);                       // [BM][CS]
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int nb = n0 + wn * (BN / 2) + j * 16 + lg * 4;
-        if (nb >= N) continue;
+        const int nl = wn * (BN / 2) + j * 16 + lg * 4;
+        const int nb = min(n0 + nl, N - 4);
         float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
         if (a.bias != nullptr) {
             b0 = a.bias[nb]; b1 = a.bias[nb + 1]; b2 = a.bias[nb + 2]; b3 = a.bias[nb + 3];
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + l15;
-            if (m < M) {
-                const f32x4 v = acc[j][i];
-                st8(Y + (int64_t)m * a.ldy + nb, pack4<T>(v[0] + b0, v[1] + b1, v[2] + b2, v[3] + b3));
-            }
+            const int ml = wm * (BM / 2) + i * 16 + l15;
+            const f32x4 v = acc[j][i];
+            st8(Cs + ml * CS + nl, pack4<T>(v[0] + b0, v[1] + b1, v[2] + b2, v[3] + b3));
         }
+    }
+    __syncthreads();
+    T* Y = reinterpret_cast<T*>(a.Y);
+    constexpr int OCH = BM * (BN / 8) / 256;
+#pragma unroll
+    for (int i = 0; i < OCH; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / (BN / 8), col = (c % (BN / 8)) * 8;
+        if (m0 + row < M && n0 + col < N)                         // N % 8 == 0: a chunk is entirely inside or outside
+            st16(Y + (int64_t)(m0 + row) * a.ldy + n0 + col, ld16(Cs + row * CS + col));
     }
 }
 
@@ -388,33 +420,43 @@ __global__ void lora_pack_kernel(mos_lora_sites s, T* __restrict__ A16, T* __res
     }
 }
 
-template <typename T, int BM, int BN, bool FUSED, bool KTAIL>
+template <typename T, int BM, int BN, int BK, bool FUSED, bool KTAIL>
 int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
-    const size_t lds = 2 * (size_t)(BM + BN + (FUSED ? 16 : 0)) * GEMM_LDS_STRIDE * sizeof(T);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lora_kernel<T, BM, BN, FUSED, KTAIL>),
+    size_t lds = 2 * (size_t)(BM + BN + (FUSED ? 16 : 0)) * (BK + 8) * sizeof(T);
+    const size_t stage = (size_t)BM * (BN + 8) * sizeof(T);
+    if (stage > lds) lds = stage;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lora_kernel<T, BM, BN, BK, FUSED, KTAIL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     GemmArgs b = a;
     b.mt = (a.M + BM - 1) / BM;
     b.nt = (a.N + BN - 1) / BN;
     const int mt8 = (b.mt + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_lora_kernel<T, BM, BN, FUSED, KTAIL>), dim3(mt8 * b.nt), dim3(256), lds, st, b);
+    hipLaunchKernelGGL((gemm_lora_kernel<T, BM, BN, BK, FUSED, KTAIL>), dim3(mt8 * b.nt), dim3(256), lds, st, b);
     return mos_check_launch("gemm_lora");
 }
 
 // Tile choice: 128-wide n tiles when N allows (halves the X re-reads and the relative cost of the fused down
 // projection), 128-row m tiles when that still yields >= 384 workgroups, otherwise 64-row / 64-wide tiles so that the
-// small-M levels (M = 1024, 256) spread over the 256 CUs.
+// small-M levels (M = 1024, 256) spread over the 256 CUs. With few workgroups per CU the K loop is latency-bound: those
+// configurations take deep stages (BK 256 / 128), see the kernel comment.
 template <typename T, bool FUSED>
 int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
-    if (a.K % GEMM_BK != 0) return launch_gemm_cfg<T, 64, 64, FUSED, true>(a, st);
+    if (a.K % GEMM_BK != 0) return launch_gemm_cfg<T, 64, 64, 64, FUSED, true>(a, st);
     int bn = (a.N % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
     if (tiles(bm, bn) < 384) bm = 64;
     if (tiles(bm, bn) < 256 && bn == 128) bn = 64;
-    if (bm == 128 && bn == 128) return launch_gemm_cfg<T, 128, 128, FUSED, false>(a, st);
-    if (bm == 128) return launch_gemm_cfg<T, 128, 64, FUSED, false>(a, st);
-    if (bn == 128) return launch_gemm_cfg<T, 64, 128, FUSED, false>(a, st);
-    return launch_gemm_cfg<T, 64, 64, FUSED, false>(a, st);
+    const bool deep = tiles(bm, bn) <= MOS_GEMM_DEEP_MAX_WG;
+    if (bm == 128 && bn == 128) return launch_gemm_cfg<T, 128, 128, 64, FUSED, false>(a, st);
+    if (bm == 128) return launch_gemm_cfg<T, 128, 64, 64, FUSED, false>(a, st);
+    if (bn == 128) {
+        if (deep && a.K % 128 == 0) return launch_gemm_cfg<T, 64, 128, 128, FUSED, false>(a, st);
+        return launch_gemm_cfg<T, 64, 128, 64, FUSED, false>(a, st);
+    }
+    if (deep && a.K % 256 == 0) return launch_gemm_cfg<T, 64, 64, 256, FUSED, false>(a, st);
+    if (deep && a.K % 128 == 0) return launch_gemm_cfg<T, 64, 64, 128, FUSED, false>(a, st);
+    // (32-row tiles for the 160-460 workgroup grids were measured too: 18.9 vs 17.5 us at M1024 N1280 K1280 — no gain)
+    return launch_gemm_cfg<T, 64, 64, 64, FUSED, false>(a, st);
 }
 
 // adown != NULL: fused down projection (t computed in-kernel, stored to tout if given); else t (may be NULL) is read.

@@ -10,6 +10,7 @@ set -u
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 VARIANTS=(
   "occ1|mos_attn|-DMOS_DQ_OCC=1|attn"                        # dQ d=40 at one block per CU
+  "deep768|mos_gemm|-DMOS_GEMM_DEEP_MAX_WG=768|step"         # deep-stage GEMM variants for all grids <= 768 workgroups (measured slower)
   "g512|mos_gemm|-DMOS_GRAD_TARGET_WG=512|step"              # fused LoRA-gradient kernel: fewer, longer token chunks
   "g2048|mos_gemm|-DMOS_GRAD_TARGET_WG=2048|step"            # ... more, shorter chunks
 )
