@@ -271,6 +271,20 @@ int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamm
                                 int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution on channels-last activations as an implicit GEMM (the ResnetBlock2D, Upsample2D
+ * and VAE convolutions that surround the attention layers; frozen weights in ED-LoRA training, so forward and
+ * backward-DATA only — the latter is this same entry point called on dy with the flipped, transposed weight).
+ *   x        (B, H, W, Cin)   in `dtype` (with upsample2x: (B, H/2, W/2, Cin), read through a nearest 2x upsample)
+ *   w        (Cout, 3, 3, Cin) in `dtype`  (= a PyTorch conv weight in channels_last memory format)
+ *   bias     fp32 [Cout] or NULL; tbias (B, Cout) in `dtype` or NULL (per-sample bias: the ResNet time-embedding add);
+ *   residual (B, H, W, Cout) in `dtype` or NULL (added after rounding the convolution, like `x + conv(h)`)
+ *   y        (B, H, W, Cout)
+ * Cin % 64 == 0, Cout % 8 == 0. No workspace.
+ * ------------------------------------------------------------------------------------------ */
+int mos_conv3x3_nhwc(const void* x, const void* w, const float* bias, const void* tbias, const void* residual,
+                     void* y, int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Row-wise operators of the transformer blocks around the attention layers:
  *   LayerNorm: y = (x - mean) * rstd * gamma + beta over the last dim; x, y (rows, C) contiguous in `dtype`, gamma/beta
  *     fp32 (frozen: no affine gradients), stats (rows, 2) fp32 = mean, rstd (may be NULL forward-only). C % 8 == 0, C <= 2048.

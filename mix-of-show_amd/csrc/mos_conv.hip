@@ -1,0 +1,235 @@
+// mos_conv.hip — 3x3 stride-1 pad-1 convolution on channels-last half activations as an implicit GEMM (gfx950).
+//
+// A CALLER of the attention path: the ResnetBlock2D / Upsample2D / VAE convolutions around every
+// transformer block. In ED-LoRA training their weights are frozen, so only forward and backward-DATA are needed, and the
+// latter is the same operator with flipped, transposed taps:
+//     y[b,y,x,co]  = sum_{ky,kx,ci} x[b, y+ky-1, x+kx-1, ci] * W[co][ky][kx][ci]   (+ bias[co] + tbias[b][co] + res[b,y,x,co])
+//     dx[b,y,x,ci] = sum_{ky,kx,co} dy[b, y+ky-1, x+kx-1, co] * Wb[ci][ky][kx][co],  Wb[ci][ky][kx][co] = W[co][2-ky][2-kx][ci]
+// GEMM view: M = B*H*W pixels, N = Cout, K = 9*Cin with k = (tap, ci). In NHWC a pixel's channels are one contiguous run and
+// pixel (b,y,x) has linear index m, so the "im2col row" of tap (dy,dx) is just the run of pixel m + dy*W + dx — or zeros
+// outside the image, which the buffer-load bounds check delivers for free when the offset is pushed past the descriptor's
+// range. No im2col buffer, no layout transposes, no zero-fill of split-K outputs; the per-sample time-embedding bias and
+// the ResNet residual add ride in the epilogue (MIOpen: separate transpose / SubTensorOp / add kernels around each call).
+// Tiling, LDS layout, MFMA feeding and the XCD-aware block map are those of gemm_lora_kernel (mos_gemm.hip).
+#include <cstdio>
+#include <type_traits>
+#include "mos_common.h"
+
+namespace {
+
+constexpr int CBK = 64;
+constexpr int CLS = CBK + 8;
+
+struct ConvArgs {
+    const void* X; const void* W; const float* bias; const void* tbias; const void* R; void* Y;
+    int B, H, Wd, Cin, Cout;      // Wd = image width
+    int M, mt, nt, cpt;           // M = B*H*W ; cpt = Cin / 64 channel chunks per tap
+    int up;                       // 1: the input is read through a nearest 2x upsample (x is (B, H/2, W/2, Cin))
+};
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
+    typedef typename MT<T>::v8 v8;
+    constexpr int MI = BM / 32, NJ = BN / 32;
+    constexpr int XCH = BM * 8 / 256, WCH = BN * 8 / 256;
+    constexpr int CS = BN + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Xs = reinterpret_cast<T*>(smem_raw);        // [2][BM][72]
+    T* Ws = Xs + 2 * BM * CLS;                     // [2][BN][72]
+
+    const int w = blockIdx.x;
+    const int slot = w >> 3;
+    const int n_tile = slot % a.nt;
+    const int m_tile = (slot / a.nt) * 8 + (w & 7);
+    if (m_tile >= a.mt) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lg = lane >> 4;
+    const int n0 = n_tile * BN, m0 = m_tile * BM;
+    const int M = a.M, N = a.Cout, C = a.Cin, H = a.H, Wd = a.Wd;
+    const int K = 9 * C;
+    const int Hs = a.up ? H / 2 : H, Ws_ = a.up ? Wd / 2 : Wd;     // source image size
+
+    const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((int64_t)a.B * Hs * Ws_ * C * (int64_t)sizeof(T)));
+    const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * K + K) * (int64_t)sizeof(T)));
+    constexpr int OOB = 0x7FFFFF00;
+
+    int py[XCH], px[XCH], pb[XCH], woff[WCH];
+#pragma unroll
+    for (int i = 0; i < XCH; ++i) {
+        const int c = tid + 256 * i;
+        const int m = m0 + (c >> 3);
+        if (m < M) {
+            const int b = m / (H * Wd), p = m - b * (H * Wd);
+            py[i] = p / Wd; px[i] = p - py[i] * Wd; pb[i] = b;
+        } else {
+            py[i] = -100000; px[i] = 0; pb[i] = 0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) {
+        const int c = tid + 256 * i;
+        woff[i] = (int)((((int64_t)(n0 + (c >> 3))) * K + (c & 7) * 8) * (int64_t)sizeof(T));
+    }
+    const int cc8 = (tid & 7) * 8;
+
+    f32x4 acc[NJ][MI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 xr[XCH], wr[WCH];
+    const int nk = 9 * a.cpt;
+    int tap = 0, cch = 0;                      // tap / channel chunk of the NEXT tile to load
+
+    auto load_tile = [&](int kt) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int yy = py[i] + dy, xx = px[i] + dx;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+            const int ys = a.up ? (yy >> 1) : yy, xs = a.up ? (xx >> 1) : xx;
+            const int off = ((pb[i] * Hs + ys) * Ws_ + xs) * C + cch * CBK + cc8;
+            xr[i] = ldbuf16(xsrc, ok ? off * (int)sizeof(T) : OOB);
+        }
+        const int kb = kt * CBK * (int)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) wr[i] = ldbuf16(wsrc, woff[i] + kb);
+        if (++cch == a.cpt) { cch = 0; ++tap; }
+    };
+    auto store_tile = [&](int buf) {
+        T* xs = Xs + buf * BM * CLS;
+        T* ws = Ws + buf * BN * CLS;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int c = tid + 256 * i;
+            st16(xs + (c >> 3) * CLS + (c & 7) * 8, xr[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int c = tid + 256 * i;
+            st16(ws + (c >> 3) * CLS + (c & 7) * 8, wr[i]);
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const T* xs = Xs + cur * BM * CLS + (wm * (BM / 2) + l15) * CLS + lg * 8;
+        const T* ws = Ws + cur * BN * CLS + (wn * (BN / 2) + l15) * CLS + lg * 8;
+#pragma unroll
+        for (int kk = 0; kk < CBK / 32; ++kk) {
+            v8 bfrag[MI], afrag[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) bfrag[i] = as_v8<T>(ld16(xs + i * 16 * CLS + kk * 32));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) afrag[j] = as_v8<T>(ld16(ws + j * 16 * CLS + kk * 32));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16(afrag[j], bfrag[i], acc[j][i]);
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: + bias[n] + tbias[b(m)][n], round, stage in LDS, then coalesced rows (+ residual)
+    T* Cs = reinterpret_cast<T*>(smem_raw);
+    const T* tb = reinterpret_cast<const T*>(a.tbias);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nl = wn * (BN / 2) + j * 16 + lg * 4;
+        const int nb = min(n0 + nl, N - 4);
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        if (a.bias != nullptr) { b0 = a.bias[nb]; b1 = a.bias[nb + 1]; b2 = a.bias[nb + 2]; b3 = a.bias[nb + 3]; }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wm * (BM / 2) + i * 16 + l15;
+            f32x4 v = acc[j][i];
+            if (tb != nullptr) {
+                const int bimg = min(m0 + ml, M - 1) / (H * Wd);
+                const typename MT<T>::v4 t4 = __builtin_bit_cast(typename MT<T>::v4, ld8(tb + (int64_t)bimg * N + nb));
+                v[0] += (float)t4[0]; v[1] += (float)t4[1]; v[2] += (float)t4[2]; v[3] += (float)t4[3];
+            }
+            st8(Cs + ml * CS + nl, pack4<T>(v[0] + b0, v[1] + b1, v[2] + b2, v[3] + b3));
+        }
+    }
+    __syncthreads();
+    T* Y = reinterpret_cast<T*>(a.Y);
+    const T* R = reinterpret_cast<const T*>(a.R);
+    constexpr int OCH = BM * (BN / 8) / 256;
+#pragma unroll
+    for (int i = 0; i < OCH; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / (BN / 8), col = (c % (BN / 8)) * 8;
+        if (m0 + row < M && n0 + col < N) {
+            const int64_t o = (int64_t)(m0 + row) * N + n0 + col;
+            u32x4 val = ld16(Cs + row * CS + col);
+            if (R != nullptr) {
+                const v8 r = as_v8<T>(ld16(R + o)), s = as_v8<T>(val);
+                v8 q;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) q[e] = (T)((float)s[e] + (float)r[e]);
+                val = from_v8<T>(q);
+            }
+            st16(Y + o, val);
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+int launch_conv_cfg(ConvArgs a, hipStream_t st) {
+    size_t lds = 2 * (size_t)(BM + BN) * CLS * sizeof(T);
+    const size_t stage = (size_t)BM * (BN + 8) * sizeof(T);
+    if (stage > lds) lds = stage;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    a.mt = (a.M + BM - 1) / BM;
+    a.nt = (a.Cout + BN - 1) / BN;
+    const int mt8 = (a.mt + 7) / 8 * 8;
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, BM, BN>), dim3(mt8 * a.nt), dim3(256), lds, st, a);
+    return mos_check_launch("conv3x3_nhwc");
+}
+
+template <typename T>
+int launch_conv(ConvArgs a, hipStream_t st) {
+    char key[96];
+    snprintf(key, sizeof(key), "%s B%d %dx%d Cin%d Cout%d%s%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", a.B, a.H, a.Wd,
+             a.Cin, a.Cout, a.up ? " up2x" : "", a.tbias ? " +tbias" : "", a.R ? " +res" : "");
+    MosProfScope prof(st, "conv3x3", key, 2.0 * a.M * (double)a.Cout * 9.0 * a.Cin,
+                      2.0 * ((double)a.M * a.Cin / (a.up ? 4 : 1) + 9.0 * a.Cin * a.Cout + (double)a.M * a.Cout * (a.R ? 2 : 1)));
+    int bn = (a.Cout % 128 == 0) ? 128 : 64, bm = 128;
+    auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
+    if (tiles(bm, bn) < 384) bm = 64;
+    if (tiles(bm, bn) < 256 && bn == 128) bn = 64;
+    if (bm == 128 && bn == 128) return launch_conv_cfg<T, 128, 128>(a, st);
+    if (bm == 128) return launch_conv_cfg<T, 128, 64>(a, st);
+    if (bn == 128) return launch_conv_cfg<T, 64, 128>(a, st);
+    return launch_conv_cfg<T, 64, 64>(a, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mos_conv3x3_nhwc(const void* x, const void* w, const float* bias, const void* tbias, const void* residual, void* y,
+                     int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* stream) {
+    MOS_REQUIRE(x && w && y, "mos_conv3x3_nhwc: NULL argument");
+    MOS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 8 == 0,
+                "mos_conv3x3_nhwc: B=%d H=%d W=%d Cin=%d Cout=%d (need Cin %% 64 == 0, Cout %% 8 == 0)", B, H, W, Cin, Cout);
+    MOS_REQUIRE(!upsample2x || (H % 2 == 0 && W % 2 == 0), "mos_conv3x3_nhwc: upsample2x needs even output H, W");
+    MOS_REQUIRE((int64_t)B * H * W * (int64_t)(Cin > Cout ? Cin : Cout) * 2 < (1ll << 31) && (int64_t)Cout * 9 * Cin * 2 < (1ll << 31),
+                "mos_conv3x3_nhwc: tensor exceeds the 2 GiB range of one buffer descriptor");
+    ConvArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.tbias = tbias; a.R = residual; a.Y = y;
+    a.B = B; a.H = H; a.Wd = W; a.Cin = Cin; a.Cout = Cout; a.M = B * H * W; a.cpt = Cin / 64; a.up = upsample2x ? 1 : 0;
+    a.mt = a.nt = 0;
+    if (dtype == MOS_F16) return launch_conv<f16_t>(a, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_conv3x3_nhwc: dtype %d", dtype);
+}
+
+}  // extern "C"

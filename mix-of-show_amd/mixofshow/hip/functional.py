@@ -449,3 +449,101 @@ def geglu(h):
         return _GEGLU.apply(h)
     a, g = h.chunk(2, dim=-1)
     return a * torch.nn.functional.gelu(g)
+
+
+# ---- 3x3 convolution (frozen weights) on the implicit-GEMM kernel ---------------------------------------------------
+class _ConvWeights:
+    """(Cout,3,3,Cin) forward operand and (Cin,3,3,Cout) flipped/transposed backward-data operand of one frozen conv."""
+
+    def __init__(self):
+        self.key, self.fwd, self.bwd, self.bias = None, None, None, None
+
+    def get(self, conv, dtype, need_bwd):
+        w, b = conv.weight, conv.bias
+        key = (w.data_ptr(), w._version, w.dtype, dtype, None if b is None else (b.data_ptr(), b._version))
+        if key != self.key:
+            self.key, self.bwd = key, None
+            self.fwd = w.detach().permute(0, 2, 3, 1).to(dtype).contiguous()
+            self.bias = None if b is None else b.detach().float().contiguous()
+        if need_bwd and self.bwd is None:
+            self.bwd = w.detach().flip(2, 3).permute(1, 2, 3, 0).to(dtype).contiguous()
+        return self.fwd, self.bwd, self.bias
+
+
+def _as_nhwc(t, dtype):
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t if ops._is_nhwc(t) else t.contiguous(memory_format=torch.channels_last)
+
+
+class _Conv3x3(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, w_fwd, w_bwd, bias32, tbias, residual, upsample):
+        dt = w_fwd.dtype
+        xc = _as_nhwc(x, dt)
+        tb = None if tbias is None else tbias.to(dt).contiguous()
+        rs = None if residual is None else _as_nhwc(residual, dt)
+        y = ops.conv3x3_nhwc(xc, w_fwd, bias32, tb, rs, upsample)
+        ctx.save_for_backward(w_bwd)
+        ctx.upsample, ctx.t_dtype, ctx.r_dtype, ctx.x_dtype = upsample, (None if tbias is None else tbias.dtype), (
+            None if residual is None else residual.dtype), x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w_bwd, ) = ctx.saved_tensors
+        dyc = _as_nhwc(dy, w_bwd.dtype if w_bwd is not None else dy.dtype)
+        dx = dt = dr = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv3x3_nhwc(dyc, w_bwd)
+            if ctx.upsample:                   # adjoint of the nearest 2x upsample: sum of each 2x2 block
+                dx = torch.nn.functional.avg_pool2d(dx, 2) * 4
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        if ctx.t_dtype is not None and ctx.needs_input_grad[4]:
+            dt = dyc.float().sum((2, 3)).to(ctx.t_dtype)
+        if ctx.r_dtype is not None and ctx.needs_input_grad[5]:
+            dr = dyc if dyc.dtype == ctx.r_dtype else dyc.to(ctx.r_dtype)
+        return dx, None, None, None, dt, dr, None
+
+
+def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
+    """`conv(x)` (+ tbias[:, :, None, None]) (+ residual) for an nn.Conv2d with a 3x3 / stride 1 / pad 1 kernel, optionally
+    reading x through a nearest 2x upsample. HIP path (implicit-GEMM kernel, channels_last, epilogue-fused adds): device
+    tensors, half activations (or half autocast), FROZEN weights, Cin % 64 == 0, Cout % 8 == 0. Anything else runs the
+    plain torch ops (CPU oracle runs, fp32 inference, trainable convolutions, conv_in / conv_out): plumbing."""
+    half = x.dtype in (torch.float16, torch.bfloat16)
+    ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
+    ok = (x.is_cuda and (half or ac) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+          and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 8 == 0
+          and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad) and _conv_enabled)
+    if not ok:
+        if upsample:
+            x = torch.nn.functional.interpolate(x, scale_factor=2.0, mode='nearest')
+        y = conv(x)
+        if tbias is not None:
+            y = y + tbias[:, :, None, None]
+        if residual is not None:
+            y = residual + y
+        return y
+    dt = x.dtype if half else torch.get_autocast_dtype('cuda')
+    cache = conv.__dict__.get('_mos_conv_cache')
+    if cache is None:
+        cache = _ConvWeights()
+        object.__setattr__(conv, '_mos_conv_cache', cache)
+    need_bwd = torch.is_grad_enabled() and (x.requires_grad or (tbias is not None and tbias.requires_grad)
+                                            or (residual is not None and residual.requires_grad))
+    w_fwd, w_bwd, bias32 = cache.get(conv, dt, need_bwd and x.requires_grad)
+    return _Conv3x3.apply(x, w_fwd, w_bwd, bias32, tbias, residual, bool(upsample))
+
+
+import os as _os
+
+_conv_enabled = _os.environ.get('MOS_CONV3X3', '1') != '0'
+
+
+def set_conv3x3_enabled(flag):
+    """A/B switch (bench / tests): False routes every 3x3 convolution through torch (MIOpen)."""
+    global _conv_enabled
+    _conv_enabled = bool(flag)

@@ -461,3 +461,29 @@ def single_head_attention_nograd(q, k, v, scale):
         softmax_rows(S, scale, out=S)
         linear_fwd(S, v[i].t().contiguous(), out=o[i])
     return o
+
+
+# ------------------------------------------------------------------------------------------------
+# 3x3 convolution on channels-last activations (implicit GEMM) — caller-side operator
+# ------------------------------------------------------------------------------------------------
+def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False):
+    """x: (B, Cin, H, W) half tensor in channels_last memory format; w_ohwi: (Cout, 3, 3, Cin) contiguous half;
+    bias fp32 (Cout,); tbias (B, Cout) half; residual like the output. Returns (B, Cout, H', W') channels_last
+    (H' = 2H with upsample2x)."""
+    _dev(x, w_ohwi, bias, tbias, residual)
+    B, Cin, Hs, Ws = x.shape
+    assert _is_nhwc(x) or (Hs == 1 and Ws == 1) or x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_nhwc needs channels_last'
+    Cout = w_ohwi.shape[0]
+    assert w_ohwi.shape == (Cout, 3, 3, Cin) and w_ohwi.is_contiguous() and w_ohwi.dtype == x.dtype
+    H, W = (2 * Hs, 2 * Ws) if upsample2x else (Hs, Ws)
+    y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+    if tbias is not None:
+        assert tbias.shape == (B, Cout) and tbias.dtype == x.dtype and tbias.is_contiguous()
+    if residual is not None:
+        assert residual.shape == y.shape and residual.dtype == x.dtype and residual.stride() == y.stride()
+    L = _lib.load()
+    _lib.check(L.mos_conv3x3_nhwc(_p(x), _p(w_ohwi), _p(bias), _p(tbias), _p(residual), _p(y), B, H, W, Cin, Cout,
+                                  int(bool(upsample2x)), _dt(x), _stream()), 'mos_conv3x3_nhwc')
+    return y

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mixofshow.hip.functional import geglu, group_norm_act, layer_norm
+from mixofshow.hip.functional import conv3x3, geglu, group_norm_act, layer_norm
 from mixofshow.models.attention import Attention
 
 
@@ -60,13 +60,15 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(group_norm_act(self.norm1, x, True))          # fused GroupNorm+SiLU on the HIP device
+        # on the HIP device: fused GroupNorm+SiLU kernels, implicit-GEMM 3x3 convolutions with the time-embedding add and
+        # the residual add in their epilogues (diffusers: conv, + temb[:, :, None, None], ..., x + h as separate kernels)
+        tb = None
         if self.time_emb_proj is not None and temb is not None:
-            h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
-        h = self.conv2(self.dropout(group_norm_act(self.norm2, h, True)))
+            tb = self.time_emb_proj(self.nonlinearity(temb))
+        h = conv3x3(self.conv1, group_norm_act(self.norm1, x, True), tbias=tb)
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
-        return x + h
+        return conv3x3(self.conv2, self.dropout(group_norm_act(self.norm2, h, True)), residual=x)
 
 
 class Downsample2D(nn.Module):
@@ -89,7 +91,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode='nearest'))
+        return conv3x3(self.conv, x, upsample=True)      # the nearest 2x upsample is folded into the conv's input addressing
 
 
 class GEGLU(nn.Module):

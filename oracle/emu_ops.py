@@ -9,7 +9,7 @@ import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
             'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd',
-            'geglu_fwd', 'geglu_bwd', 'softmax_rows', 'single_head_attention_nograd')
+            'geglu_fwd', 'geglu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
 PAD = 16
 
 
@@ -252,3 +252,18 @@ def single_head_attention_nograd(q, k, v, scale):
     s = (q.float() @ k.float().transpose(-1, -2)).to(q.dtype)
     p = torch.softmax(s.float() * scale, -1).to(q.dtype)
     return (p.float() @ v.float()).to(q.dtype)
+
+
+def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False):
+    """fp32 convolution of the half inputs, + bias + per-sample bias, rounded ONCE, then + residual rounded again."""
+    import torch.nn.functional as F
+    xf = x.float()
+    if upsample2x:
+        xf = F.interpolate(xf, scale_factor=2.0, mode='nearest')
+    y = F.conv2d(xf, w_ohwi.float().permute(0, 3, 1, 2), bias, padding=1)
+    if tbias is not None:
+        y = y + tbias.float()[:, :, None, None]
+    y = y.to(x.dtype)
+    if residual is not None:
+        y = (y.float() + residual.float()).to(x.dtype)
+    return y.contiguous(memory_format=torch.channels_last)

@@ -473,3 +473,42 @@ def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
     _check('vae attention vs emulation', o, emu.single_head_attention_nograd(q, k, v, d**-0.5), dtype)
     exact = torch.softmax(q.float() @ k.float().transpose(-1, -2) * d**-0.5, -1) @ v.float()
     _check('vae attention vs exact fp32', o, exact, dtype, ulps=6.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,Cin,Cout,H,W,extras', [
+    (4, 320, 320, 64, 64, 'tr'),      # level-0 ResNet conv1 (+temb) / conv2 (+residual)     128 x 64 tiles
+    (4, 640, 640, 32, 32, 't'),       # level 1                                              64 x 128
+    (4, 1280, 1280, 16, 16, 'r'),     # level 2                                              64 x 64
+    (4, 1280, 1280, 8, 8, 'tr'),      # level 3: 128-row tiles span two images
+    (2, 2560, 1280, 8, 8, ''),        # up-block concat input
+    (2, 960, 320, 64, 64, 't'),       # last up block
+    (1, 1920, 640, 32, 48, 'r'),      # 512x768 regional sample (non-square map)
+    (2, 1280, 1280, 16, 16, 'u'),     # Upsample2D: nearest 2x folded into the gather, output 32x32
+    (2, 128, 128, 96, 80, 't'),       # VAE-like stage, ragged tile count
+    (1, 64, 8, 5, 7, 'tr'),           # tiny / odd sizes
+])
+def test_conv3x3_nhwc(ops, emu, dtype, B, Cin, Cout, H, W, extras):
+    """Implicit-GEMM 3x3 convolution (channels_last) vs fp32 torch conv2d on the same half operands: forward with the
+    fused per-sample bias / residual / upsample, and the backward-data form (flipped, transposed weight)."""
+    g = torch.Generator(device='cpu').manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=g).to('cuda', dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to('cuda', dtype)
+    bias = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    up = 'u' in extras
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    tb = torch.randn(B, Cout, generator=g).to('cuda', dtype) if 't' in extras else None
+    res = torch.randn(B, Cout, Ho, Wo, generator=g).to('cuda', dtype).contiguous(memory_format=torch.channels_last) \
+        if 'r' in extras else None
+    w_fwd = w.permute(0, 2, 3, 1).contiguous()
+    y = ops.conv3x3_nhwc(x, w_fwd, bias, tb, res, up)
+    assert y.shape == (B, Cout, Ho, Wo) and y.is_contiguous(memory_format=torch.channels_last)
+    y_ref = emu.conv3x3_nhwc(x, w_fwd, bias, tb, res, up)
+    _check(f'conv3x3[{B}x{Cin}->{Cout}x{H}x{W} {extras}]', y, y_ref, dtype)
+    # backward-data: dx = conv(dy, flip(W)^T) == autograd of the fp32 convolution
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g).to('cuda', dtype).contiguous(memory_format=torch.channels_last)
+    w_bwd = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()
+    dx = ops.conv3x3_nhwc(dy, w_bwd)
+    xf = torch.zeros(B, Cin, Ho, Wo, device='cuda', requires_grad=True)
+    (dx_ref, ) = torch.autograd.grad(torch.nn.functional.conv2d(xf, w.float(), None, padding=1), xf, dy.float())
+    _check('conv3x3 backward-data', dx, dx_ref, dtype)

@@ -650,3 +650,38 @@ def test_upcast_flags_raise_on_the_fused_path(emulated_hip):
     a = Attention(64, heads=8, dim_head=8, upcast_softmax=True)
     with pytest.raises(NotImplementedError, match='upcast'):
         a(torch.randn(1, 16, 64).half())
+
+
+@pytest.mark.parametrize('upsample', [False, True])
+def test_conv3x3_autograd_function_vs_torch(emulated_hip, upsample):
+    """_Conv3x3 (implicit-GEMM kernel emulated): forward with the time-embedding bias and the residual in the epilogue, and
+    backward-data through the flipped / transposed weight, the per-sample bias gradient and the residual gradient, against
+    torch's conv2d autograd (the diffusers ResnetBlock2D / Upsample2D arithmetic)."""
+    from mixofshow.hip import functional as F_hip
+    torch.manual_seed(0)
+    B, Cin, Cout, H, W = 2, 64, 16, 6, 5
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1)
+    for p in conv.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(B, Cin, H, W, requires_grad=True)
+    Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
+    tb = torch.randn(B, Cout, requires_grad=True)
+    res = torch.randn(B, Cout, Ho, Wo, requires_grad=True)
+    cache = F_hip._ConvWeights()
+    w_fwd, w_bwd, bias32 = cache.get(conv, torch.float32, True)
+    y = F_hip._Conv3x3.apply(x.contiguous(memory_format=torch.channels_last), w_fwd, w_bwd, bias32, tb, res, upsample)
+    xr, tr, rr = (t.detach().clone().requires_grad_(True) for t in (x, tb, res))
+    xin = torch.nn.functional.interpolate(xr, scale_factor=2.0, mode='nearest') if upsample else xr
+    y_ref = rr + (conv(xin) + tr[:, :, None, None])
+    torch.testing.assert_close(y, y_ref, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(y_ref)
+    y.backward(g)
+    y_ref.backward(g)
+    torch.testing.assert_close(x.grad, xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(tb.grad, tr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(res.grad, rr.grad, rtol=0, atol=0)
+    # the weight cache follows in-place weight updates
+    with torch.no_grad():
+        conv.weight.mul_(2.0)
+    w2, _, _ = cache.get(conv, torch.float32, False)
+    torch.testing.assert_close(w2, conv.weight.permute(0, 2, 3, 1))

@@ -85,6 +85,40 @@ def blas_reference(shapes, dtype, iters):
         print(f"{f'M{M} N{N} K{K}':30s} {us:14.1f} {fl / us / 1e6:9.1f} {us2:12.1f} {fl / us2 / 1e6:9.1f}")
 
 
+def conv_reference(shapes, dtype, iters):
+    """3x3 convolutions of the SD-1.5 UNet / VAE: the implicit-GEMM kernel vs MIOpen (torch conv2d, channels_last), forward
+    and backward-data, one event pair around `iters` back-to-back launches."""
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / iters
+
+    print(f"{'conv3x3 B Cin Cout HxW':34s} {'mos fwd':>9s} {'MIOpen fwd':>11s} {'mos bwd':>9s} {'MIOpen bwd':>11s} {'mos TF/s':>9s}")
+    for B, Cin, Cout, H, W in shapes:
+        x = torch.randn(B, Cin, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
+        conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).to('cuda', dtype).to(memory_format=torch.channels_last)
+        w_fwd = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+        w_bwd = conv.weight.detach().flip(2, 3).permute(1, 2, 3, 0).contiguous()
+        b32 = conv.bias.detach().float()
+        dy = torch.randn(B, Cout, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            t_mf = timed(lambda: ops.conv3x3_nhwc(x, w_fwd, b32))
+            t_rf = timed(lambda: conv(x))
+            t_mb = timed(lambda: ops.conv3x3_nhwc(dy, w_bwd))
+        xg = x.clone().requires_grad_(True)
+        yg = conv(xg)
+        t_rb = timed(lambda: torch.autograd.grad(yg, xg, dy, retain_graph=True))
+        fl = 2.0 * B * H * W * Cout * 9 * Cin
+        print(f"{f'B{B} {Cin}->{Cout} {H}x{W}':34s} {t_mf:9.1f} {t_rf:11.1f} {t_mb:9.1f} {t_rb:11.1f} {fl / t_mf / 1e6:9.1f}")
+
+
 def region_case(fh, fw, d, dtype, iters):
     B, H = 2, 8
     C = H * d
@@ -136,6 +170,12 @@ def main():
                   lambda: region_case(16, 24, 160, dt, args.iters)]
     if args.only in ('', 'gram'):
         cases += [lambda: gram_case(81920, 320, 320, dt, 5), lambda: gram_case(20480, 1280, 1280, dt, 5)]
+    if args.only in ('', 'conv'):
+        conv_reference([(4, 320, 320, 64, 64), (4, 640, 320, 64, 64), (4, 960, 320, 64, 64), (4, 640, 640, 32, 32),
+                        (4, 1280, 640, 32, 32), (4, 1920, 640, 32, 32), (4, 1280, 1280, 16, 16), (4, 2560, 1280, 16, 16),
+                        (4, 1280, 1280, 8, 8), (4, 2560, 1280, 8, 8), (4, 128, 128, 512, 512), (4, 256, 256, 256, 256),
+                        (4, 512, 512, 128, 128), (4, 512, 512, 64, 64), (2, 320, 320, 64, 96), (2, 1280, 1280, 16, 24)],
+                       dt, args.iters)
     if args.only in ('', 'gemm', 'blas'):
         blas_reference([(16384, 320, 320), (16384, 960, 320), (4096, 640, 640), (4096, 1920, 640), (1024, 1280, 1280),
                         (1024, 3840, 1280), (256, 1280, 1280), (4928, 768, 768), (4928, 2304, 768), (12288, 320, 320),

@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -ffp-cont
 SRC="${VARIANT_SRC:-mos_attn}"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c "$C/${SRC}.hip" -o "$V/${NAME}_${SRC}.o"
 OBJS=""
-for f in mos_api mos_gemm mos_attn mos_gram mos_norm mos_elem; do
+for f in mos_api mos_gemm mos_attn mos_gram mos_norm mos_elem mos_conv; do
   if [ "$f" = "$SRC" ]; then OBJS="$OBJS $V/${NAME}_${SRC}.o"; else OBJS="$OBJS $C/_build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$V/${NAME}.so" $OBJS
