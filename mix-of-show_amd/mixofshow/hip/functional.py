@@ -517,7 +517,8 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
     ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
     ok = (x.is_cuda and (half or ac) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
           and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 8 == 0
-          and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad) and _conv_enabled)
+          and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad) and _conv_enabled
+          and not conv._forward_hooks and not conv._forward_pre_hooks)
     need_bwd = torch.is_grad_enabled() and (x.requires_grad or (tbias is not None and tbias.requires_grad)
                                             or (residual is not None and residual.requires_grad))
     if ok:
@@ -554,3 +555,30 @@ def set_conv3x3_enabled(flag):
     """A/B switch (bench / tests): False routes every 3x3 convolution through torch (MIOpen)."""
     global _conv_enabled
     _conv_enabled = bool(flag)
+
+
+def conv1x1(conv, x):
+    """`conv(x)` for a frozen 1x1 nn.Conv2d (Transformer2DModel.proj_in / proj_out, ResnetBlock2D.conv_shortcut) as a plain
+    GEMM of the library on the token-major view of a channels_last tensor (free view in, free view out). A LoRA-wrapped
+    conv never gets here (its forward is LoRALinearLayer.forward); CPU / fp32 / trainable / NCHW inputs take torch."""
+    half = x.dtype in (torch.float16, torch.bfloat16)
+    ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
+    ok = (x.is_cuda and (half or ac) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+          and conv.groups == 1 and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
+          and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
+          and getattr(conv, '_mos_lora', None) is None and conv.forward.__func__ is torch.nn.Conv2d.forward
+          and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and _conv_enabled
+          and not conv._forward_hooks and not conv._forward_pre_hooks)      # hooks (gradient fusion) need conv.__call__
+    if not ok:
+        return conv(x)
+    dt = x.dtype if half else torch.get_autocast_dtype('cuda')
+    cache = conv.__dict__.get('_mos_cache')
+    if cache is None:
+        cache = WeightCache()
+        object.__setattr__(conv, '_mos_cache', cache)
+    b, c, h, w = x.shape
+    W16, Wt16 = cache.weight('w', [conv.weight], dt, transposed=torch.is_grad_enabled() and x.requires_grad)
+    b32 = cache.bias('w', [conv.bias])
+    tokens = x.permute(0, 2, 3, 1).reshape(b * h * w, c)
+    y = lora_linear(tokens if tokens.dtype == dt else tokens.to(dt), W16, Wt16, b32, [])
+    return y.view(b, h, w, -1).permute(0, 3, 1, 2)

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mixofshow.hip.functional import conv3x3, geglu, group_norm_act, layer_norm
+from mixofshow.hip.functional import conv1x1, conv3x3, geglu, group_norm_act, layer_norm
 from mixofshow.models.attention import Attention
 
 
@@ -67,7 +67,7 @@ class ResnetBlock2D(nn.Module):
             tb = self.time_emb_proj(self.nonlinearity(temb))
         h = conv3x3(self.conv1, group_norm_act(self.norm1, x, True), tbias=tb)
         if self.conv_shortcut is not None:
-            x = self.conv_shortcut(x)
+            x = conv1x1(self.conv_shortcut, x)
         return conv3x3(self.conv2, self.dropout(group_norm_act(self.norm2, h, True)), residual=x)
 
 
@@ -147,14 +147,14 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, encoder_hidden_states=None, cross_attention_kwargs=None):
         b, c, h, w = x.shape
         residual = x
-        x = self.proj_in(group_norm_act(self.norm, x, False))
+        x = conv1x1(self.proj_in, group_norm_act(self.norm, x, False))
         x = x.permute(0, 2, 3, 1).reshape(b, h * w, -1)
         for blk in self.transformer_blocks:
             x = blk(x, encoder_hidden_states=encoder_hidden_states, cross_attention_kwargs=cross_attention_kwargs)
         # (b, hw, c) -> NCHW view with channels-last strides: free when the UNet runs in channels_last memory format
         # (the token-major layout of the attention path IS NHWC); the 1x1 conv accepts either layout
         x = x.reshape(b, h, w, -1).permute(0, 3, 1, 2)
-        return self.proj_out(x) + residual
+        return conv1x1(self.proj_out, x) + residual
 
 
 class CrossAttnDownBlock2D(nn.Module):
