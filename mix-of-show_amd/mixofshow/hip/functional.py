@@ -366,6 +366,25 @@ class _GroupNormSiLU(torch.autograd.Function):
         return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
 
 
+def _frozen(*params):
+    """True when no gradient will be asked for these parameters: they are frozen, or autograd is off (sampling pipelines run
+    under no_grad with ordinary requires_grad=True modules)."""
+    return not (torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params))
+
+
+def _affine32(norm):
+    """fp32 copies of a norm's affine parameters (the kernels take fp32 gamma / beta; fp16 pipelines store them in half)."""
+    w, b = norm.weight, norm.bias
+    if w.dtype == torch.float32 and b.dtype == torch.float32:
+        return w, b
+    key = (w.data_ptr(), w._version, b.data_ptr(), b._version, w.dtype)
+    ent = norm.__dict__.get('_mos_affine32')
+    if ent is None or ent[0] != key:
+        ent = (key, w.detach().float().contiguous(), b.detach().float().contiguous())
+        object.__setattr__(norm, '_mos_affine32', ent)
+    return ent[1], ent[2]
+
+
 def group_norm_act(norm, x, silu):
     """`silu(norm(x))` (or `norm(x)`) for an nn.GroupNorm `norm`.
 
@@ -375,9 +394,10 @@ def group_norm_act(norm, x, silu):
     hw = x.numel() // max(1, x.shape[0] * x.shape[1])
     nhwc = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
     use_hip = (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and (hw % 8 == 0 or (nhwc and x.shape[1] % 8 == 0))
-               and not norm.weight.requires_grad and not norm.bias.requires_grad and norm.weight.dtype == torch.float32)
+               and norm.weight is not None and norm.bias is not None and _frozen(norm.weight, norm.bias))
     if use_hip:
-        return _GroupNormSiLU.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, bool(silu))
+        gamma, beta = _affine32(norm)
+        return _GroupNormSiLU.apply(x, gamma, beta, norm.num_groups, norm.eps, bool(silu))
     y = norm(x)
     return torch.nn.functional.silu(y) if silu else y
 
@@ -414,13 +434,13 @@ def layer_norm(norm, x):
     half = x.dtype in (torch.float16, torch.bfloat16)
     ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
     use_hip = (x.is_cuda and (half or ac) and len(norm.normalized_shape) == 1 and norm.weight is not None
-               and norm.bias is not None and not norm.weight.requires_grad and not norm.bias.requires_grad
-               and norm.weight.dtype == torch.float32 and C % 8 == 0 and C <= 2048)
+               and norm.bias is not None and _frozen(norm.weight, norm.bias) and C % 8 == 0 and C <= 2048)
     if not use_hip:
         return norm(x)
     if not half:
         x = x.to(torch.get_autocast_dtype('cuda'))
-    return _LayerNorm.apply(x, norm.weight, norm.bias, norm.eps)
+    gamma, beta = _affine32(norm)
+    return _LayerNorm.apply(x, gamma, beta, norm.eps)
 
 
 class _GEGLU(torch.autograd.Function):
@@ -517,7 +537,7 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
     ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
     ok = (x.is_cuda and (half or ac) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
           and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 8 == 0
-          and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad) and _conv_enabled
+          and _frozen(conv.weight, conv.bias) and _conv_enabled
           and not conv._forward_hooks and not conv._forward_pre_hooks)
     need_bwd = torch.is_grad_enabled() and (x.requires_grad or (tbias is not None and tbias.requires_grad)
                                             or (residual is not None and residual.requires_grad))
@@ -548,6 +568,7 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
 import os as _os
 
 _conv_enabled = _os.environ.get('MOS_CONV3X3', '1') != '0'
+_conv1x1_enabled = _os.environ.get('MOS_CONV1X1', '1') != '0'
 _conv_min_pixels = int(_os.environ.get('MOS_CONV3X3_MIN_PIXELS', 8192))
 
 
@@ -565,9 +586,9 @@ def conv1x1(conv, x):
     ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
     ok = (x.is_cuda and (half or ac) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
           and conv.groups == 1 and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0
-          and not conv.weight.requires_grad and (conv.bias is None or not conv.bias.requires_grad)
+          and _frozen(conv.weight, conv.bias)
           and getattr(conv, '_mos_lora', None) is None and conv.forward.__func__ is torch.nn.Conv2d.forward
-          and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and _conv_enabled
+          and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and _conv_enabled and _conv1x1_enabled
           and not conv._forward_hooks and not conv._forward_pre_hooks)      # hooks (gradient fusion) need conv.__call__
     if not ok:
         return conv(x)
