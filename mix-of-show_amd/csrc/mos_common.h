@@ -97,6 +97,12 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
 __device__ __forceinline__ u32x4 ldbuf16(rsrc_t src, int byte_off) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(src, byte_off, 0, 0));
 }
+// LDS-DMA: 16 B per lane straight from the buffer into LDS at (wave-uniform base) + lane * 16 -- no VGPRs, no ds_write.
+// Out-of-range lanes deposit zeros. Completion is tracked by vmcnt; a barrier makes it visible to the other waves.
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __forceinline__ void dma16(rsrc_t src, void* lds_wave_base, int byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void_t*)lds_wave_base, 16, byte_off, 0, 0, 0);
+}
 
 // ---- host-side error plumbing (defined in mos_api.hip) --------------------------------------
 int mos_set_error(int code, const char* fmt, ...);

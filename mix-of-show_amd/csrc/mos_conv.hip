@@ -10,15 +10,30 @@
 // outside the image, which the buffer-load bounds check delivers for free when the offset is pushed past the descriptor's
 // range. No im2col buffer, no layout transposes, no zero-fill of split-K outputs; the per-sample time-embedding bias and
 // the ResNet residual add ride in the epilogue (MIOpen: separate transpose / SubTensorOp / add kernels around each call).
-// Tiling, LDS layout, MFMA feeding and the XCD-aware block map are those of gemm_lora_kernel (mos_gemm.hip).
+//
+// Staging: the tiles go global -> LDS directly (`buffer_load_dwordx4 ... lds`, LDS-DMA): no staging VGPRs and, above all,
+// no ds_write_b128 pass — the VGPR->LDS store path moves ~79 B/clk/CU against 256 B/clk for ds_read_b128
+// (MI355X_MICROARCH.md, LDS), so at 128x128x64 register-staged stores cost ~415 clk per 515 clk of MFMA. Measured
+// against the register-staged form of this kernel (same box): 64x64 maps 83 -> 49 us, VAE 512-px stage 536 -> 463 us,
+// 128-px stage 447 -> 377 us. The DMA destination is lane-linear (M0 base + lane * 16 B), so rows cannot be padded: the
+// tile image is [row][8 chunks of 16 B] with the chunk index XOR-ed with (row & 7), applied on the SOURCE side (which
+// chunk a lane fetches) and undone in the fragment reads — conflict-free for the ds_read_b128 lane groups (checked
+// exhaustively). Out-of-image taps and rows past M still come from the bounds check: the DMA deposits the zeros.
+//
+// Two pipelines: NS = 2 — double buffer, one tile ahead, `vmcnt(0)` + barrier per K tile — for grids with several blocks
+// per CU (block-level overlap hides the DMA latency); NS >= 3 — a ring with NS - 1 tiles in flight and a COUNTED
+// `s_waitcnt vmcnt((NS-2) * loads-per-tile)` in front of a raw `s_barrier` (a `__syncthreads()` would drain the queue) —
+// for the low-resolution levels, where ~1 block per CU walks a 9*Cin-deep K loop and every K tile otherwise pays a full
+// L2/HBM round trip. Tiles past the end of K are issued as out-of-range (zero) DMAs so the count is the same every
+// iteration; the ring is drained before the epilogue reuses the LDS.
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "mos_common.h"
 
 namespace {
 
 constexpr int CBK = 64;
-constexpr int CLS = CBK + 8;
 
 struct ConvArgs {
     const void* X; const void* W; const float* bias; const void* tbias; const void* R; void* Y;
@@ -27,17 +42,25 @@ struct ConvArgs {
     int up;                       // 1: the input is read through a nearest 2x upsample (x is (B, H/2, W/2, Cin))
 };
 
-template <typename T, int BM, int BN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_then_barrier() {
+    // counted wait on this wave's DMAs (and on its LDS reads: the scheduler may sink MFMAs, with the wait for their
+    // operands, below this point), then the workgroup barrier; one asm block with a memory clobber so that no LDS access
+    // moves across it (s_barrier itself does not drain VMEM: later tiles stay in flight)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, bool UP, int NS>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     typedef typename MT<T>::v8 v8;
     constexpr int MI = BM / 32, NJ = BN / 32;
     constexpr int XCH = BM * 8 / 256, WCH = BN * 8 / 256;
     constexpr int CS = BN + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Xs = reinterpret_cast<T*>(smem_raw);        // [2][BM][72]
-    T* Ws = Xs + 2 * BM * CLS;                     // [2][BN][72]
+    T* Xs = reinterpret_cast<T*>(smem_raw);        // [NS][BM][64], chunk-swizzled
+    T* Ws = Xs + NS * BM * CBK;                    // [NS][BN][64]
 
-    const int w = blockIdx.x;
+    const int w = blockIdx.x;                      // XCD-aware map: the 8 m-tiles of a slot share one weight column block
     const int slot = w >> 3;
     const int n_tile = slot % a.nt;
     const int m_tile = (slot / a.nt) * 8 + (w & 7);
@@ -47,30 +70,29 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     const int n0 = n_tile * BN, m0 = m_tile * BM;
     const int M = a.M, N = a.Cout, C = a.Cin, H = a.H, Wd = a.Wd;
     const int K = 9 * C;
-    const int Hs = a.up ? H / 2 : H, Ws_ = a.up ? Wd / 2 : Wd;     // source image size
+    const int Hs = UP ? H / 2 : H, Ws_ = UP ? Wd / 2 : Wd;     // source image size
 
     const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((int64_t)a.B * Hs * Ws_ * C * (int64_t)sizeof(T)));
     const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * K + K) * (int64_t)sizeof(T)));
     constexpr int OOB = 0x7FFFFF00;
 
-    int py[XCH], px[XCH], pb[XCH], woff[WCH];
+    // this lane's 16-byte slot in a wave-instruction: row = slot / 8, physical chunk = slot % 8 -> logical chunk
+    const int cc8 = ((tid & 7) ^ ((tid >> 3) & 7)) * 8;
+    int py[XCH], px[XCH], rowoff[XCH], woff[WCH];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
-        const int c = tid + 256 * i;
-        const int m = m0 + (c >> 3);
+        const int m = m0 + ((tid + 256 * i) >> 3);
         if (m < M) {
             const int b = m / (H * Wd), p = m - b * (H * Wd);
-            py[i] = p / Wd; px[i] = p - py[i] * Wd; pb[i] = b;
+            py[i] = p / Wd; px[i] = p - py[i] * Wd;
+            rowoff[i] = UP ? b * Hs : (((b * Hs + py[i]) * Ws_ + px[i]) * C + cc8) * (int)sizeof(T);
         } else {
-            py[i] = -100000; px[i] = 0; pb[i] = 0;
+            py[i] = -100000; px[i] = 0; rowoff[i] = 0;
         }
     }
 #pragma unroll
-    for (int i = 0; i < WCH; ++i) {
-        const int c = tid + 256 * i;
-        woff[i] = (int)((((int64_t)(n0 + (c >> 3))) * K + (c & 7) * 8) * (int64_t)sizeof(T));
-    }
-    const int cc8 = (tid & 7) * 8;
+    for (int i = 0; i < WCH; ++i)
+        woff[i] = (int)((((int64_t)(n0 + ((tid + 256 * i) >> 3))) * K + cc8) * (int64_t)sizeof(T));
 
     f32x4 acc[NJ][MI];
 #pragma unroll
@@ -78,61 +100,76 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 xr[XCH], wr[WCH];
     const int nk = 9 * a.cpt;
-    int tap = 0, cch = 0;                      // tap / channel chunk of the NEXT tile to load
+    int tap = 0, cch = 0;                      // tap / channel chunk of the NEXT tile to issue
 
-    auto load_tile = [&](int kt) {
+    auto issue_tile = [&](int kt, int buf) {   // tile kt -> LDS buffer buf; wave w's i-th piece = slots (4 i + w) * 64 ..
+        const bool live = kt < nk;             // ring only: tiles past the end are issued out of range (zeros, no traffic)
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        T* xs = Xs + buf * BM * CBK + wave * 512;
+        T* ws = Ws + buf * BN * CBK + wave * 512;
+        const int delta = ((dy * Ws_ + dx) * C + cch * CBK) * (int)sizeof(T);      // non-upsampled source: linear in the tap
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             const int yy = py[i] + dy, xx = px[i] + dx;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
-            const int ys = a.up ? (yy >> 1) : yy, xs = a.up ? (xx >> 1) : xx;
-            const int off = ((pb[i] * Hs + ys) * Ws_ + xs) * C + cch * CBK + cc8;
-            xr[i] = ldbuf16(xsrc, ok ? off * (int)sizeof(T) : OOB);
+            const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+            int off;
+            if (UP) off = (((rowoff[i] + (yy >> 1)) * Ws_ + (xx >> 1)) * C + cch * CBK + cc8) * (int)sizeof(T);
+            else off = rowoff[i] + delta;
+            dma16(xsrc, xs + i * 2048, ok ? off : OOB);
         }
         const int kb = kt * CBK * (int)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) wr[i] = ldbuf16(wsrc, woff[i] + kb);
+        for (int i = 0; i < WCH; ++i) dma16(wsrc, ws + i * 2048, live ? woff[i] + kb : OOB);
         if (++cch == a.cpt) { cch = 0; ++tap; }
     };
-    auto store_tile = [&](int buf) {
-        T* xs = Xs + buf * BM * CLS;
-        T* ws = Ws + buf * BN * CLS;
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int c = tid + 256 * i;
-            st16(xs + (c >> 3) * CLS + (c & 7) * 8, xr[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int c = tid + 256 * i;
-            st16(ws + (c >> 3) * CLS + (c & 7) * 8, wr[i]);
-        }
-    };
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const T* xs = Xs + cur * BM * CLS + (wm * (BM / 2) + l15) * CLS + lg * 8;
-        const T* ws = Ws + cur * BN * CLS + (wn * (BN / 2) + l15) * CLS + lg * 8;
+    // fragment reads: row l15 (+16 i), logical chunk kk * 4 + lg -> physical chunk ^ (row & 7)
+    const int sw0 = ((lg ^ (l15 & 7)) * 8), sw1 = sw0 ^ 32;
+    auto compute_tile = [&](int buf) {
+        const T* xs = Xs + buf * BM * CBK + (wm * (BM / 2) + l15) * CBK;
+        const T* ws = Ws + buf * BN * CBK + (wn * (BN / 2) + l15) * CBK;
 #pragma unroll
         for (int kk = 0; kk < CBK / 32; ++kk) {
+            const int sw = kk ? sw1 : sw0;
             v8 bfrag[MI], afrag[NJ];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) bfrag[i] = as_v8<T>(ld16(xs + i * 16 * CLS + kk * 32));
+            for (int i = 0; i < MI; ++i) bfrag[i] = as_v8<T>(ld16(xs + i * 16 * CBK + sw));
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) afrag[j] = as_v8<T>(ld16(ws + j * 16 * CLS + kk * 32));
+            for (int j = 0; j < NJ; ++j) afrag[j] = as_v8<T>(ld16(ws + j * 16 * CBK + sw));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16(afrag[j], bfrag[i], acc[j][i]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+    };
+
+    if constexpr (NS == 2) {
+        issue_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+            compute_tile(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else {
+        constexpr int L = XCH + WCH;           // DMAs per wave per tile
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) issue_tile(s, s);
+        int cur = 0, nxt = NS - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt has landed for this wave once at most the NS-2 younger tiles are outstanding; past the barrier it has
+            // landed for all waves, and all of them have finished reading tile kt-1, whose buffer the next issue overwrites
+            wait_vmcnt_then_barrier<(NS - 2) * L>();
+            issue_tile(kt + NS - 1, nxt);
+            compute_tile(cur);
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero tiles issued past the end
         __syncthreads();
     }
 
@@ -180,18 +217,30 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, int BM, int BN>
-int launch_conv_cfg(ConvArgs a, hipStream_t st) {
-    size_t lds = 2 * (size_t)(BM + BN) * CLS * sizeof(T);
+template <typename T, int BM, int BN, bool UP, int NS>
+int launch_conv_cfg2(ConvArgs a, hipStream_t st) {
+    size_t lds = (size_t)NS * (BM + BN) * CBK * sizeof(T);
     const size_t stage = (size_t)BM * (BN + 8) * sizeof(T);
     if (stage > lds) lds = stage;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN, UP, NS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     a.mt = (a.M + BM - 1) / BM;
     a.nt = (a.Cout + BN - 1) / BN;
     const int mt8 = (a.mt + 7) / 8 * 8;
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, BM, BN>), dim3(mt8 * a.nt), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, BM, BN, UP, NS>), dim3(mt8 * a.nt), dim3(256), lds, st, a);
     return mos_check_launch("conv3x3_nhwc");
+}
+
+template <typename T, int BM, int BN, int NS>
+int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
+    return a.up ? launch_conv_cfg2<T, BM, BN, true, NS>(a, st) : launch_conv_cfg2<T, BM, BN, false, NS>(a, st);
+}
+
+// Workgroup count below which the K loop is latency-bound and the DMA ring replaces the double buffer (MOS_RING_MAX_WG=0
+// disables the ring).
+inline int ring_max_wg() {
+    static const int v = [] { const char* e = getenv("MOS_RING_MAX_WG"); return e ? atoi(e) : 640; }();
+    return v;
 }
 
 template <typename T>
@@ -205,10 +254,11 @@ int launch_conv(ConvArgs a, hipStream_t st) {
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
     if (tiles(bm, bn) < 384) bm = 64;
     if (tiles(bm, bn) < 256 && bn == 128) bn = 64;
-    if (bm == 128 && bn == 128) return launch_conv_cfg<T, 128, 128>(a, st);
-    if (bm == 128) return launch_conv_cfg<T, 128, 64>(a, st);
-    if (bn == 128) return launch_conv_cfg<T, 64, 128>(a, st);
-    return launch_conv_cfg<T, 64, 64>(a, st);
+    if (bm == 128 && bn == 128) return launch_conv_cfg<T, 128, 128, 2>(a, st);
+    if (bm == 128) return launch_conv_cfg<T, 128, 64, 2>(a, st);
+    const bool ring = tiles(bm, bn) <= ring_max_wg();
+    if (bn == 128) return ring ? launch_conv_cfg<T, 64, 128, 3>(a, st) : launch_conv_cfg<T, 64, 128, 2>(a, st);
+    return ring ? launch_conv_cfg<T, 64, 64, 4>(a, st) : launch_conv_cfg<T, 64, 64, 2>(a, st);
 }
 
 }  // namespace

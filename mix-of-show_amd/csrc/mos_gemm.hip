@@ -19,6 +19,7 @@
 // We feed A <- weight rows (n), B <- activation rows (m), so every lane ends up with 4
 // CONSECUTIVE output features of one token: an 8-byte store.
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "mos_common.h"
 
@@ -59,8 +60,10 @@ struct GemmArgs {
 //     below ~100 workgroups (M = 256). hipBLASLt sits at the same level on these shapes (profiles/r02_kernel_bench_gemm_vs_hipblaslt.txt).
 //   * The output tile goes through LDS so that every store instruction writes whole 16 B chunks of consecutive features
 //     (a lane's accumulators are 4 features of one token: written directly, a wave's store touches 16 rows x 32 B).
-template <typename T, int BM, int BN, int BK, bool FUSED, bool KTAIL>
+template <typename T, int BM, int BN, int BK, bool FUSED, bool KTAIL, bool DMA, int NS>
 __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
+    static_assert(!DMA || (BK == 64 && !KTAIL), "the LDS-DMA tile image is [row][8 swizzled 16 B chunks]");
+    static_assert(NS == 2 || DMA, "more than two stages: LDS-DMA ring only");
     typedef typename MT<T>::v8 v8;
     typedef typename MT<T>::v4 v4;
     constexpr int MI = BM / 32;             // 16-row m sub-tiles per wave (wave tile = BM/2 x BN/2)
@@ -69,13 +72,15 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
     constexpr int XCH = BM * CPR / 256;     // chunks of the X tile per thread
     constexpr int WCH = BN * CPR / 256;
     constexpr int ACH = (16 * CPR + 255) / 256;
-    constexpr int LS = BK + 8;              // LDS row stride: (BK/8 + 1) 16-byte slots, odd -> conflict-free b128 reads
+    // LDS row stride. Register staging: (BK/8 + 1) 16-byte slots, odd -> conflict-free b128 reads. LDS-DMA: the image is
+    // lane-linear, rows cannot be padded; chunk c of row r sits at slot c ^ (r & 7) instead (same property, see mos_conv.hip).
+    constexpr int LS = DMA ? BK : BK + 8;
     constexpr int CS = BN + 8;              // output staging stride
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Xs = reinterpret_cast<T*>(smem_raw);                       // [2][BM][LS]
-    T* Ws = Xs + 2 * BM * LS;                                     // [2][BN][LS]
-    T* As = Ws + 2 * BN * LS;                                     // [2][16][LS]   (FUSED)
+    T* Xs = reinterpret_cast<T*>(smem_raw);                       // [NS][BM][LS]
+    T* Ws = Xs + NS * BM * LS;                                    // [NS][BN][LS]
+    T* As = Ws + NS * BN * LS;                                    // [NS][16][LS]   (FUSED)
 
     const int w = blockIdx.x;
     const int slot = w >> 3;
@@ -96,21 +101,23 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
     const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * a.ldw + K) * (int64_t)sizeof(T)));
     const rsrc_t asrc = make_rsrc(FUSED ? a.Adown : a.W, (uint32_t)(FUSED ? 16 * (int64_t)K * sizeof(T) : 16));
 
+    // chunk (16 B) this thread moves in row c / CPR: column c % CPR, or its swizzled partner under LDS-DMA
+    auto chunk_col = [](int c) { return DMA ? ((c & 7) ^ ((c >> 3) & 7)) : (c % CPR); };
     int xoff[XCH], woff[WCH], aoff[ACH];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int c = tid + 256 * i;
-        xoff[i] = (int)((((int64_t)(m0 + c / CPR)) * a.ldx + (c % CPR) * 8) * (int64_t)sizeof(T));
+        xoff[i] = (int)((((int64_t)(m0 + c / CPR)) * a.ldx + chunk_col(c) * 8) * (int64_t)sizeof(T));
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
         const int c = tid + 256 * i;
-        woff[i] = (int)((((int64_t)(n0 + c / CPR)) * a.ldw + (c % CPR) * 8) * (int64_t)sizeof(T));
+        woff[i] = (int)((((int64_t)(n0 + c / CPR)) * a.ldw + chunk_col(c) * 8) * (int64_t)sizeof(T));
     }
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
-        const int c = min(tid + 256 * i, 16 * CPR - 1);
-        aoff[i] = (int)(((int64_t)(c / CPR) * K + (c % CPR) * 8) * (int64_t)sizeof(T));
+        const int c = DMA ? (tid & 127) : min(tid + 256 * i, 16 * CPR - 1);
+        aoff[i] = (int)(((int64_t)(c / CPR) * K + chunk_col(c) * 8) * (int64_t)sizeof(T));
     }
 
     f32x4 acc[NJ][MI];
@@ -125,6 +132,21 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
     u32x4 xr[XCH], wr[WCH], ar[ACH];
     const int nk = (K + BK - 1) / BK;
 
+    // DMA: tile kt -> LDS buffer buf; wave w's i-th piece = slots (4i + w) * 64 .. The 16 A rows are two pieces: waves 2, 3
+    // repeat those of waves 0, 1 (same bytes, same place) so that every wave has the same number of DMAs in flight, which
+    // is what the ring's counted wait needs. Ring tiles past the end of K are issued out of range (zeros, no traffic).
+    constexpr int OOB = 0x7FFFFF00;
+    auto dma_tile = [&](int kt, int buf) {
+        const bool live = (NS == 2) || kt < nk;
+        const int kb = kt * BK * (int)sizeof(T);
+        T* xs = Xs + buf * BM * LS + wave * 512;
+        T* ws = Ws + buf * BN * LS + wave * 512;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) dma16(xsrc, xs + i * 2048, live ? xoff[i] + kb : OOB);
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) dma16(wsrc, ws + i * 2048, live ? woff[i] + kb : OOB);
+        if constexpr (FUSED) dma16(asrc, As + buf * 16 * LS + (wave & 1) * 512, live ? aoff[0] + kb : OOB);
+    };
     auto load_tile = [&](int kt) {
         const int kb = kt * BK * (int)sizeof(T);
 #pragma unroll
@@ -170,35 +192,71 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
         }
     };
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMAs below
-        const T* xs = Xs + cur * BM * LS + (wm * (BM / 2) + l15) * LS + lg * 8;
-        const T* ws = Ws + cur * BN * LS + (wn * (BN / 2) + l15) * LS + lg * 8;
-        const T* as = As + cur * 16 * LS + l15 * LS + lg * 8;
+    // fragment chunk of k-step kk: lg + 4 kk, at its swizzled slot under DMA (every fragment row r has r & 7 == l15 & 7)
+    const int fc0 = DMA ? ((lg ^ (l15 & 7)) * 8) : lg * 8;
+    auto compute_tile = [&](int buf) {
+        const T* xs = Xs + buf * BM * LS + (wm * (BM / 2) + l15) * LS;
+        const T* ws = Ws + buf * BN * LS + (wn * (BN / 2) + l15) * LS;
+        const T* as = As + buf * 16 * LS + l15 * LS;
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
+            const int fc = DMA ? (fc0 ^ (kk * 32)) : (fc0 + kk * 32);
             v8 bfrag[MI], afrag[NJ];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) bfrag[i] = as_v8<T>(ld16(xs + i * 16 * LS + kk * 32));
+            for (int i = 0; i < MI; ++i) bfrag[i] = as_v8<T>(ld16(xs + i * 16 * LS + fc));
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) afrag[j] = as_v8<T>(ld16(ws + j * 16 * LS + kk * 32));
+            for (int j = 0; j < NJ; ++j) afrag[j] = as_v8<T>(ld16(ws + j * 16 * LS + fc));
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16(afrag[j], bfrag[i], acc[j][i]);
             if constexpr (FUSED) {
-                const v8 at = as_v8<T>(ld16(as + kk * 32));
+                const v8 at = as_v8<T>(ld16(as + fc));
 #pragma unroll
                 for (int i = 0; i < MI; ++i) acct[i] = MT<T>::mfma16(at, bfrag[i], acct[i]);
             }
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+    };
+
+    if constexpr (DMA && NS > 2) {
+        // ring: NS - 1 tiles in flight; tile kt is complete for this wave once at most the NS - 2 younger ones are
+        // outstanding, and for the block past the barrier, which also retires every read of tile kt - 1 (the next target)
+        constexpr int L = XCH + WCH + (FUSED ? 1 : 0);
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s) dma_tile(s, s);
+        int cur = 0, nxt = NS - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NS - 2) * L) : "memory");
+            dma_tile(kt + NS - 1, nxt);
+            compute_tile(cur);
+            cur = (cur + 1 == NS) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero tiles issued past the end
         __syncthreads();
+    } else {
+        if constexpr (DMA) {
+            dma_tile(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            load_tile(0);
+            store_tile(0);
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {                   // next tile in flight under the MFMAs below
+                if constexpr (DMA) dma_tile(kt + 1, cur ^ 1);
+                else load_tile(kt + 1);
+            }
+            compute_tile(cur);
+            if constexpr (DMA) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (kt + 1 < nk) store_tile(cur ^ 1);
+            }
+            __syncthreads();
+        }
     }
 
     // Rank augmentation: y += t[M,16] . Baug[N,16]^T, one K=16 MFMA per tile
@@ -420,18 +478,18 @@ __global__ void lora_pack_kernel(mos_lora_sites s, T* __restrict__ A16, T* __res
     }
 }
 
-template <typename T, int BM, int BN, int BK, bool FUSED, bool KTAIL>
+template <typename T, int BM, int BN, int BK, bool FUSED, bool KTAIL, bool DMA, int NS>
 int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
-    size_t lds = 2 * (size_t)(BM + BN + (FUSED ? 16 : 0)) * (BK + 8) * sizeof(T);
+    size_t lds = (size_t)NS * (BM + BN + (FUSED ? 16 : 0)) * (DMA ? BK : BK + 8) * sizeof(T);
     const size_t stage = (size_t)BM * (BN + 8) * sizeof(T);
     if (stage > lds) lds = stage;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lora_kernel<T, BM, BN, BK, FUSED, KTAIL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lora_kernel<T, BM, BN, BK, FUSED, KTAIL, DMA, NS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     GemmArgs b = a;
     b.mt = (a.M + BM - 1) / BM;
     b.nt = (a.N + BN - 1) / BN;
     const int mt8 = (b.mt + 7) / 8 * 8;
-    hipLaunchKernelGGL((gemm_lora_kernel<T, BM, BN, BK, FUSED, KTAIL>), dim3(mt8 * b.nt), dim3(256), lds, st, b);
+    hipLaunchKernelGGL((gemm_lora_kernel<T, BM, BN, BK, FUSED, KTAIL, DMA, NS>), dim3(mt8 * b.nt), dim3(256), lds, st, b);
     return mos_check_launch("gemm_lora");
 }
 
@@ -441,22 +499,27 @@ int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
 // configurations take deep stages (BK 256 / 128), see the kernel comment.
 template <typename T, bool FUSED>
 int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
-    if (a.K % GEMM_BK != 0) return launch_gemm_cfg<T, 64, 64, 64, FUSED, true>(a, st);
+    if (a.K % GEMM_BK != 0) return launch_gemm_cfg<T, 64, 64, 64, FUSED, true, false, 2>(a, st);
     int bn = (a.N % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
     if (tiles(bm, bn) < 384) bm = 64;
     if (tiles(bm, bn) < 256 && bn == 128) bn = 64;
-    const bool deep = tiles(bm, bn) <= MOS_GEMM_DEEP_MAX_WG;
-    if (bm == 128 && bn == 128) return launch_gemm_cfg<T, 128, 128, 64, FUSED, false>(a, st);
-    if (bm == 128) return launch_gemm_cfg<T, 128, 64, 64, FUSED, false>(a, st);
-    if (bn == 128) {
-        if (deep && a.K % 128 == 0) return launch_gemm_cfg<T, 64, 128, 128, FUSED, false>(a, st);
-        return launch_gemm_cfg<T, 64, 128, 64, FUSED, false>(a, st);
+    if (bm == 128 && bn == 128) return launch_gemm_cfg<T, 128, 128, 64, FUSED, false, true, 2>(a, st);
+    if (bm == 128) return launch_gemm_cfg<T, 128, 64, 64, FUSED, false, true, 2>(a, st);
+    static const int ring_max_wg = [] { const char* e = getenv("MOS_RING_MAX_WG"); return e ? atoi(e) : 640; }();
+    const bool ring = tiles(bm, bn) <= ring_max_wg;
+    if (ring) {
+        if (bn == 128) return launch_gemm_cfg<T, 64, 128, 64, FUSED, false, true, 3>(a, st);
+        return launch_gemm_cfg<T, 64, 64, 64, FUSED, false, true, 4>(a, st);
     }
-    if (deep && a.K % 256 == 0) return launch_gemm_cfg<T, 64, 64, 256, FUSED, false>(a, st);
-    if (deep && a.K % 128 == 0) return launch_gemm_cfg<T, 64, 64, 128, FUSED, false>(a, st);
-    // (32-row tiles for the 160-460 workgroup grids were measured too: 18.9 vs 17.5 us at M1024 N1280 K1280 — no gain)
-    return launch_gemm_cfg<T, 64, 64, 64, FUSED, false>(a, st);
+    const bool deep = tiles(bm, bn) <= MOS_GEMM_DEEP_MAX_WG;
+    if (bn == 128) {
+        if (deep && a.K % 128 == 0) return launch_gemm_cfg<T, 64, 128, 128, FUSED, false, false, 2>(a, st);
+        return launch_gemm_cfg<T, 64, 128, 64, FUSED, false, true, 2>(a, st);
+    }
+    if (deep && a.K % 256 == 0) return launch_gemm_cfg<T, 64, 64, 256, FUSED, false, false, 2>(a, st);
+    if (deep && a.K % 128 == 0) return launch_gemm_cfg<T, 64, 64, 128, FUSED, false, false, 2>(a, st);
+    return launch_gemm_cfg<T, 64, 64, 64, FUSED, false, true, 2>(a, st);
 }
 
 // adown != NULL: fused down projection (t computed in-kernel, stored to tout if given); else t (may be NULL) is read.

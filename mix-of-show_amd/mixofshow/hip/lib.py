@@ -140,6 +140,9 @@ _lib = None
 _lock = threading.Lock()
 
 
+RING_MAX_WG_DEFAULT = 640
+
+
 def load():
     """Return the loaded library (ctypes.CDLL) with typed entry points; raise if it is missing."""
     global _lib
@@ -153,6 +156,9 @@ def load():
                 f'libmos_hip.so not found at {LIB_PATH}. Build it with `bash mix-of-show_amd/csrc/build.sh` '
                 '(or `python -c "import __graft_entry__ as g; g.build()"`). mixofshow has no CPU/PyTorch fallback '
                 'for its kernel-backed ops.')
+        # Host-side tuning defaults of the kernels' own switches (read by the library with getenv at first launch):
+        # MOS_RING_MAX_WG = workgroup count up to which the GEMM / conv K loops run as an LDS-DMA ring (0 = never).
+        os.environ.setdefault('MOS_RING_MAX_WG', str(RING_MAX_WG_DEFAULT))
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -84,7 +84,10 @@ def test_roofline_helper_and_pmc_traffic_staleness(tmp_path):
     assert bench._pmc_traffic(recs[0]['name'], str(good)) == 1.27e8
     assert bench._pmc_traffic(recs[0]['name'], str(stale)) is None
     assert bench._pmc_traffic('no such kernel', str(good)) is None
-    a = bench.attention_path_aggregate(604.0, 4, 21.7)
+    agg = [dict(name='attn_fwd f16 d40', total_ms=30.0), dict(name='gemm_nt f16 M1', total_ms=13.4),
+           dict(name='conv3x3 f16 B4', total_ms=20.0), dict(name='groupnorm_apply f16', total_ms=2.0)]
+    a = bench.attention_path_aggregate(604.0, 4, agg, 2)
+    assert abs(a['attention_path_kernel_ms'] - 21.7) < 1e-6 and abs(a['other_library_kernel_ms'] - 11.0) < 1e-6
     assert abs(a['achieved_tflops'] - 2.416 / 21.7e-3) < 0.5 and abs(a['frac_of_mfma_peak'] - a['achieved_tflops'] / 2500) < 1e-4
 
 

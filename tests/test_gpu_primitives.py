@@ -113,6 +113,7 @@ def test_lora_linear_fwd_bwd(ops, emu, dtype, M, N, K, sites):
     (100, 320, 320, [320]),               # ragged tile
     (4928, 2304, 768, [768, 768, 768]),   # CLIP fused q/k/v on 64x77 tokens
     (72, 328, 200, [328]),                # K % 64 != 0: the column-masked variant
+    (512, 320, 64, [320]),                # one K tile: the DMA ring's prologue runs past the end of K
 ])
 def test_lora_linear_fused_fwd_bwd(ops, emu, dtype, M, N, K, sites):
     """One-launch forward (down projection fused into the GEMM) and two-launch backward (dx+dt, then both factor
@@ -486,6 +487,8 @@ def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
     (1, 1920, 640, 32, 48, 'r'),      # 512x768 regional sample (non-square map)
     (2, 1280, 1280, 16, 16, 'u'),     # Upsample2D: nearest 2x folded into the gather, output 32x32
     (2, 128, 128, 96, 80, 't'),       # VAE-like stage, ragged tile count
+    (1, 128, 256, 250, 203, 'r'),     # VAE stage, 128 x 128 tiles, ragged last tile
+    (1, 128, 128, 512, 500, ''),      # VAE 512-px stage (largest tile variant when enabled)
     (1, 64, 8, 5, 7, 'tr'),           # tiny / odd sizes
 ])
 def test_conv3x3_nhwc(ops, emu, dtype, B, Cin, Cout, H, W, extras):

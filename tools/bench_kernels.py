@@ -85,7 +85,7 @@ def blas_reference(shapes, dtype, iters):
         print(f"{f'M{M} N{N} K{K}':30s} {us:14.1f} {fl / us / 1e6:9.1f} {us2:12.1f} {fl / us2 / 1e6:9.1f}")
 
 
-def conv_reference(shapes, dtype, iters):
+def conv_reference(shapes, dtype, iters, ref=True):
     """3x3 convolutions of the SD-1.5 UNet / VAE: the implicit-GEMM kernel vs MIOpen (torch conv2d, channels_last), forward
     and backward-data, one event pair around `iters` back-to-back launches."""
     def timed(fn):
@@ -110,11 +110,13 @@ def conv_reference(shapes, dtype, iters):
         dy = torch.randn(B, Cout, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
             t_mf = timed(lambda: ops.conv3x3_nhwc(x, w_fwd, b32))
-            t_rf = timed(lambda: conv(x))
+            t_rf = timed(lambda: conv(x)) if ref else float('nan')
             t_mb = timed(lambda: ops.conv3x3_nhwc(dy, w_bwd))
-        xg = x.clone().requires_grad_(True)
-        yg = conv(xg)
-        t_rb = timed(lambda: torch.autograd.grad(yg, xg, dy, retain_graph=True))
+        t_rb = float('nan')
+        if ref:
+            xg = x.clone().requires_grad_(True)
+            yg = conv(xg)
+            t_rb = timed(lambda: torch.autograd.grad(yg, xg, dy, retain_graph=True))
         fl = 2.0 * B * H * W * Cout * 9 * Cin
         print(f"{f'B{B} {Cin}->{Cout} {H}x{W}':34s} {t_mf:9.1f} {t_rf:11.1f} {t_mb:9.1f} {t_rb:11.1f} {fl / t_mf / 1e6:9.1f}")
 
@@ -149,6 +151,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--dtype', default='f16')
     ap.add_argument('--legacy', type=int, default=0, help='gemm: also time the round-1 multi-launch LoRA path')
+    ap.add_argument('--ref', type=int, default=1, help='0: skip the MIOpen / hipBLASLt reference timings')
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
     cases = []
@@ -175,8 +178,8 @@ def main():
                         (4, 1280, 640, 32, 32), (4, 1920, 640, 32, 32), (4, 1280, 1280, 16, 16), (4, 2560, 1280, 16, 16),
                         (4, 1280, 1280, 8, 8), (4, 2560, 1280, 8, 8), (4, 128, 128, 512, 512), (4, 256, 256, 256, 256),
                         (4, 512, 512, 128, 128), (4, 512, 512, 64, 64), (2, 320, 320, 64, 96), (2, 1280, 1280, 16, 24)],
-                       dt, args.iters)
-    if args.only in ('', 'gemm', 'blas'):
+                       dt, args.iters, ref=bool(args.ref))
+    if args.only in ('', 'gemm', 'blas') and args.ref:
         blas_reference([(16384, 320, 320), (16384, 960, 320), (4096, 640, 640), (4096, 1920, 640), (1024, 1280, 1280),
                         (1024, 3840, 1280), (256, 1280, 1280), (4928, 768, 768), (4928, 2304, 768), (12288, 320, 320),
                         (3072, 640, 640), (768, 1280, 1280)], dt, args.iters)

@@ -15,9 +15,17 @@ pass() {   # name, counters...
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "/tmp/pmc_$name" -o p -- \
       python "$ROOT/tools/bench_kernels.py" --only "$WHAT" --iters 3 > "/tmp/pmc_$name.log" 2>&1 || tail -5 "/tmp/pmc_$name.log"
 }
-pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS
-pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES
-pass fetch FETCH_SIZE
-pass write WRITE_SIZE
-python "$ROOT/tools/pmc_summary.py" /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_fetch /tmp/pmc_write > "$OUT/pmc_${WHAT}.txt" 2>&1
-tail -60 "$OUT/pmc_${WHAT}.txt"
+# PMC_PASSES="fetch write" limits the run to the HBM-traffic counters (tools/pmc_traffic.py needs only those)
+PASSES="${PMC_PASSES:-sq1 sq2 fetch write}"
+for p in $PASSES; do
+  case "$p" in
+    sq1) pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS ;;
+    sq2) pass sq2 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES ;;
+    fetch) pass fetch FETCH_SIZE ;;
+    write) pass write WRITE_SIZE ;;
+  esac
+done
+if [ "$PASSES" = "sq1 sq2 fetch write" ]; then
+  python "$ROOT/tools/pmc_summary.py" /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_fetch /tmp/pmc_write > "$OUT/pmc_${WHAT}.txt" 2>&1
+  tail -60 "$OUT/pmc_${WHAT}.txt"
+fi
