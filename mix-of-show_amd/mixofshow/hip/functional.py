@@ -542,9 +542,10 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
     need_bwd = torch.is_grad_enabled() and (x.requires_grad or (tbias is not None and tbias.requires_grad)
                                             or (residual is not None and residual.requires_grad))
     if ok:
-        # measured against MIOpen on MI355X (profiles/r02_kernel_bench_conv_vs_miopen.txt): the implicit-GEMM kernel wins
-        # from 8 k output pixels up (64x64 maps at batch 4: 94 vs 112 us; the VAE's 128..512 px stages: 0.45-0.54 vs
-        # 0.67-0.81 ms) and loses below (16x16: 117 vs 80 us, 8x8: 111 vs 40 us — few blocks walking a 9*Cin-deep K loop)
+        # measured against MIOpen on MI355X (profiles/r02_kernel_bench_conv_vs_miopen.txt for MIOpen,
+        # profiles/r02_dma_ring_ab.txt for this kernel): the implicit-GEMM kernel wins from 4 k output pixels up (64x64 maps
+        # at batch 4: 49 vs 112 us; 32x32: 63 vs 79 us; the VAE's 128..512 px stages: 0.37-0.46 vs 0.67-0.81 ms) and still
+        # loses below (16x16: 89 vs 80 us, 8x8: 73 vs 40 us); whole-step A/B: 4096 -> 44.85, 1024 -> 45.0, 256 -> 46.0 ms
         pixels = x.shape[0] * x.shape[2] * x.shape[3] * (4 if upsample else 1)
         ok = pixels >= _conv_min_pixels and (not need_bwd or conv.out_channels % 64 == 0)
     if not ok:
@@ -569,7 +570,7 @@ import os as _os
 
 _conv_enabled = _os.environ.get('MOS_CONV3X3', '1') != '0'
 _conv1x1_enabled = _os.environ.get('MOS_CONV1X1', '1') != '0'
-_conv_min_pixels = int(_os.environ.get('MOS_CONV3X3_MIN_PIXELS', 8192))
+_conv_min_pixels = int(_os.environ.get('MOS_CONV3X3_MIN_PIXELS', 4096))
 
 
 def set_conv3x3_enabled(flag):
