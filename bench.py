@@ -370,7 +370,7 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
         pipe.unet.to(memory_format=torch.channels_last)
     prompt, neg = regional_prompt(H, W)
     latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14))
-    graph = args.regional_graph
+    graph = None if args.regional_graph < 0 else bool(args.regional_graph)
 
     def sample(g):
         return pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50,
@@ -529,8 +529,8 @@ def main():
     ap.add_argument('--channels-last', type=int, default=1, help='NHWC UNet/VAE (the product default)')
     ap.add_argument('--graph', type=int, default=1, help='train: forward+backward replayed from a hipGraph (the product '
                     'default, train_edlora.py); 0 = eager')
-    ap.add_argument('--regional-graph', type=int, default=0, help='regional: replay the UNet call from a hipGraph (opt-in '
-                    'in the product too; the loop is GPU-bound)')
+    ap.add_argument('--regional-graph', type=int, default=-1, help='regional: 1 = replay the UNet call from a hipGraph, '
+                    '0 = eager, -1 = the product default (mixofshow.utils.hipgraph.sampling_default)')
     ap.add_argument('--concepts', type=int, default=14)
     ap.add_argument('--textenc-iters', type=int, default=500)
     ap.add_argument('--unet-iters', type=int, default=50)

@@ -224,11 +224,14 @@ class StableDiffusionPipeline:
             return self.unet(x, t, encoder_hidden_states=prompt_embeds,
                              cross_attention_kwargs=cross_attention_kwargs).sample
 
-        # `hipgraph=True` (opt-in; not with an attention-recording controller, which keeps Python-side state per
-        # call): step 0 is eager, the UNet call is captured at step 1 and replayed afterwards.
+        # hipGraph replay (`hipgraph=None` -> hipgraph_util.sampling_default(), on; not with an attention-recording
+        # controller or forward hooks, which keep Python-side state per call): step 0 is eager, the UNet call is
+        # captured at step 1 and replayed afterwards.
         from mixofshow.utils import hipgraph as hipgraph_util
+        if hipgraph is None:
+            hipgraph = hipgraph_util.sampling_default()
         hipgraph = (bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
-                    and not hasattr(self, 'controller'))
+                    and not hasattr(self, 'controller') and not hipgraph_util.has_forward_hooks(self.unet))
         graphed = None
         self.last_call_graphed = False
         for i, t in enumerate(timesteps):

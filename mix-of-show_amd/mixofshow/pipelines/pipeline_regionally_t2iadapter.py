@@ -288,10 +288,13 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
             return self.unet(x, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak,
                              down_block_additional_residuals=residuals).sample
 
-        # `hipgraph=True` (opt-in): step 0 runs eagerly (it fills the per-layer source K/V caches), the UNet call is
-        # captured at step 1 and replayed from then on. Off by default: at 512x768 with a CFG pair the loop is
-        # GPU-bound once the scheduler no longer reads the timestep back, so replay gains nothing.
-        hipgraph = bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
+        # hipGraph replay (`hipgraph=None` -> hipgraph_util.sampling_default(), on): step 0 runs eagerly (it fills the
+        # per-layer source K/V caches), the UNet call is captured at step 1 and replayed from then on: 544 vs 774 ms per
+        # 50-step sample. Not with forward hooks on the UNet (they would only run at capture time).
+        if hipgraph is None:
+            hipgraph = hipgraph_util.sampling_default()
+        hipgraph = (bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
+                    and not hipgraph_util.has_forward_hooks(self.unet))
         graphed = None
         self.last_call_graphed = False
         for i, t in enumerate(timesteps):

@@ -685,3 +685,21 @@ def test_conv3x3_autograd_function_vs_torch(emulated_hip, upsample):
         conv.weight.mul_(2.0)
     w2, _, _ = cache.get(conv, torch.float32, False)
     torch.testing.assert_close(w2, conv.weight.permute(0, 2, 3, 1))
+
+
+def test_sampling_hipgraph_default_and_hook_guard(monkeypatch):
+    """Sampling pipelines replay the UNet call from a hipGraph by default (MOS_SAMPLING_HIPGRAPH=0 opts out); a model
+    with forward hooks must run eagerly (hooks only fire at capture time)."""
+    import torch
+    from mixofshow.utils import hipgraph as hg
+    monkeypatch.delenv('MOS_SAMPLING_HIPGRAPH', raising=False)
+    assert hg.sampling_default() is True
+    monkeypatch.setenv('MOS_SAMPLING_HIPGRAPH', '0')
+    assert hg.sampling_default() is False
+    net = torch.nn.Sequential(torch.nn.Linear(2, 2), torch.nn.Sequential(torch.nn.Linear(2, 2)))
+    assert not hg.has_forward_hooks(net)
+    h = net[1][0].register_forward_hook(lambda m, i, o: None)
+    assert hg.has_forward_hooks(net)
+    h.remove()
+    assert not hg.has_forward_hooks(net)
+    assert not hg.graphs_usable('cpu')

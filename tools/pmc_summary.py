@@ -9,13 +9,15 @@ import sys
 
 def short(name):
     m = re.search(r'(attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkdv_kernel|attn_bwd_prep_kernel|region_attn_kernel|'
+                  r'gemm_lora_kernel|conv3x3_nhwc_kernel|gn_nhwc_reduce_kernel|gn_nhwc_apply_kernel|lora_grad_kernel|'
                   r'gemm_nt_kernel|skinny_nt_kernel|skinny_tn_kernel|gram_kernel|lsq_grad_kernel)', name)
     if not m:
         return None
-    t = re.findall(r'I(DF16_|DF16b)Li(\d+)', name)
-    extra = ''
-    if t:
-        extra = ('f16' if t[0][0] == 'DF16_' else 'bf16') + ' ' + t[0][1]
+    dt = re.search(r'I(DF16_|DF16b)', name)
+    extra = ('f16' if dt.group(1) == 'DF16_' else 'bf16') if dt else ''
+    # every integral / bool template argument, in order (tile sizes, head dim, flags, pipeline stages)
+    args = re.findall(r'L([ib])(\d+)E', name)
+    extra += ' <' + ','.join(v for _, v in args) + '>'
     return f'{m.group(1)} {extra}'
 
 
