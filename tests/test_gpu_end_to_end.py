@@ -314,7 +314,8 @@ def test_pipeline_call_equals_written_out_loop():
 
 
 def test_hipgraph_regional_sampling_equals_eager_sampling():
-    """50-step regional latents with the UNet call replayed from a hipGraph (opt-in) vs launched eagerly."""
+    """50-step regional latents with the UNet call replayed from a hipGraph (the default) vs launched eagerly; a UNet with
+    forward hooks falls back to the eager loop."""
     from bench import regional_prompt
     from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionallyT2IAdapterPipeline
     H, W = 512, 768
@@ -325,11 +326,15 @@ def test_hipgraph_regional_sampling_equals_eager_sampling():
     prompt, neg = regional_prompt(H, W)
     rkw = dict(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50, guidance_scale=7.5,
                output_type='latent')
-    r_eager = rp(latents=lat.clone(), **rkw).images
+    r_eager = rp(latents=lat.clone(), hipgraph=False, **rkw).images
     assert not rp.last_call_graphed
-    r_eager2 = rp(latents=lat.clone(), **rkw).images
-    r_graph = rp(latents=lat.clone(), hipgraph=True, **rkw).images
-    assert rp.last_call_graphed, 'capture fell back to eager'
+    r_eager2 = rp(latents=lat.clone(), hipgraph=False, **rkw).images
+    r_graph = rp(latents=lat.clone(), **rkw).images              # the default (hipgraph=None) replays
+    assert rp.last_call_graphed, 'the default call did not replay from a hipGraph (capture fell back to eager?)'
+    h = rp.unet.conv_in.register_forward_hook(lambda m, i, o: None)
+    rp(latents=lat.clone(), **dict(rkw, num_inference_steps=4))
+    h.remove()
+    assert not rp.last_call_graphed, 'a hooked UNet must be called eagerly'
     d = (r_eager.float() - r_graph.float()).abs().max().item()
     # a replayed graph launches the same kernels on the same data; yardstick = the eager loop's own run-to-run spread
     spread = (r_eager.float() - r_eager2.float()).abs().max().item()
