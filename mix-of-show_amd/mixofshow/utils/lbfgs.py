@@ -1,0 +1,229 @@
+"""L-BFGS with strong-Wolfe line search for a device-resident objective, without the host round trips of
+`torch.optim.LBFGS`.
+
+The reference's gradient fusion (gradient_fusion.py:78-85) runs ONE `torch.optim.LBFGS(lr=1, history_size=25,
+line_search_fn='strong_wolfe', tolerance_* = 1e-16).step(closure)` per layer. That optimiser is the algorithm to
+reproduce; its implementation, though, synchronises with the device ~2 x history + 6 times per iteration (every
+`q.add_(old_dirs[i], alpha=-al[i])` of the two-loop recursion reads a 0-dim tensor back as a Python scalar, and so does
+every comparison in the line search). With the Gram-form closure a function evaluation is one ~0.2 ms kernel, so
+fourteen-concept fusion spent ~100 of its 132 s in those round trips.
+
+Here the same iteration is organised so that the host reads back ONE small vector per function evaluation
+([loss, g.d, max|g|]) and one per search direction ([g.d, max|d|, sum|g|]):
+  * the two-loop recursion is replaced by its closed form, the compact representation of the L-BFGS inverse Hessian
+    (Byrd, Nocedal, Schnabel 1994, eq. 3.1):  H = gamma I + [S  gamma Y] M [S^T ; gamma Y^T],
+    M = [[R^-T (D + gamma Y^T Y) R^-1, -R^-T], [-R^-1, 0]],  R = triu(S^T Y),  D = diag(S^T Y) —
+    two (k x n) mat-vecs, two k x k triangular solves and one (n x k) combination, all on the device, identical to the
+    recursion in exact arithmetic (same pairs, same gamma = s.y / y.y of the newest accepted pair);
+  * curvature s.y of a new pair needs no reduction: y.s = t (g_new.d - g_old.d), both already on the host;
+  * the line search (`_strong_wolfe` below) is the optimiser's bracketing / zoom procedure on Python floats.
+Update rules, constants (c1 = 1e-4, c2 = 0.9, curvature threshold 1e-10, first step min(1, 1/|g|_1), max_eval =
+5/4 max_iter, max_ls = max_eval - evals so far), termination tests and their order follow torch.optim.LBFGS.step, so the
+iterates agree with it to rounding (tests/test_fusion_cpu.py compares them on random and on the reference's golden
+problems).
+"""
+import math
+
+import torch
+
+
+def _cubic_interpolate(x1, f1, g1, x2, f2, g2, bounds=None):
+    """Minimiser of the cubic through (x1, f1, g1), (x2, f2, g2), clipped to `bounds` (default: the interval)."""
+    if bounds is not None:
+        lo, hi = bounds
+    else:
+        lo, hi = (x1, x2) if x1 <= x2 else (x2, x1)
+    d1 = g1 + g2 - 3 * (f1 - f2) / (x1 - x2)
+    d2_square = d1 * d1 - g1 * g2
+    if d2_square >= 0:
+        d2 = math.sqrt(d2_square)
+        if x1 <= x2:
+            pos = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2 * d2))
+        else:
+            pos = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2 * d2))
+        return min(max(pos, lo), hi)
+    return (lo + hi) / 2.0
+
+
+def _strong_wolfe(evaluate, t, d_norm, f, g, gtd, c1=1e-4, c2=0.9, tolerance_change=1e-9, max_ls=25):
+    """Bracketing + zoom line search for the strong Wolfe conditions. `evaluate(t)` -> (f(t), g(t), g(t).d) with f and
+    g.d Python floats and g a device tensor that is not modified afterwards. Returns (f, g, t, evaluations, g.d)."""
+    f_new, g_new, gtd_new = evaluate(t)
+    evals = 1
+    t_prev, f_prev, g_prev, gtd_prev = 0.0, f, g, gtd
+    done = False
+    ls_iter = 0
+    bracket = bracket_f = bracket_g = bracket_gtd = None
+    while ls_iter < max_ls:
+        if f_new > (f + c1 * t * gtd) or (ls_iter > 1 and f_new >= f_prev):
+            bracket, bracket_f, bracket_g, bracket_gtd = [t_prev, t], [f_prev, f_new], [g_prev, g_new], [gtd_prev, gtd_new]
+            break
+        if abs(gtd_new) <= -c2 * gtd:
+            bracket, bracket_f, bracket_g, bracket_gtd = [t], [f_new], [g_new], [gtd_new]
+            done = True
+            break
+        if gtd_new >= 0:
+            bracket, bracket_f, bracket_g, bracket_gtd = [t_prev, t], [f_prev, f_new], [g_prev, g_new], [gtd_prev, gtd_new]
+            break
+        min_step = t + 0.01 * (t - t_prev)
+        max_step = t * 10
+        tmp = t
+        t = _cubic_interpolate(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, bounds=(min_step, max_step))
+        t_prev, f_prev, g_prev, gtd_prev = tmp, f_new, g_new, gtd_new
+        f_new, g_new, gtd_new = evaluate(t)
+        evals += 1
+        ls_iter += 1
+    if ls_iter == max_ls:
+        bracket, bracket_f, bracket_g, bracket_gtd = [0.0, t], [f, f_new], [g, g_new], [gtd, gtd_new]
+
+    insuf_progress = False
+    low_pos, high_pos = (0, 1) if bracket_f[0] <= bracket_f[-1] else (1, 0)
+    while not done and ls_iter < max_ls:
+        if abs(bracket[1] - bracket[0]) * d_norm < tolerance_change:
+            break
+        t = _cubic_interpolate(bracket[0], bracket_f[0], bracket_gtd[0], bracket[1], bracket_f[1], bracket_gtd[1])
+        # too close to an end of the bracket twice in a row, or on it: step 10 % of the bracket inside instead
+        eps = 0.1 * (max(bracket) - min(bracket))
+        if min(max(bracket) - t, t - min(bracket)) < eps:
+            if insuf_progress or t >= max(bracket) or t <= min(bracket):
+                t = max(bracket) - eps if abs(t - max(bracket)) < abs(t - min(bracket)) else min(bracket) + eps
+                insuf_progress = False
+            else:
+                insuf_progress = True
+        else:
+            insuf_progress = False
+        f_new, g_new, gtd_new = evaluate(t)
+        evals += 1
+        ls_iter += 1
+        if f_new > (f + c1 * t * gtd) or f_new >= bracket_f[low_pos]:
+            bracket[high_pos], bracket_f[high_pos], bracket_g[high_pos], bracket_gtd[high_pos] = t, f_new, g_new, gtd_new
+            low_pos, high_pos = (0, 1) if bracket_f[0] <= bracket_f[1] else (1, 0)
+        else:
+            if abs(gtd_new) <= -c2 * gtd:
+                done = True
+            elif gtd_new * (bracket[high_pos] - bracket[low_pos]) >= 0:
+                bracket[high_pos], bracket_f[high_pos] = bracket[low_pos], bracket_f[low_pos]
+                bracket_g[high_pos], bracket_gtd[high_pos] = bracket_g[low_pos], bracket_gtd[low_pos]
+            bracket[low_pos], bracket_f[low_pos], bracket_g[low_pos], bracket_gtd[low_pos] = t, f_new, g_new, gtd_new
+    return bracket_f[low_pos], bracket_g[low_pos], bracket[low_pos], evals, bracket_gtd[low_pos]
+
+
+class _History:
+    """The last `size` accepted (s, y) pairs as rows of S, Y in a ring (the oldest row is overwritten in place: no
+    shifting of the (size x n) buffers), with S Y^T and Y Y^T kept up to date in the same physical row order."""
+
+    def __init__(self, size, n, like):
+        self.size = size
+        kw = dict(dtype=like.dtype, device=like.device)
+        self.S = torch.empty(size, n, **kw)
+        self.Y = torch.empty(size, n, **kw)
+        self.SY = torch.zeros(size, size, **kw)
+        self.YY = torch.zeros(size, size, **kw)
+        self.k = 0              # pairs stored
+        self.start = 0          # physical row of the oldest pair once the ring is full
+        ar = torch.arange(size, device=like.device)
+        self.rot = (ar.unsqueeze(0) + ar.unsqueeze(1)) % size          # rot[r] = physical rows, oldest first, for start r
+
+    def push(self, s, y):
+        if self.k == self.size:
+            slot = self.start
+            self.start = (self.start + 1) % self.size
+        else:
+            slot = self.k
+            self.k += 1
+        k = self.k
+        self.S[slot], self.Y[slot] = s, y
+        self.SY[:k, slot] = self.S[:k] @ y           # s_i . y_new
+        self.SY[slot, :k] = self.Y[:k] @ s           # s_new . y_i
+        yy = self.Y[:k] @ y
+        self.YY[:k, slot] = yy
+        self.YY[slot, :k] = yy
+
+    def direction(self, g, gamma):
+        """-H g with H the L-BFGS inverse Hessian of the stored pairs and H0 = gamma I."""
+        k = self.k
+        q = g.neg()
+        if k == 0:
+            return q * gamma
+        S, Y = self.S[:k], self.Y[:k]
+        idx = self.rot[self.start, :k] if k == self.size else self.rot[0, :k]   # physical rows in age order
+        SY = self.SY[:k, :k][idx][:, idx]
+        YY = self.YY[:k, :k][idx][:, idx]
+        R = torch.triu(SY)
+        a = (S @ q)[idx]
+        b = (Y @ q)[idx] * gamma
+        Ra = torch.linalg.solve_triangular(R, a.unsqueeze(1), upper=True)                      # R^-1 a
+        mid = (torch.diag(torch.diagonal(SY)) + gamma * YY) @ Ra - b.unsqueeze(1)
+        v1 = torch.linalg.solve_triangular(R.t(), mid, upper=False).squeeze(1)                 # R^-T ((D + gamma YY) R^-1 a - b)
+        v2 = -Ra.squeeze(1)
+        back = torch.empty_like(idx)
+        back[idx] = self.rot[0, :k]                  # age position of each physical row
+        return q * gamma + S.t() @ v1[back] + (Y.t() @ v2[back]) * gamma
+
+
+def minimize(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolerance_grad=1e-16, tolerance_change=1e-16,
+             max_eval=None, on_eval=None):
+    """Minimise f from x0 (1-D device tensor). `value_and_grad(x)` -> (f(x) as a 0-dim device tensor, grad f(x) as a
+    1-D tensor that the caller does not modify afterwards). `on_eval(x, f_float)` is called after every evaluation
+    (the reference keeps the best-loss iterate over ALL evaluations, line-search trials included).
+    Returns (x, f(x), evaluations)."""
+    max_eval = max_iter * 5 // 4 if max_eval is None else max_eval
+    x = x0
+
+    def evaluate_at(xt, d=None):
+        f_t, g_t = value_and_grad(xt)
+        parts = [f_t.reshape(()), g_t.abs().max()]
+        if d is not None:
+            parts.append(g_t.dot(d))
+        vals = torch.stack(parts).tolist()           # the one host read-back of this evaluation
+        if on_eval is not None:
+            on_eval(xt, vals[0])
+        return vals, g_t
+
+    (loss, gmax), g = evaluate_at(x)
+    evals = 1
+    if gmax <= tolerance_grad:
+        return x, loss, evals
+    hist = _History(history_size, x.numel(), x)
+    gamma = 1.0
+    d = t = None
+    gtd_new = None
+    n_iter = 0
+    while n_iter < max_iter:
+        n_iter += 1
+        if n_iter == 1:
+            d = g.neg()
+        else:
+            ys = t * (gtd_new - gtd)                 # y.s = (g_new - g_old).(t d)
+            if ys > 1e-10:
+                y = g - prev_g
+                hist.push(d * t, y)
+                gamma = ys / y.dot(y)                # stays on the device
+            d = hist.direction(g, gamma)
+        prev_g, prev_loss = g, loss
+        gtd, d_norm, g_l1 = torch.stack([g.dot(d), d.abs().max(), g.abs().sum()]).tolist()
+        t = min(1.0, 1.0 / g_l1) * lr if n_iter == 1 else lr
+        if gtd > -tolerance_change:
+            break
+        x_init = x
+
+        def evaluate(step):
+            xt = torch.add(x_init, d, alpha=step)
+            (f_t, gmax_t, gtd_t), g_t = evaluate_at(xt, d)
+            trial[step] = (xt, gmax_t)
+            return f_t, g_t, gtd_t
+
+        trial = {}
+        loss, g, t, ls_evals, gtd_new = _strong_wolfe(evaluate, t, d_norm, loss, g, gtd, tolerance_change=1e-9,
+                                                      max_ls=max_eval - evals)
+        x, gmax = trial[t] if t in trial else (x_init, gmax)       # t == 0: the search returned the starting point
+        evals += ls_evals
+        if n_iter == max_iter or evals >= max_eval:
+            break
+        if gmax <= tolerance_grad:
+            break
+        if d_norm * abs(t) <= tolerance_change:
+            break
+        if abs(loss - prev_loss) < tolerance_change:
+            break
+    return x, loss, evals

@@ -7,7 +7,8 @@ returns the best-loss iterate; its closure re-uploads every 5000-row chunk of K 
 function evaluation. Here the data is reduced ONCE to G = K^T K, P = V^T K, c = sum V^2 (streamed through the MFMA
 Gram kernel, fp64 accumulators) and the same L-BFGS runs on the equivalent Gram-form loss
     L(W) = (tr(W G W^T) - 2 tr(W P^T) + c) / (n * Cout),   dL/dW = 2 (W G - P) / (n * Cout)
-evaluated in fp64 on the device — same optimiser, same hyper-parameters, same best-iterate rule.
+evaluated in fp64 on the device — same algorithm, same hyper-parameters, same best-iterate rule; the optimiser loop is
+mixofshow.utils.lbfgs (torch.optim.LBFGS's iteration without its ~60 device read-backs per iteration).
 """
 import torch
 
@@ -60,13 +61,33 @@ class GramAccumulator:
         self.c += (Y.double()**2).sum()
 
 
-def lbfgs_on_gram(W0, acc, iters):
+def lbfgs_on_gram(W0, acc, iters, solver='lean'):
     """L-BFGS of the reference (gradient_fusion.py:78-85) on the Gram-form loss. W0 (Cout, Cin) any float dtype.
-    Returns the best-loss iterate as fp32 on the CPU (like the reference, :72-74,96)."""
+    Returns the best-loss iterate over all function evaluations as fp32 on the CPU (like the reference, :72-74,96).
+    solver='lean': mixofshow.utils.lbfgs.minimize (same algorithm, two host read-backs per iteration);
+    solver='torch': torch.optim.LBFGS itself (~60 read-backs per iteration) — kept as the yardstick of the tests."""
     dev = acc.G.device
-    W = W0.detach().to(dev, torch.float64).clone().requires_grad_(True)
     nm = float(acc.n) * acc.cout
     best = {'loss': float('inf'), 'W': None}
+    shape = (acc.cout, acc.cin)
+
+    if solver == 'lean':
+        from mixofshow.utils import lbfgs
+
+        def value_and_grad(x):
+            loss, grad = ops.lsq_loss_grad(x.view(shape), acc.G, acc.P, acc.c, nm)
+            return loss, grad.reshape(-1)
+
+        def on_eval(x, lv):
+            if lv < best['loss']:
+                best['loss'], best['W'] = lv, x          # evaluation points are never modified afterwards
+
+        x0 = W0.detach().to(dev, torch.float64).reshape(-1).contiguous().clone()
+        lbfgs.minimize(value_and_grad, x0, iters, history_size=25, lr=1.0, tolerance_grad=1e-16, tolerance_change=1e-16,
+                       on_eval=on_eval)
+        return best['W'].view(shape).to(torch.float32).cpu(), best['loss']
+
+    W = W0.detach().to(dev, torch.float64).clone().requires_grad_(True)
 
     def closure():
         opt.zero_grad()

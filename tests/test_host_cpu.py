@@ -329,6 +329,60 @@ def test_update_quasi_newton_host_logic_vs_reference_golden(emulated_hip, golden
             assert rel < 1e-3, f'{name}: rel dW {rel:.2e}'
 
 
+def test_lean_lbfgs_follows_torch_lbfgs(emulated_hip, golden):
+    """mixofshow.utils.lbfgs.minimize (compact-form direction, host-side strong Wolfe, two read-backs per iteration) is
+    the SAME iteration as torch.optim.LBFGS(lr=1, history 25, strong_wolfe): (a) on the reference's golden layer problems
+    through lbfgs_on_gram both solvers return the same best-loss iterate; (b) on a non-quadratic function the iterates,
+    losses and evaluation counts coincide while rounding has not yet separated the trajectories."""
+    from mixofshow.utils import lbfgs, lsq
+    for name, c in golden['lbfgs'].items():
+        conv = c['W0'].dim() == 4
+        cout, cin = c['W0'].shape[:2]
+        acc = lsq.GramAccumulator(cin, cout, torch.device('cpu'))
+        acc.add(c['X'], c['Y'], exact_fp32=True)
+        Wl, ll = lsq.lbfgs_on_gram(c['W0'].reshape(cout, cin), acc, c['iters'], solver='lean')
+        Wt, lt = lsq.lbfgs_on_gram(c['W0'].reshape(cout, cin), acc, c['iters'], solver='torch')
+        step = (Wt - c['W0'].reshape(cout, cin)).norm()
+        rel = ((Wl - Wt).norm() / step).item()
+        print(f'[parity] lean vs torch L-BFGS [{name}{" conv" if conv else ""}]: best loss {ll:.6e} / {lt:.6e}, |dW|/|W-W0| = {rel:.2e}')
+        assert ll <= lt * (1 + 1e-6) + 1e-30 or abs(ll - lt) <= 1e-9 * max(abs(lt), 1e-12)
+        if name in ('over', 'spatial'):                     # strictly convex: the minimiser is unique
+            assert rel < 1e-5
+
+    def rosen(x):
+        return ((1 - x[:-1])**2).sum() + 100 * ((x[1:] - x[:-1]**2)**2).sum()
+
+    x0 = torch.randn(20, dtype=torch.float64, generator=torch.Generator().manual_seed(0)) * 0.5
+    for iters, hist in ((12, 25), (60, 5), (40, 25)):
+        xr = x0.clone().requires_grad_(True)
+        n_ref = [0]
+
+        def closure():
+            opt.zero_grad()
+            loss = rosen(xr)
+            loss.backward()
+            n_ref[0] += 1
+            return loss
+
+        opt = torch.optim.LBFGS([xr], lr=1, max_iter=iters, history_size=hist, line_search_fn='strong_wolfe',
+                                tolerance_grad=1e-16, tolerance_change=1e-16)
+        opt.step(closure)
+
+        def value_and_grad(x):
+            xx = x.detach().clone().requires_grad_(True)
+            loss = rosen(xx)
+            (g, ) = torch.autograd.grad(loss, xx)
+            return loss.detach(), g
+
+        seen = []
+        x, loss, evals = lbfgs.minimize(value_and_grad, x0.clone(), iters, history_size=hist,
+                                        on_eval=lambda xt, fv: seen.append(fv))
+        rel = ((x - xr.detach()).norm() / (xr.detach() - x0).norm()).item()
+        print(f'[parity] lean vs torch L-BFGS [rosenbrock-20, {iters} iters, history {hist}]: evaluations {evals} / {n_ref[0]}, '
+              f'rel dx {rel:.2e}')
+        assert evals == n_ref[0] == len(seen) and rel < 1e-5 and abs(loss - rosen(xr.detach()).item()) <= 1e-4 * max(1e-12, abs(loss))
+
+
 def test_gram_accumulator_chunks_and_split(emulated_hip):
     """G, P, c are independent of chunking and of the representation of the features (half, fp32-on-a-half-grid,
     general fp32 through the hi+lo split)."""
