@@ -3,6 +3,7 @@ keys and shapes of the published diffusers SD-1.5 checkpoint. No checkpoint exis
 layout is pinned to are: the per-module parameter TOTALS of runwayml/stable-diffusion-v1-5 (UNet 859,520,964; VAE
 83,653,863; CLIP ViT-L/14 text encoder 123,060,480), the tensor counts, and a spot list of (key, shape) pairs spanning
 every block type (taken from the diffusers 0.19 checkpoint index)."""
+import pytest
 import torch
 
 import mos_path  # noqa: F401
@@ -121,3 +122,31 @@ def test_real_checkpoint_directory_roundtrip(tmp_path):
         assert set(a) == set(b)
         for k in a:
             assert torch.equal(a[k].float(), b[k].float()), (name, k)
+
+
+def test_clip_text_tower_equals_transformers_clip_text_model():
+    """The text tower is restated locally (mixofshow/models/clip.py keeps the module paths ED-LoRA checkpoints name);
+    `transformers` IS installed here, so its semantics are pinned against the real thing: same random weights loaded into
+    transformers.CLIPTextModel and into the local model -> identical hidden states (causal mask, quick-GELU MLP, pre-LN
+    blocks, final LayerNorm, learned positions), fp32 on the CPU."""
+    transformers = pytest.importorskip('transformers')
+    from mixofshow.models.clip import CLIPTextModel
+    cfg = transformers.CLIPTextConfig(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=3,
+                                      num_attention_heads=4, max_position_embeddings=77, hidden_act='quick_gelu',
+                                      eos_token_id=999, bos_token_id=998, pad_token_id=1)
+    torch.manual_seed(0)
+    theirs = transformers.CLIPTextModel(cfg).eval()
+    ours = CLIPTextModel(vocab_size=1000, hidden_size=128, num_attention_heads=4, intermediate_size=512,
+                         num_hidden_layers=3, max_position_embeddings=77).eval()
+    sd = {(k if k.startswith('text_model.') else 'text_model.' + k): v for k, v in theirs.state_dict().items()}
+    ours.load_state_dict(sd, strict=True)
+    ids = torch.randint(2, 990, (3, 77), generator=torch.Generator().manual_seed(1))
+    ids[:, 0] = 998
+    ids[0, 10:] = 999
+    ids[1, 40:] = 999
+    ids[2, 76] = 999
+    with torch.no_grad():
+        ref = theirs(input_ids=ids).last_hidden_state
+        got = ours(ids)[0]
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
