@@ -2,24 +2,28 @@
 # Build libmos_hip.so for gfx950 (MI355X). Cross-compiles without a GPU.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="${HERE}/../libmos_hip.so"
+# MOS_OUT / MOS_BUILD_DIR / MOS_ATTN_SRC / MOS_ATTN_FLAGS: kernel-variant builds for same-box A/B runs (load with MOS_HIP_LIB=...)
+OUT="${MOS_OUT:-${HERE}/../libmos_hip.so}"
+BUILD="${MOS_BUILD_DIR:-${HERE}/_build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast"
 SRCS="mos_api mos_gemm mos_attn mos_gram mos_norm mos_elem mos_conv"
-mkdir -p "${HERE}/_build"
+mkdir -p "${BUILD}"
 pids=()
 # mos_attn only: at one wave per SIMD hipcc selects the AccVGPR form of every MFMA and then copies the accumulators the
 # VALU touches (softmax) through v_accvgpr_read/write -- 6..10 copies per MFMA in the d = 80/160 and region kernels.
 # The VGPR form keeps them in arch VGPRs (main-loop VALU count -40 %; region kernels -15..-26 % measured, parity
 # unchanged). Two-wave kernels (d = 40) compile to the same code either way.
-EXTRA_mos_attn="-mllvm -amdgpu-mfma-vgpr-form=1"
+EXTRA_mos_attn="-mllvm -amdgpu-mfma-vgpr-form=1 ${MOS_ATTN_FLAGS:-}"
 for f in ${SRCS}; do
   extra_var="EXTRA_${f}"
-  ( ${HIPCC} ${FLAGS} ${!extra_var:-} -c "${HERE}/${f}.hip" -o "${HERE}/_build/${f}.o" ) &
+  src="${HERE}/${f}.hip"
+  if [ "${f}" = mos_attn ] && [ -n "${MOS_ATTN_SRC:-}" ]; then src="${MOS_ATTN_SRC}"; fi
+  ( ${HIPCC} ${FLAGS} ${!extra_var:-} -I"${HERE}" -c "${src}" -o "${BUILD}/${f}.o" ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
 OBJS=""
-for f in ${SRCS}; do OBJS="${OBJS} ${HERE}/_build/${f}.o"; done
+for f in ${SRCS}; do OBJS="${OBJS} ${BUILD}/${f}.o"; done
 ${HIPCC} --offload-arch=gfx950 -shared -fPIC -o "${OUT}" ${OBJS}
 echo "built ${OUT}"

@@ -224,14 +224,16 @@ struct TrStage {
 // Returns unnormalised O^T accumulators, running max m (raw score units) and PER-LANE partial sums l.
 // LSUM: the caller put a row of ones into row D of the transposed V tiles (a padding row), so accumulator row D of O^T
 // IS the running row sum (rescaled with O^T for free): no per-element adds here, `l` is left untouched.
-template <typename T, int D, int NQ, bool PCOLS, bool LSUM = false>
+// CAUSAL is a template parameter and the ragged last tile is a peeled copy of the loop body (TAIL): as run-time flags
+// both masks were if-converted by hipcc into a compare + select per score element in EVERY tile -- ~350 of the 760
+// instructions of the d = 40 forward loop, for masks the UNet never uses (no causal attention; 4096/1024/256/64 keys).
+template <typename T, int D, int NQ, bool PCOLS, bool LSUM = false, bool CAUSAL = false>
 __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vbase, int64_t v_rs, int Nkv,
                                        float c /* scale*log2e */, T* Ks_, T* Vt_,
                                        const typename MT<T>::v8 (&qf)[NQ][HD<D>::KS],
                                        f32x16 (&o)[NQ][HD<D>::DT], float (&m)[NQ], float (&l)[NQ],
                                        const int (&tok)[MOS_MAX_PCOLS], int n_pcols,
-                                       float (&cap)[NQ][MOS_MAX_PCOLS], int tid, int l31, int hh,
-                                       bool causal = false, int qfirst = 0) {
+                                       float (&cap)[NQ][MOS_MAX_PCOLS], int tid, int l31, int hh, int qfirst = 0) {
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
 #pragma unroll
@@ -259,7 +261,11 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the dK/dV kernel
     int cur = 0;
-    for (int kv0 = 0; kv0 < Nkv; kv0 += KV_TILE, cur ^= 1) {
+    // tail_c: 0 = full tile, 1 = ragged tile (peeled copy), 2 = decided at run time (one body: the PCOLS instantiations --
+    // 77-key cross attention, two tiles, latency-bound -- spill registers with two copies of the body)
+    auto tile = [&](const int kv0, auto tail_c) __attribute__((always_inline)) {
+        constexpr int TM = decltype(tail_c)::value;
+        const bool tail = TM == 2 ? (kv0 + KV_TILE > Nkv) : (TM == 1);
         const T* Ks = Ks_ + cur * HD<D>::ROW_TILE_ELEMS;
         const T* Vt = Vt_ + cur * HD<D>::TR_TILE_ELEMS;
         const bool more = kv0 + KV_TILE < Nkv;
@@ -283,7 +289,6 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
 #pragma unroll
                 for (int iq = 0; iq < NQ; ++iq) s[iq][t] = MT<T>::mfma32(a, qf[iq][ks], s[iq][t]);
             }
-        const bool tail = (kv0 + KV_TILE > Nkv);
         v8 pf[NQ][2][2];
 #pragma unroll
         for (int iq = 0; iq < NQ; ++iq) {
@@ -294,7 +299,7 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
                     for (int r = 0; r < 16; ++r)
                         if (kv0 + 32 * t + acc_row(r, hh) >= Nkv) s[iq][t][r] = NEG_BIG;
             }
-            if (causal) {       // wave-uniform flag; this lane's query of sub-tile iq is qfirst + 32*iq + l31
+            if constexpr (CAUSAL) {       // this lane's query of sub-tile iq is qfirst + 32*iq + l31
                 const int qidx = qfirst + 32 * iq + l31;
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -360,6 +365,14 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
             vst.store(Vt_ + (cur ^ 1) * HD<D>::TR_TILE_ELEMS, tid);
         }
         __syncthreads();  // tile i+1 visible; every wave is done reading tile i before it is overwritten next round
+        cur ^= 1;
+    };
+    int kv0 = 0;
+    if constexpr (PCOLS) {
+        for (; kv0 < Nkv; kv0 += KV_TILE) tile(kv0, std::integral_constant<int, 2>{});
+    } else {
+        for (; kv0 + KV_TILE <= Nkv; kv0 += KV_TILE) tile(kv0, std::integral_constant<int, 0>{});
+        if (kv0 < Nkv) tile(kv0, std::integral_constant<int, 1>{});
     }
 }
 
@@ -378,7 +391,7 @@ __device__ __forceinline__ void store_out_rows(T* orow, bool valid, const f32x16
 }
 
 // ---- forward -----------------------------------------------------------------------------------
-template <typename T, int D, int QW, bool PCOLS>
+template <typename T, int D, int QW, bool PCOLS, bool CAUSAL = false>
 __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) void attn_fwd_kernel(AttnArgs a) {
     typedef typename MT<T>::v8 v8;
     constexpr int NQ = QW / 32;
@@ -426,8 +439,8 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
     f32x16 o[NQ][HD<D>::DT];
     float m[NQ], l[NQ];
     const float c = a.scale * LOG2E;
-    attend<T, D, NQ, PCOLS, LSUM>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, a.n_pcols, cap, tid, l31,
-                                  hh, a.causal != 0, q0);
+    attend<T, D, NQ, PCOLS, LSUM, CAUSAL>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, a.n_pcols, cap, tid,
+                                          l31, hh, q0);
 
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
@@ -459,31 +472,94 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
 }
 
 // ---- regional cross-attention: sum over covering sources of attention / count ---------------------
+// One LDS residency per pass: the K rows and the transposed V of up to NSP sources (context prompt + regions, 65..96
+// keys each: CLIP's 77-token context in three 32-key sub-tiles) are staged together -- every global load of the pass is in
+// flight at once, ONE barrier, then each wave walks only the sources that cover one of ITS 32 queries, with no further
+// block-wide synchronisation (the previous kernel walked the sources serially: a full memory round trip, two 64-key
+// tiles and three barriers per source, and a block-wide vote before each).
+//   * softmax over all keys of a source at once (no running max / rescale);
+//   * keys >= Nkv: their K rows are zeros (buffer bounds check) and the S^T accumulator of the last sub-tile starts from a
+//     bias of -1e30 for those rows (the C operand of its first MFMA) -> exp2 gives exactly 0 without a compare/select;
+//   * d = 40 / 80: row sums from the P.V MFMA (ones row D of V^T), out += O * w/l;  d = 160 / 64 (no spare V^T row):
+//     probabilities are normalised and weighted BEFORE P.V, which then accumulates straight into the output;
+//   * only the V^T rows that produce kept output rows are staged (D, + the ones row): the A-operand reads of the MFMA row
+//     padding run into the next image (the K images sit behind the V^T images) and feed output rows nobody stores.
+template <int D> struct RG {
+    static constexpr int KEYS = 96;
+    static constexpr int TS3 = KEYS + 8;                        // 104 el = 13 x 16 B: odd -> conflict-free b128 reads
+    static constexpr bool PRENORM = HD<D>::DV == D;
+    static constexpr int VR = PRENORM ? D : D + 1;
+    static constexpr int K_ELEMS = KEYS * HD<D>::RS;
+    static constexpr int V_ELEMS = VR * TS3;
+    static constexpr int NSP = D <= 40 ? 4 : D <= 80 ? 2 : 1;   // sources resident per pass (<= 77 KB: two blocks per CU)
+    static constexpr bool PREFETCH = NSP < 4;                   // next pass's loads fly under this pass's MFMAs
+    static constexpr int NK = (KEYS * HD<D>::DCH + 255) / 256;  // 16-byte chunks per thread: K rows
+    static constexpr int NV = (KEYS / 2 * HD<D>::DCH + 255) / 256;   // row PAIRS x chunks per thread: V
+    static constexpr size_t lds_bytes(size_t es) { return (size_t)NSP * (K_ELEMS + V_ELEMS) * es + 16; }
+};
+
 template <typename T, int D>
-__global__ __launch_bounds__(256) void region_attn_kernel(AttnArgs a, mos_region_desc reg) {
+struct RegionStage {     // registers of one source in flight
+    u32x4 k[RG<D>::NK], v0[RG<D>::NV], v1[RG<D>::NV];
+};
+
+template <typename T, int D>
+__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(AttnArgs a, mos_region_desc reg) {
     typedef typename MT<T>::v8 v8;
-    constexpr int DT = HD<D>::DT;
+    typedef RG<D> G;
+    constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS, DCH = HD<D>::DCH, TS3 = G::TS3, NSP = G::NSP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Ks = reinterpret_cast<T*>(smem_raw);
-    T* Vt = Ks + 2 * HD<D>::ROW_TILE_ELEMS;
+    T* Vt_ = reinterpret_cast<T*>(smem_raw);                  // [NSP] V^T images, then [NSP] K images, then the need word
+    T* Ks_ = Vt_ + NSP * G::V_ELEMS;
+    unsigned* need_w = reinterpret_cast<unsigned*>(Ks_ + NSP * G::K_ELEMS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int h = blockIdx.x % a.H;
     const int rest = blockIdx.x / a.H;
     const int qb = rest % a.nqb, b = rest / a.nqb;
     const int qi = qb * 128 + wave * 32 + l31;
+    const int S = reg.n_regions + 1;
 
-    zero_row_pads<T, D>(Ks, tid); zero_row_pads<T, D>(Ks + HD<D>::ROW_TILE_ELEMS, tid);
-    zero_tr_pads<T, D>(Vt, tid); zero_tr_pads<T, D>(Vt + HD<D>::TR_TILE_ELEMS, tid);
+    // ---- which sources does this lane / wave / block use ------------------------------------------------------------
+    const int y = qi / reg.feat_w, x = qi - y * reg.feat_w;
+    unsigned inbits = 0;
+    int cnt = 0;
+    for (int r = 0; r < reg.n_regions; ++r) {
+        const bool in = (y >= reg.box[r][0] && y < reg.box[r][2] && x >= reg.box[r][1] && x < reg.box[r][3]);
+        inbits |= in ? (2u << r) : 0u;
+        cnt += in ? 1 : 0;
+    }
+    if (cnt == 0) inbits = 1u;
+    if (qi >= a.Nq) inbits = 0u;
+    const float wreg = cnt > 0 ? 1.f / (float)cnt : 1.f;      // weight of every source this query uses
+    unsigned wave_need = 0;
+    for (int j = 0; j < S; ++j) wave_need |= (__ballot((inbits >> j) & 1u) != 0ull) ? (1u << j) : 0u;
+    if (tid == 0) *need_w = 0u;
+    // constant parts of the images: K pad columns [D, DK) = 0, V^T ones row (row sums), for every resident slot
+    for (int sl = 0; sl < NSP; ++sl) {
+        T* Ki = Ks_ + sl * G::K_ELEMS;
+        if constexpr (HD<D>::DK > D) {
+            constexpr int PC = (HD<D>::DK - D) / 8;
+            for (int c = tid; c < G::KEYS * PC; c += 256) st16(Ki + (c / PC) * RS + D + (c % PC) * 8, u32x4{0, 0, 0, 0});
+        }
+        if constexpr (!G::PRENORM) {
+            T* ones = Vt_ + sl * G::V_ELEMS + D * TS3;
+            if (tid < G::KEYS) ones[tid] = (T)1.0f;
+        }
+    }
+    __syncthreads();
+    if (lane == 0 && wave_need) atomicOr(need_w, wave_need);
+    __syncthreads();
+    unsigned need = __builtin_amdgcn_readfirstlane(*need_w);    // block-uniform
 
     const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
     T* op = (T*)a.o + (int64_t)b * a.o_bs + h * D;
-    v8 qf[1][HD<D>::KS];
-    load_row_frags<T, D>(qf[0], qp + (int64_t)min(qi, a.Nq - 1) * a.q_rs, qi < a.Nq, hh);
+    v8 qf[KS];
+    load_row_frags<T, D>(qf, qp + (int64_t)min(qi, a.Nq - 1) * a.q_rs, qi < a.Nq, hh);
 
-    const int y = qi / reg.feat_w, x = qi - y * reg.feat_w;
-    int cnt = 0;
-    for (int r = 0; r < reg.n_regions; ++r)
-        cnt += (y >= reg.box[r][0] && y < reg.box[r][2] && x >= reg.box[r][1] && x < reg.box[r][3]) ? 1 : 0;
+    // bias of the last key sub-tile (keys 64..95): -1e30 on the accumulator rows whose key is past Nkv
+    f32x16 bias2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias2[r] = (64 + acc_row(r, hh) >= a.Nkv) ? NEG_BIG : 0.f;
 
     f32x16 fin[DT];
 #pragma unroll
@@ -491,31 +567,190 @@ __global__ __launch_bounds__(256) void region_attn_kernel(AttnArgs a, mos_region
 #pragma unroll
         for (int r = 0; r < 16; ++r) fin[dt][r] = 0.f;
     const float c = a.scale * LOG2E;
-    int tok[MOS_MAX_PCOLS] = {-1, -1, -1, -1};
-    float cap[1][MOS_MAX_PCOLS];
 
-    for (int src = 0; src <= reg.n_regions; ++src) {
-        float w;
-        if (src == 0) {
-            w = (cnt == 0) ? 1.f : 0.f;
-        } else {
-            const int r = src - 1;
-            const bool in = (y >= reg.box[r][0] && y < reg.box[r][2] && x >= reg.box[r][1] && x < reg.box[r][3]);
-            w = in ? 1.f / (float)cnt : 0.f;
+    // ---- staging --------------------------------------------------------------------------------------------------
+    const uint32_t kbytes = slice_bytes<T, D>(a.Nkv, a.k_rs), vbytes = slice_bytes<T, D>(a.Nkv, a.v_rs);
+    auto load_src = [&](RegionStage<T, D>& st, int src) __attribute__((always_inline)) {
+        const rsrc_t ksrc = make_rsrc((const T*)a.k + (int64_t)src * reg.src_stride + (int64_t)b * a.k_bs + h * D, kbytes);
+        const rsrc_t vsrc = make_rsrc((const T*)a.v + (int64_t)src * reg.src_stride + (int64_t)b * a.v_bs + h * D, vbytes);
+#pragma unroll
+        for (int i = 0; i < G::NK; ++i) {
+            const int cc = min(tid + 256 * i, G::KEYS * DCH - 1);
+            const int row = cc / DCH, ch = cc - row * DCH;
+            st.k[i] = ldbuf16(ksrc, (row * (int)a.k_rs + ch * 8) * (int)sizeof(T));
         }
-        if (qi >= a.Nq) w = 0.f;
-        if (!__syncthreads_or(w != 0.f)) continue;  // block-uniform: no query of this block uses src
-        const T* kp = (const T*)a.k + (int64_t)src * reg.src_stride + (int64_t)b * a.k_bs + h * D;
-        const T* vp = (const T*)a.v + (int64_t)src * reg.src_stride + (int64_t)b * a.v_bs + h * D;
-        f32x16 o[1][DT];
-        float m[1], l[1];
-        attend<T, D, 1, false>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, 0, cap, tid, l31, hh);
-        const float lt = l[0] + __shfl_xor(l[0], 32);
-        const float mul = w / lt;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int i = 0; i < G::NV; ++i) {
+            const int it = min(tid + 256 * i, G::KEYS / 2 * DCH - 1);
+            const int pr = it % (G::KEYS / 2), ch = it / (G::KEYS / 2);
+            const int off = (2 * pr * (int)a.v_rs + ch * 8) * (int)sizeof(T);
+            st.v0[i] = ldbuf16(vsrc, off);
+            st.v1[i] = ldbuf16(vsrc, off + (int)a.v_rs * (int)sizeof(T));
+        }
+    };
+    auto store_src = [&](const RegionStage<T, D>& st, int slot) __attribute__((always_inline)) {
+        T* Ki = Ks_ + slot * G::K_ELEMS;
+        T* Vi = Vt_ + slot * G::V_ELEMS;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) fin[dt][r] += o[0][dt][r] * mul;
+        for (int i = 0; i < G::NK; ++i) {
+            const int cc = tid + 256 * i;
+            const int row = cc / DCH, ch = cc - row * DCH;
+            if (G::NK * 256 <= G::KEYS * DCH || cc < G::KEYS * DCH) st16(Ki + row * RS + ch * 8, st.k[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < G::NV; ++i) {
+            const int it = tid + 256 * i;
+            const int pr = it % (G::KEYS / 2), ch = it / (G::KEYS / 2);
+            if (G::NV * 256 <= G::KEYS / 2 * DCH || it < G::KEYS / 2 * DCH) {
+                uint32_t* dst = reinterpret_cast<uint32_t*>(Vi + (ch * 8) * TS3 + tr_col(2 * pr));
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {     // word e = {row 2p+1 elem e (high half), row 2p elem e (low half)}
+                    dst[(2 * w) * (TS3 / 2)] = __builtin_amdgcn_perm(st.v1[i][w], st.v0[i][w], 0x05040100u);
+                    dst[(2 * w + 1) * (TS3 / 2)] = __builtin_amdgcn_perm(st.v1[i][w], st.v0[i][w], 0x07060302u);
+                }
+            }
+        }
+    };
+    // ---- one source of the resident pass, for this wave's 32 queries ------------------------------------------------
+    auto attend_src = [&](int slot, int src) __attribute__((always_inline)) {
+        const T* Ki = Ks_ + slot * G::K_ELEMS;
+        const T* Vi = Vt_ + slot * G::V_ELEMS;
+        f32x16 sT[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v8 af = as_v8<T>(ld16(Ki + (32 * t + l31) * RS + ks * 16 + hh * 8));
+                if (ks == 0) {
+                    if (t == 2) sT[t] = MT<T>::mfma32(af, qf[ks], bias2);
+                    else {
+                        f32x16 z;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        sT[t] = MT<T>::mfma32(af, qf[ks], z);
+                    }
+                } else {
+                    sT[t] = MT<T>::mfma32(af, qf[ks], sT[t]);
+                }
+            }
+        }
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mc = mx * c;
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pexp = __builtin_amdgcn_exp2f(sT[t][r] * c - mc);
+                sT[t][r] = pexp;
+                if constexpr (G::PRENORM) ls += pexp;
+            }
+        const float w = ((inbits >> src) & 1u) ? wreg : 0.f;
+        if constexpr (G::PRENORM) {
+            ls += __shfl_xor(ls, 32);
+            const float mul = w / ls;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sT[t][r] *= mul;
+        }
+        v8 pf[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) pf[t][s2] = acc_to_bfrag<T>(sT[t], s2);
+        f32x16 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const T* vrow = Vi + (32 * dt + l31) * TS3;
+            bool first = true;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (t == 2 && s2 == 1 && a.Nkv <= 80) continue;   // keys 80..95: all past Nkv (wave-uniform)
+                    const v8 af = tr_afrag<T>(vrow, t, s2, hh);
+                    if constexpr (G::PRENORM) {
+                        fin[dt] = MT<T>::mfma32(af, pf[t][s2], fin[dt]);
+                    } else {
+                        if (first) {
+                            f32x16 z;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                            o[dt] = MT<T>::mfma32(af, pf[t][s2], z);
+                            first = false;
+                        } else {
+                            o[dt] = MT<T>::mfma32(af, pf[t][s2], o[dt]);
+                        }
+                    }
+                }
+        }
+        if constexpr (!G::PRENORM) {
+            constexpr int RL = (D % 32) / 8 * 4;      // accumulator row D (the ones row) = register RL of the hh = 0 lanes
+            static_assert(G::PRENORM || ((D % 32) % 8 == 0 && D % 32 != 0), "ones row must sit in a register of hh = 0");
+            const float lt = __shfl(o[D / 32][RL], l31);
+            const float mul = w / lt;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fin[dt][r] += o[dt][r] * mul;
+        }
+    };
+
+    // ---- passes over the sources this block needs, NSP at a time ----------------------------------------------------
+    RegionStage<T, D> stg[NSP];
+    int cur_src[NSP], nxt_src[NSP];
+    auto take = [&](int (&dst)[NSP]) __attribute__((always_inline)) {      // pop the next <= NSP needed sources
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < NSP; ++i) {
+            dst[i] = -1;
+            if (need) { dst[i] = __builtin_ctz(need); need &= need - 1; ++n; }
+        }
+        return n;
+    };
+    int ncur = take(cur_src);
+#pragma unroll
+    for (int i = 0; i < NSP; ++i)
+        if (cur_src[i] >= 0) load_src(stg[i], cur_src[i]);
+#pragma unroll
+    for (int i = 0; i < NSP; ++i)
+        if (cur_src[i] >= 0) store_src(stg[i], i);
+    __syncthreads();
+    while (ncur > 0) {
+        int nnxt = 0;
+        if constexpr (G::PREFETCH) {
+            nnxt = take(nxt_src);
+#pragma unroll
+            for (int i = 0; i < NSP; ++i)
+                if (nxt_src[i] >= 0) load_src(stg[i], nxt_src[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NSP; ++i)
+            if (cur_src[i] >= 0 && ((wave_need >> cur_src[i]) & 1u)) attend_src(i, cur_src[i]);
+        if constexpr (!G::PREFETCH) {
+            nnxt = take(nxt_src);
+            if (nnxt > 0) {
+#pragma unroll
+                for (int i = 0; i < NSP; ++i)
+                    if (nxt_src[i] >= 0) load_src(stg[i], nxt_src[i]);
+            }
+        }
+        if (nnxt > 0) {
+            __syncthreads();          // every wave is done reading the resident images
+#pragma unroll
+            for (int i = 0; i < NSP; ++i)
+                if (nxt_src[i] >= 0) store_src(stg[i], i);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < NSP; ++i) cur_src[i] = nxt_src[i];
+        ncur = nnxt;
     }
     store_out_rows<T, D>(op + (int64_t)qi * a.o_rs, qi < a.Nq, fin, 1.0f, hh);
 }
@@ -553,8 +788,9 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, int64_t o_bs, int6
 // NW waves per block share each staged K / V / K^T tile. NW = 8 (512 threads, two blocks per CU = 4 waves per
 // SIMD): a wave's MFMA -> exp/VALU -> MFMA phases are serialised by data dependence, so the pipes only overlap across
 // waves; the kernels need < 128 VGPRs at d = 40, and the per-tile staging cost is shared by twice as many rows.
-template <typename T, int D, bool PCOLS, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MOS_DQ_OCC : D <= 80 ? 2 : 1))) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+template <typename T, int D, bool PCOLS, int NW, bool CAUSAL = false>
+__global__ __launch_bounds__(64 * NW, (D <= 40 ? MOS_DQ_OCC : (D <= 80 && !PCOLS) ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs a) {
+    // (d = 80 with exported probability columns -- 77-key cross attention, latency-bound -- spilled at two waves per SIMD)
     constexpr int NT = 64 * NW;
     constexpr bool PIN = D <= 80 && NW == 4;   // explicit fragment prefetch where the registers allow it
     typedef typename MT<T>::v8 v8;
@@ -620,11 +856,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MO
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the dK/dV kernel
     int cur = 0;
-    for (int kv0 = 0; kv0 < a.Nkv; kv0 += KV_TILE, cur ^= 1) {
+    f32x16 negD16;      // -D of this lane's query in all 16 rows: the C operand of the first dP MFMA of every half tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negD16[r] = -Dq;
+    // ragged last key tile = peeled copy of the body (TAIL), causal mask = template parameter: see attend()
+    auto tile = [&](const int kv0, auto tail_c) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(tail_c)::value;
         const T* Ks = Ks_ + cur * RT;
         const T* Vs = Vs_ + cur * RT;
         const T* Kt = Kt_ + cur * TT;
-        const bool more = kv0 + KV_TILE < a.Nkv;
+        const bool more = !TAIL && kv0 + KV_TILE < a.Nkv;
         if (more) {  // prefetch the next key tile into registers; written to the other LDS buffer after the MFMAs
             const int nt = kv0 / KV_TILE + 1;
             vst.load(vsrc, nt * v_tile_bytes);
@@ -649,20 +890,21 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MO
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) tk[dt][s2] = tr_afrag<T>(Kt + (32 * dt + l31) * TS, t, s2, hh);
             if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
+            // dP accumulates on top of -D (this lane's query): the MFMA does the subtraction of dS = P o (dP - D)
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s = MT<T>::mfma32(ak[ks], qf[ks], s);
-                dp = MT<T>::mfma32(av[ks], dof[ks], dp);
+                dp = MT<T>::mfma32(av[ks], dof[ks], ks == 0 ? negD16 : dp);
             }
-            if (kv0 + KV_TILE > a.Nkv) {  // ragged last tile only (wave-uniform): keys past Nkv get probability 0
+            if constexpr (TAIL) {  // ragged last tile only: keys past Nkv get probability 0
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kv0 + 32 * t + acc_row(r, hh) >= a.Nkv) s[r] = NEG_BIG;
             }
-            if (a.causal) {
+            if constexpr (CAUSAL) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kv0 + 32 * t + acc_row(r, hh) > qi) s[r] = NEG_BIG;
@@ -677,7 +919,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MO
                     for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
                         if (kvi == tok[tt]) g += dpc[tt];
                 }
-                s[r] = p * (g - Dq);
+                s[r] = p * g;
             }
             v8 dsf[2];
             dsf[0] = acc_to_bfrag<T>(s, 0);
@@ -695,15 +937,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? MO
             ktst.store(Kt_ + (cur ^ 1) * TT, tid);
         }
         __syncthreads();
-    }
+        cur ^= 1;
+    };
+    int kv0 = 0;
+    for (; kv0 + KV_TILE <= a.Nkv; kv0 += KV_TILE) tile(kv0, std::false_type{});
+    if (kv0 < a.Nkv) tile(kv0, std::true_type{});
     T* dqp = (T*)a.dq + (int64_t)b * a.dq_bs + (int64_t)qi * a.dq_rs + h * D;
     store_out_rows<T, D>(dqp, qvalid, dq, a.scale, hh);
 }
 
 // ---- backward dK/dV: one wave = 32 keys, loop over query tiles of this split ------------------------
 //   S = Q K^T ; P = exp(scale*S - lse) ; dV^T += dO^T P ; dP = dO V^T ; dS = P o (dP - D) ; dK^T += Q^T dS
-template <typename T, int D, bool PCOLS, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 : 1))) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
+template <typename T, int D, bool PCOLS, int NW, bool CAUSAL = false>
+__global__ __launch_bounds__(64 * NW, (D <= 40 ? 2 : 1)) void attn_bwd_dkdv_kernel(AttnBwdArgs a) {
     constexpr int NT = 64 * NW;
     typedef typename MT<T>::v8 v8;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
@@ -787,7 +1033,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
             float* sb = stat_ + bf * ST;
             const bool ok = tid < st_nv;
             sb[tid] = ok ? st_lse * LOG2E : 0.f;
-            sb[KV_TILE + tid] = ok ? st_D : 0.f;
+            sb[KV_TILE + tid] = ok ? -st_D : 0.f;     // stored negated: it is the initial value of the dP accumulator
             if constexpr (PCOLS) {
 #pragma unroll
                 for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
@@ -821,7 +1067,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
         // alone, hipcc sinks each ds_read next to its consumer (`ds_read; s_waitcnt lgkmcnt(0); v_mfma`), which puts
         // one LDS round trip in front of nearly every MFMA.
         v8 aq[KS], ado[KS];
-        f32x4 l4[4], d4[4];
+        f32x4 l4[4];
+        f32x16 d16;     // -D of this half tile's 16 accumulator rows: the C operand of the first dP MFMA
         auto read_rows = [&](int t) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -833,7 +1080,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int ql = 32 * t + 8 * r4 + 4 * hh;
                 l4[r4] = *reinterpret_cast<const f32x4*>(lse_s + ql);
-                d4[r4] = *reinterpret_cast<const f32x4*>(D_s + ql);
+                const f32x4 dd = *reinterpret_cast<const f32x4*>(D_s + ql);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) d16[4 * r4 + rr] = dd[rr];
             }
         };
         read_rows(0);
@@ -849,13 +1098,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
                     tq[dt][s2] = tr_afrag<T>(Qt + (32 * dt + l31) * TS, t, s2, hh);
                 }
             if constexpr (D <= 80) __builtin_amdgcn_sched_barrier(0);   // d = 160: the fragments would spill
+            // dP accumulates on top of -D (rows = queries: d4 holds exactly this lane's 16 accumulator rows), so the MFMA
+            // does the subtraction of dS = P o (dP - D)
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s = MT<T>::mfma32(aq[ks], kf[ks], s);
-                dp = MT<T>::mfma32(ado[ks], vf[ks], dp);
+                dp = MT<T>::mfma32(ado[ks], vf[ks], ks == 0 ? d16 : dp);
             }
             // accumulator rows are query-local indices 32t + acc_row(r, hh); column = this lane's key
 #pragma unroll
@@ -867,12 +1118,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 ? 4 : NW == 6 ? 3 : (D <= 40 ? 2 
                     // dK^T / dV^T, columns never mix, and the store skips invalid keys
                     float p, g = dp[r];
                     p = __builtin_amdgcn_exp2f(s[r] * c - l4[r4][rr]);
-                    if (a.causal && kvi > q0 + 32 * t + 8 * r4 + 4 * hh + rr) p = 0.f;   // this lane's key vs the row's query
+                    if constexpr (CAUSAL) {
+                        if (kvi > q0 + 32 * t + 8 * r4 + 4 * hh + rr) p = 0.f;   // this lane's key vs the row's query
+                    }
                     if constexpr (PCOLS) {
                         if (mytok >= 0) g += dpc_s[(32 * t + 8 * r4 + 4 * hh + rr) * MOS_MAX_PCOLS + mytok];
                     }
                     s[r] = p;
-                    dp[r] = p * (g - d4[r4][rr]);
+                    dp[r] = p * g;
                 }
             }
             v8 pf[2], dsf[2];
@@ -995,6 +1248,28 @@ struct AttnKey {
     }
 };
 
+// causal masking (the CLIP text tower's d = 64 is the only user on the path; the other head dims keep it for the tests)
+template <int D> constexpr bool has_causal() { return true; }
+
+template <typename T, int D, int QW, bool PCOLS, bool CAUSAL>
+void launch_fwd_one(const AttnArgs& a, size_t lds, hipStream_t st) {
+    const dim3 grid((unsigned)(a.H * a.nqb * a.B));
+    set_lds(&attn_fwd_kernel<T, D, QW, PCOLS, CAUSAL>, lds);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, D, QW, PCOLS, CAUSAL>), grid, dim3(256), lds, st, a);
+}
+template <typename T, int D, int QW>
+void launch_fwd_qw(const AttnArgs& a, int np, size_t lds, hipStream_t st) {
+    if constexpr (has_causal<D>()) {
+        if (a.causal) {
+            if (np > 0) launch_fwd_one<T, D, QW, true, true>(a, lds, st);
+            else launch_fwd_one<T, D, QW, false, true>(a, lds, st);
+            return;
+        }
+    }
+    if (np > 0) launch_fwd_one<T, D, QW, true, false>(a, lds, st);
+    else launch_fwd_one<T, D, QW, false, false>(a, lds, st);
+}
+
 template <typename T, int D>
 int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* tok, int np,
                float* pcols, const mos_attn_shape* s, hipStream_t st) {
@@ -1007,25 +1282,9 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     // not give every CU at least two workgroups.
     const int64_t wg_big = (int64_t)s->H * s->B * ((s->Nq + 4 * QW - 1) / (4 * QW));
     if (QW == 64 && wg_big < 512) {
-        AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 128);
-        const dim3 grid((unsigned)(a.H * a.nqb * a.B));
-        if (np > 0) {
-            set_lds(&attn_fwd_kernel<T, D, 32, true>, lds);
-            hipLaunchKernelGGL((attn_fwd_kernel<T, D, 32, true>), grid, dim3(256), lds, st, a);
-        } else {
-            set_lds(&attn_fwd_kernel<T, D, 32, false>, lds);
-            hipLaunchKernelGGL((attn_fwd_kernel<T, D, 32, false>), grid, dim3(256), lds, st, a);
-        }
-        return mos_check_launch("attn_fwd");
-    }
-    AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 4 * QW);
-    const dim3 grid((unsigned)(a.H * a.nqb * a.B));
-    if (np > 0) {
-        set_lds(&attn_fwd_kernel<T, D, QW, true>, lds);
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, QW, true>), grid, dim3(256), lds, st, a);
+        launch_fwd_qw<T, D, 32>(make_args(q, k, v, o, lse, tok, np, pcols, s, 128), np, lds, st);
     } else {
-        set_lds(&attn_fwd_kernel<T, D, QW, false>, lds);
-        hipLaunchKernelGGL((attn_fwd_kernel<T, D, QW, false>), grid, dim3(256), lds, st, a);
+        launch_fwd_qw<T, D, QW>(make_args(q, k, v, o, lse, tok, np, pcols, s, 4 * QW), np, lds, st);
     }
     return mos_check_launch("attn_fwd");
 }
@@ -1035,7 +1294,7 @@ int launch_region(const void* q, const void* k, const void* v, void* o, const mo
                   const mos_region_desc* reg, hipStream_t st) {
     AttnArgs a = make_args(q, k, v, o, nullptr, nullptr, 0, nullptr, s, 128);
     const dim3 grid((unsigned)(a.H * a.nqb * a.B));
-    const size_t lds = fwd_lds<D>(sizeof(T));
+    const size_t lds = RG<D>::lds_bytes(sizeof(T));
     set_lds(&region_attn_kernel<T, D>, lds);
     // algorithmic work: every query attends to the context OR to its covering regions (box areas)
     double cover = 0.0, area = 0.0;
@@ -1052,15 +1311,12 @@ int launch_region(const void* q, const void* k, const void* v, void* o, const mo
     return mos_check_launch("region_attn");
 }
 
-constexpr int DQ_NW = 4, DKDV_NW = 4;   // waves per block (8-wave dQ blocks measured +47 % slower at d = 40)
 struct BwdPlan { int nw_q, nw_k, nqb, nkb, nsplit, q_per_split; };
-// waves per block of the backward kernels: 8 where the register budget allows four waves per SIMD (d = 40) and the
-// grid still holds >= 512 blocks of 256 rows; 4 otherwise
+// 4 waves per block in both backward kernels (8-wave dQ blocks measured +47 % slower at d = 40)
 BwdPlan plan_bwd(const mos_attn_shape* s) {
     BwdPlan p;
-    const int64_t bh = (int64_t)s->B * s->H;
-    p.nw_q = (s->d == 40 && bh * ((s->Nq + 32 * DQ_NW - 1) / (32 * DQ_NW)) >= 512) ? DQ_NW : 4;
-    p.nw_k = (s->d == 40 && bh * ((s->Nkv + 32 * DKDV_NW - 1) / (32 * DKDV_NW)) >= 512) ? DKDV_NW : 4;
+    p.nw_q = 4;
+    p.nw_k = 4;
     p.nqb = (s->Nq + 32 * p.nw_q - 1) / (32 * p.nw_q);
     p.nkb = (s->Nkv + 32 * p.nw_k - 1) / (32 * p.nw_k);
     const int64_t base = (int64_t)p.nkb * s->B * s->H;
@@ -1109,22 +1365,19 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         const size_t lds = dq_lds<D>(sizeof(T));
         AttnKey key(tname<T>(), s, 3.0);
         MosProfScope prof(st, "attn_bwd_dq", key.s, key.flops, key.bytes * 1.5);
-        constexpr int NWMAX = (D == 40) ? DQ_NW : 4;
-        if (p.nw_q > 4 && NWMAX > 4) {
-            if (pc) {
-                set_lds(&attn_bwd_dq_kernel<T, D, true, NWMAX>, lds);
-                hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true, NWMAX>), grid, dim3(64 * NWMAX), lds, st, a);
-            } else {
-                set_lds(&attn_bwd_dq_kernel<T, D, false, NWMAX>, lds);
-                hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false, NWMAX>), grid, dim3(64 * NWMAX), lds, st, a);
+        auto go = [&](auto pc_c, auto ca_c) {
+            constexpr bool PC = decltype(pc_c)::value, CA = decltype(ca_c)::value;
+            set_lds(&attn_bwd_dq_kernel<T, D, PC, 4, CA>, lds);
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, PC, 4, CA>), grid, dim3(256), lds, st, a);
+        };
+        bool done = false;
+        if constexpr (has_causal<D>()) {
+            if (a.causal) {
+                if (pc) go(std::true_type{}, std::true_type{}); else go(std::false_type{}, std::true_type{});
+                done = true;
             }
-        } else if (pc) {
-            set_lds(&attn_bwd_dq_kernel<T, D, true, 4>, lds);
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, true, 4>), grid, dim3(256), lds, st, a);
-        } else {
-            set_lds(&attn_bwd_dq_kernel<T, D, false, 4>, lds);
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, D, false, 4>), grid, dim3(256), lds, st, a);
         }
+        if (!done) { if (pc) go(std::true_type{}, std::false_type{}); else go(std::false_type{}, std::false_type{}); }
         int rc = mos_check_launch("attn_bwd_dq");
         if (rc) return rc;
     }
@@ -1133,22 +1386,19 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         const size_t lds = dkdv_lds<D>(sizeof(T));
         AttnKey key(tname<T>(), s, 4.0);
         MosProfScope prof(st, "attn_bwd_dkdv", key.s, key.flops, key.bytes * 1.5);
-        constexpr int NWMAX = (D == 40) ? DKDV_NW : 4;
-        if (p.nw_k > 4 && NWMAX > 4) {
-            if (pc) {
-                set_lds(&attn_bwd_dkdv_kernel<T, D, true, NWMAX>, lds);
-                hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true, NWMAX>), grid, dim3(64 * NWMAX), lds, st, a);
-            } else {
-                set_lds(&attn_bwd_dkdv_kernel<T, D, false, NWMAX>, lds);
-                hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, false, NWMAX>), grid, dim3(64 * NWMAX), lds, st, a);
+        auto go = [&](auto pc_c, auto ca_c) {
+            constexpr bool PC = decltype(pc_c)::value, CA = decltype(ca_c)::value;
+            set_lds(&attn_bwd_dkdv_kernel<T, D, PC, 4, CA>, lds);
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, PC, 4, CA>), grid, dim3(256), lds, st, a);
+        };
+        bool done = false;
+        if constexpr (has_causal<D>()) {
+            if (a.causal) {
+                if (pc) go(std::true_type{}, std::true_type{}); else go(std::false_type{}, std::true_type{});
+                done = true;
             }
-        } else if (pc) {
-            set_lds(&attn_bwd_dkdv_kernel<T, D, true, 4>, lds);
-            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, true, 4>), grid, dim3(256), lds, st, a);
-        } else {
-            set_lds(&attn_bwd_dkdv_kernel<T, D, false, 4>, lds);
-            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, false, 4>), grid, dim3(256), lds, st, a);
         }
+        if (!done) { if (pc) go(std::true_type{}, std::false_type{}); else go(std::false_type{}, std::false_type{}); }
         int rc = mos_check_launch("attn_bwd_dkdv");
         if (rc) return rc;
     }
@@ -1237,6 +1487,9 @@ int mos_region_cross_attn_fwd(const void* q, const void* k_src, const void* v_sr
                 reg->n_regions);
     MOS_REQUIRE(reg->feat_h > 0 && reg->feat_w > 0 && reg->feat_h * reg->feat_w == s->Nq,
                 "mos_region_cross_attn_fwd: feat %dx%d != Nq %d", reg->feat_h, reg->feat_w, s->Nq);
+    if (s->Nkv <= 64 || s->Nkv > 96)
+        return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_region_cross_attn_fwd: built for CLIP's 77-token context "
+                             "(65..96 keys per source), got Nkv=%d", s->Nkv);
     hipStream_t st = (hipStream_t)stream;
     MOS_DISPATCH_TD(dtype, s->d, (launch_region<TT, DD>(q, k_src, v_src, o, s, reg, st)));
 }

@@ -4,7 +4,7 @@
 unet/ vae/ text_encoder/ tokenizer/ scheduler/). When the directory exists its safetensors / .bin weights are
 loaded into the local modules (state-dict keys are diffusers-compatible). There is no network and no SD-1.5
 checkpoint in the build/benchmark environment, so `synthetic://<preset>?seed=N` builds seeded random-init
-modules of the same architecture:  sd15 (full size), small (2 UNet levels, GPU-valid head dims), tiny (CPU tests).
+modules of the same architecture:  sd15 (full size), small (2 UNet levels, GPU-valid head dims), tiny / tiny768 (CPU tests).
 """
 import os
 import re
@@ -25,6 +25,12 @@ PRESETS = {
                            cross_attention_dim=64, norm_num_groups=8),
                  clip=dict(hidden_size=64, num_attention_heads=2, intermediate_size=128, num_hidden_layers=1),
                  vae=dict(block_out_channels=(32, 32, 32, 32))),
+    # tiny UNet / VAE, but a 768-wide text tower: the reference's gradient fusion hard-codes 768 (gradient_fusion.py:202),
+    # so its own merge_* functions can run on this preset (tests/golden/make_golden.py fusion)
+    'tiny768': dict(unet=dict(block_out_channels=(32, 64), layers_per_block=1, attention_head_dim=2,
+                              cross_attention_dim=768, norm_num_groups=8),
+                    clip=dict(hidden_size=768, num_attention_heads=12, intermediate_size=128, num_hidden_layers=1),
+                    vae=dict(block_out_channels=(32, 32, 32, 32))),
 }
 
 

@@ -17,7 +17,8 @@ SURVEY.md App. A). Everything else that runs here is the reference's own code:
   gradient_fusion.py                    chunk_compute_mse, update_quasi_newton, merge_lora_into_weight
   regionally_controlable_sampling.py    prepare_text
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [output.pt]            -> reference_golden.pt
+        python tests/golden/make_golden.py fusion [output.pt]     -> reference_fusion_golden.pt (G8, see fusion_golden)
 """
 import importlib.abc
 import importlib.machinery
@@ -97,9 +98,12 @@ def _import_reference():
     sys.meta_path.insert(0, _StubFinder())
     np.Inf = np.inf  # gradient_fusion.py:59 uses np.Inf (removed in numpy 2)
     # only the NAME is needed (type annotation in RegionallyT2IAdapterPipeline.__init__); transformers 5 dropped it
-    sys.path.insert(0, REF)
+    # REF must come BEFORE the repo root: the repo root holds the product's own gradient_fusion.py /
+    # regionally_controlable_sampling.py (same script names as the reference); only `oracle` is taken from the repo
     sys.path.insert(0, REPO)
+    sys.path.insert(0, REF)
     import gradient_fusion as ref_fusion
+    assert ref_fusion.__file__.startswith(REF), ref_fusion.__file__
     # (the transformers module object in sys.modules is swapped during the imports above, so patch it late)
     sys.modules['transformers'].__dict__['CLIPFeatureExtractor'] = type('CLIPFeatureExtractor', (), {})
     import regionally_controlable_sampling as ref_region_cli
@@ -134,7 +138,7 @@ def _attach_lora(ref_edlora, attn, rank, alpha, seed):
     return loras
 
 
-def main():
+def main(out_path=None):
     ref = _import_reference()
     from oracle.attention_shim import Attention as Shim
     out = {}
@@ -291,7 +295,7 @@ def main():
                         merged_te=merged_te)
 
     out['adapter'] = adapter_region_weight_golden()
-    path = os.path.join(HERE, 'reference_golden.pt')
+    path = out_path or os.path.join(HERE, 'reference_golden.pt')
     torch.save(out, path)
     print(f'wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
 
@@ -330,12 +334,168 @@ def adapter_region_weight_golden():
     return dict(height=height, width=width, keypose=kp, sketch=sk, cases=cases, source_lines=(first + 1, last + 1))
 
 
+# =====================================================================================================================
+# G8: gradient fusion feature collection — the reference's OWN merge_text_encoder / merge_kv_in_cross_attention /
+# merge_spatial_attention (gradient_fusion.py:325-457, 460-576, 627-747, with get_hooker :150-167, get_text_feature
+# :183-214, decode_to_latents :579-624) executed on duck-typed local modules: the product's 'tiny768' tokenizer / CLIP /
+# UNet / DPM-Solver classes. Both packages are called `mixofshow`, so the product package is imported a second time under
+# the alias `mosproduct` (source text rewritten on load: every `mixofshow` -> `mosproduct`); the reference keeps the real
+# name. What the reference hands to update_quasi_newton (X, Y, W0 per layer) and what it returns are recorded per layer.
+# =====================================================================================================================
+ALIAS = 'mosproduct'
+PRESET = 'tiny768'      # 768-wide text tower: the reference hard-codes reshape(-1, 768) (:202)
+
+
+class _AliasLoader(importlib.machinery.SourceFileLoader):
+
+    def get_code(self, fullname):
+        path = self.get_filename(fullname)
+        with open(path, 'rb') as f:
+            src = f.read().decode().replace('mixofshow', ALIAS).replace('import mos_path', 'pass')
+        return compile(src, path, 'exec', dont_inherit=True)
+
+
+class _AliasFinder(importlib.abc.MetaPathFinder):
+    """mosproduct[.a.b] -> mix-of-show_amd/mixofshow/a/b ; mosproduct_root.<script> -> <repo>/<script>.py"""
+
+    def find_spec(self, fullname, path, target=None):
+        import importlib.util
+        parts = fullname.split('.')
+        if parts[0] == ALIAS:
+            base = os.path.join(REPO, 'mix-of-show_amd', 'mixofshow', *parts[1:])
+        elif parts[0] == ALIAS + '_root':
+            base = os.path.join(REPO, *parts[1:]) if len(parts) > 1 else REPO
+        else:
+            return None
+        if os.path.isdir(base):
+            init = os.path.join(base, '__init__.py')
+            if os.path.exists(init):
+                return importlib.util.spec_from_file_location(fullname, init, loader=_AliasLoader(fullname, init),
+                                                              submodule_search_locations=[base])
+            return importlib.machinery.ModuleSpec(fullname, None, is_package=True)     # namespace (repo root)
+        if os.path.exists(base + '.py'):
+            return importlib.util.spec_from_file_location(fullname, base + '.py', loader=_AliasLoader(fullname, base + '.py'))
+        return None
+
+
+def fusion_golden(out_path=None, iters_te=30, iters_unet=12):
+    import importlib
+    import logging
+    import pathlib
+    import re
+    import tempfile
+    ref = _import_reference()
+    rf = ref['fusion']
+    sys.dont_write_bytecode = True
+    sys.meta_path.insert(0, _AliasFinder())
+    os.environ['MOS_TEST_ALLOW_CPU'] = '1'
+    from oracle import emu_ops
+    pops = importlib.import_module(ALIAS + '.hip.ops')
+    for name in emu_ops.EMULATED:                       # same CPU stand-ins for the kernel library as tests/conftest.py
+        setattr(pops, name, getattr(emu_ops, name))
+    pgf = importlib.import_module(ALIAS + '_root.gradient_fusion')
+    pbench = importlib.import_module(ALIAS + '_root.bench')
+    spec = importlib.util.spec_from_file_location('fusion_fixture', os.path.join(HERE, 'fusion_fixture.py'))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    dev = torch.device('cpu')
+    out = dict(preset=PRESET, n_concepts=2, iters_te=iters_te, iters_unet=iters_unet, seed_spatial=77, stages={})
+    with tempfile.TemporaryDirectory() as td:
+        cfg = fx.make_fusion_fixture(pathlib.Path(td), PRESET, 2, build_trainer=pbench.build_trainer)
+        pipe, _, sched = pgf.init_stable_diffusion(f'synthetic://{PRESET}?seed=0', dev)
+        for p_ in list(pipe.text_encoder.parameters()) + list(pipe.unet.parameters()):
+            p_.requires_grad = False
+        # the layers the reference leaves on diffusers' default AttnProcessor (every attn1: revise_edlora_unet_attention_forward
+        # only replaces attn2, edlora.py:176-190) get the restatement of that default processor (oracle/edlora_ref.py), so
+        # that to_q / to_k / to_v / to_out run as module calls and the reference's hooks fire as they do under diffusers
+        from oracle.edlora_ref import PlainAttnProcessorRef
+        for m_ in pipe.unet.modules():
+            if m_.__class__.__name__ == 'Attention':
+                m_.set_processor(PlainAttnProcessorRef())
+        emb, te, kv, sp, concepts = rf.parse_new_concepts(cfg)                                   # reference :269-322
+        _, new_cfg = rf.merge_new_concepts_(emb, concepts, pipe.tokenizer, pipe.text_encoder)    # reference :217-266
+        out['new_concept_cfg'] = new_cfg
+        current = {}
+        calls = []
+        real_uqn, real_info = rf.update_quasi_newton, logging.info
+
+        def info(msg, *a, **k):
+            m = re.search(r'optimizing (\S+)', str(msg))
+            if m:
+                current['name'] = m.group(1)
+
+        def spy(K_target, V_target, W, iters, device):
+            W0 = W.detach().clone()                 # (the reference's L-BFGS updates the tensor it is given in place)
+            Wn = real_uqn(K_target, V_target, W, iters, device)
+            calls.append(dict(name=current['name'], X=K_target.detach().clone(), Y=V_target.detach().clone(), W0=W0,
+                              W=Wn.detach().clone(), loss0=rf.chunk_compute_mse(K_target, V_target, W0, device).item()
+                              if W0.dim() == 2 else None,
+                              loss=rf.chunk_compute_mse(K_target, V_target, Wn, device).item() if W0.dim() == 2 else None))
+            return Wn
+
+        rf.update_quasi_newton, logging.info = spy, info
+        try:
+            def compact(t):      # fp16 storage where it is lossless (features recorded from the fp16 models)
+                h = t.half()
+                return h if torch.equal(h.float(), t.float()) else t
+
+            def record(stage):
+                """Per layer: n and the Gram statistics G = X^T X, P = Y^T X, c = sum Y^2 (fp64) of what the reference handed to
+                update_quasi_newton; the raw X / Y where they are small (768-wide layers: few rows) INSTEAD of G / P; the
+                reference's loss before / after its L-BFGS; its fused weight where that is small."""
+                layers, seen = {}, []
+                for c in sorted(calls, key=lambda c_: c_['name']):     # (the reference iterates a set: order varies per run)
+                    X, Y = c['X'], c['Y']
+                    if X.dim() == 4:
+                        X2, Y2 = X.permute(0, 2, 3, 1).reshape(-1, X.shape[1]).double(), Y.permute(0, 2, 3, 1).reshape(-1, Y.shape[1]).double()
+                    else:
+                        X2, Y2 = X.reshape(-1, X.shape[-1]).double(), Y.reshape(-1, Y.shape[-1]).double()
+                    ent = dict(n=X2.shape[0], c=(Y2 * Y2).sum(), x_shape=tuple(X.shape), y_shape=tuple(Y.shape),
+                               loss0=c['loss0'], loss=c['loss'], dW_norm=(c['W'] - c['W0']).norm().item(),
+                               W0_norm=c['W0'].norm().item())
+                    if X.numel() + Y.numel() <= 1_000_000:
+                        same = next((nm for nm, t in seen if t.shape == X.shape and torch.equal(t, X)), None)
+                        ent.update(X=('same_as', same) if same else compact(X), Y=compact(Y))
+                        if same is None:
+                            seen.append((c['name'], X))
+                    else:
+                        ent.update(G=X2.T @ X2, P=Y2.T @ X2)
+                    if c['W'].numel() <= 65536:
+                        ent.update(W=c['W'])
+                    layers[c['name']] = ent
+                out['stages'][stage] = layers
+                calls.clear()
+
+            # every stage starts from the PRETRAINED weights (compose_concepts chains them, :766-797; unchained, a stage's
+            # features do not depend on the previous stage's solver, so each pins the feature collection on its own)
+            te0 = {k: v.detach().clone() for k, v in pipe.text_encoder.state_dict().items()}
+            u0 = {k: v.detach().clone() for k, v in pipe.unet.state_dict().items()}
+            rf.merge_text_encoder(concepts, iters_te, new_cfg, pipe.tokenizer, pipe.text_encoder, te, dev)
+            record('text_encoder')
+            pipe.text_encoder.load_state_dict(te0)      # (the reference leaves the LAST concept's merged weights loaded)
+            rf.merge_kv_in_cross_attention(concepts, iters_te, new_cfg, pipe.tokenizer, pipe.text_encoder, pipe.unet, kv, dev)
+            record('cross_kv')
+            pipe.unet.load_state_dict(u0)
+            torch.manual_seed(77)                   # decode_to_latents draws the latents from the global generator (:601)
+            rf.merge_spatial_attention(concepts, iters_unet, new_cfg, pipe.tokenizer, pipe.text_encoder, pipe.unet, sp,
+                                       sched, dev)
+            record('spatial')
+        finally:
+            rf.update_quasi_newton, logging.info = real_uqn, real_info
+    path = out_path or os.path.join(HERE, 'reference_fusion_golden.pt')
+    torch.save(out, path)
+    n = {k: len(v) for k, v in out['stages'].items()}
+    print(f'wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); layers per stage: {n}')
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'adapter':      # add G7 to the existing fixture without touching the rest
+    if len(sys.argv) > 1 and sys.argv[1] == 'fusion':
+        fusion_golden(sys.argv[2] if len(sys.argv) > 2 else None)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'adapter':      # add G7 to the existing fixture without touching the rest
         path = os.path.join(HERE, 'reference_golden.pt')
         out = torch.load(path, weights_only=False)
         out['adapter'] = adapter_region_weight_golden()
         torch.save(out, path)
         print('added adapter golden; reference source lines', out['adapter']['source_lines'])
     else:
-        main()
+        main(sys.argv[1] if len(sys.argv) > 1 else None)      # optional output path (tests regenerate into tmp_path)

@@ -75,26 +75,13 @@ def test_compose_concepts_end_to_end(emulated_hip, tmp_path):
 
 # ---- F2 / F3: product feature collection + fused weights against the oracle's restatement of the reference -------
 def make_fusion_fixture(tmp_path, preset, n_concepts=2, up_std=0.02):
-    """Synthetic ED-LoRA checkpoints (SURVEY 8d cfg #4 recipe: seeds 0.., lora_up ~ N(0, 0.02^2), alphas 1.0)."""
-    from bench import build_trainer
-    names = [('<potter1>', '<potter2>'), ('<thanos1>', '<thanos2>'), ('<hermione1>', '<hermione2>')][:n_concepts]
-    ckpts = []
-    for i, (a, b) in enumerate(names):
-        tr = build_trainer(preset, torch.device('cpu'), seed=i)
-        torch.manual_seed(100 + i)
-        with torch.no_grad():
-            for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
-                l.lora_up.weight.normal_(0, up_std)
-            tr.concept_embedding.add_(torch.randn_like(tr.concept_embedding) * 0.01)
-        d = tr.delta_state_dict()
-        d['new_concept_embedding'] = {a: d['new_concept_embedding']['<potter1>'], b: d['new_concept_embedding']['<potter2>']}
-        p = str(tmp_path / f'c{i}.pth')
-        torch.save({'params': d}, p)
-        ckpts.append(dict(lora_path=p, unet_alpha=1.0 - 0.2 * i, text_encoder_alpha=0.9, concept_name=f'{a} {b}'))
-    cfg = str(tmp_path / 'fuse.json')
-    with open(cfg, 'w') as f:
-        json.dump(ckpts, f)
-    return cfg
+    """Synthetic ED-LoRA checkpoints (tests/golden/fusion_fixture.py: the same recipe the reference golden G8 was made with)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'fusion_fixture', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fusion_fixture.py'))
+    fx = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fx)
+    return fx.make_fusion_fixture(tmp_path, preset, n_concepts, up_std)
 
 
 def run_product_and_oracle_fusion(cfg, preset, device, iters_te, iters_unet, monkeypatch):
@@ -259,3 +246,102 @@ def test_product_merge_lora_into_weight_vs_reference_golden(golden):
         up = dn.replace('lora_down', 'lora_up')
         want = sd16[k] if up not in m['te_lora'] else (sd16[k] + m['te_alpha'] * m['te_lora'][up] @ m['te_lora'][dn]).half()
         assert torch.equal(got[k].half(), want), k
+
+
+# ---- F2 pinned by the reference itself: golden G8 = the reference's OWN merge_* functions on the 'tiny768' modules -------
+def _gram(X, Y):
+    X = X.double().reshape(-1, X.shape[-1]) if X.dim() != 4 else X.double().permute(0, 2, 3, 1).reshape(-1, X.shape[1])
+    Y = Y.double().reshape(-1, Y.shape[-1]) if Y.dim() != 4 else Y.double().permute(0, 2, 3, 1).reshape(-1, Y.shape[1])
+    return X.shape[0], X.T @ X, Y.T @ X, (Y * Y).sum()
+
+
+def _golden_layer_stats(layers, name):
+    e = layers[name]
+    if 'G' in e:
+        return e['n'], e['G'], e['P'], e['c'], None, None
+    X = e['X']
+    if isinstance(X, tuple):                    # ('same_as', other layer): identical input features stored once
+        X = layers[X[1]]['X']
+    n, G, P, c = _gram(X.float(), e['Y'].float())
+    assert n == e['n']
+    return n, G, P, c, X.float(), e['Y'].float()
+
+
+def test_feature_collection_vs_reference_golden(emulated_hip, tmp_path, monkeypatch):
+    """What the REFERENCE's own merge_text_encoder / merge_kv_in_cross_attention / merge_spatial_attention hand to
+    update_quasi_newton (tests/golden/reference_fusion_golden.pt, recorded by make_golden.py `fusion` with the
+    reference's code on the product's 'tiny768' modules) against (a) the oracle's restatement of those functions
+    (oracle/fusion_ref.py) and (b) the Gram statistics the PRODUCT streams through its hooks / feature taps. Every stage
+    starts from the pretrained weights, as in the fixture."""
+    import gradient_fusion as gf
+    from oracle import edlora_ref as R
+    from oracle import fusion_ref as FR
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_fusion_golden.pt'),
+                   weights_only=False)
+    preset, dev = g['preset'], torch.device('cpu')
+    cfg = make_fusion_fixture(tmp_path, preset, n_concepts=g['n_concepts'])
+    pipes = []
+    for _ in range(2):
+        pipe, _, sched = gf.init_stable_diffusion(f'synthetic://{preset}?seed=0', dev)
+        for p in list(pipe.text_encoder.parameters()) + list(pipe.unet.parameters()):
+            p.requires_grad = False
+        pipes.append((pipe, sched))
+    (pp, ps), (op, os_) = pipes
+    emb, te, kv, sp, concepts = gf.parse_new_concepts(cfg)
+    _, cfg_p = gf.merge_new_concepts_(emb, concepts, pp.tokenizer, pp.text_encoder)
+    _, cfg_o = gf.merge_new_concepts_(emb, concepts, op.tokenizer, op.text_encoder)
+    assert cfg_p == cfg_o == g['new_concept_cfg'], 'concept-token numbering differs from the reference merge_new_concepts_'
+    for m in op.unet.modules():
+        if m.__class__.__name__ == 'Attention':
+            m.set_processor(R.PlainAttnProcessorRef())
+    captured = {}
+    real_solve = gf._solve_layers
+
+    def spy_solve(accs, original_state_dict, iters, tag):
+        captured[tag] = accs
+        return real_solve(accs, original_state_dict, iters, tag)
+
+    monkeypatch.setattr(gf, '_solve_layers', spy_solve)
+    bind = R.bind_concept_prompt_ref
+    it_te, it_un = 2, 2               # the solver is not under test here (golden['lbfgs'] pins it): features only
+    oracle, te0 = {}, {k: v.detach().clone() for k, v in pp.text_encoder.state_dict().items()}
+    u0 = {k: v.detach().clone() for k, v in pp.unet.state_dict().items()}
+    gf.merge_text_encoder(concepts, it_te, cfg_p, pp.tokenizer, pp.text_encoder, te, dev)
+    oracle['text_encoder'] = FR.merge_text_encoder_ref(concepts, it_te, cfg_o, op.tokenizer, op.text_encoder, te, dev, bind,
+                                                       return_features=True)[:2]
+    gf.merge_kv_in_cross_attention(concepts, it_te, cfg_p, pp.tokenizer, pp.text_encoder, pp.unet, kv, dev)
+    oracle['cross_kv'] = FR.merge_kv_in_cross_attention_ref(concepts, it_te, cfg_o, op.tokenizer, op.text_encoder, op.unet, kv,
+                                                            dev, bind, return_features=True)[:2]
+    torch.manual_seed(g['seed_spatial'])
+    gf.merge_spatial_attention(concepts, it_un, cfg_p, pp.tokenizer, pp.text_encoder, pp.unet, sp, ps, dev)
+    torch.manual_seed(g['seed_spatial'])
+    oracle['spatial'] = FR.merge_spatial_attention_ref(concepts, it_un, cfg_o, op.tokenizer, op.text_encoder, op.unet, sp, os_,
+                                                       dev, bind, return_features=True)[:2]
+    assert all(torch.equal(v, te0[k]) for k, v in pp.text_encoder.state_dict().items())
+    assert all(torch.equal(v, u0[k]) for k, v in pp.unet.state_dict().items())
+    tags = dict(text_encoder='text-encoder', cross_kv='cross-kv', spatial='spatial')
+    # oracle: same arithmetic as the reference on the same modules -> (near-)identical features; product: fp16 fused
+    # projections + fp32-partial Gram accumulation of the emulated kernels
+    tol_oracle = dict(text_encoder=1e-6, cross_kv=1e-6, spatial=2e-3)
+    tol_product = dict(text_encoder=2e-4, cross_kv=2e-4, spatial=5e-3)
+    for stage, layers in g['stages'].items():
+        Xo, Yo = oracle[stage]
+        accs = captured[tags[stage]]
+        assert set(layers) == set(Xo) == set(accs), f'{stage}: layer sets differ from the reference'
+        worst_o = worst_p = (0.0, '')
+        for name in sorted(layers):
+            n, G, P, c, Xg, Yg = _golden_layer_stats(layers, name)
+            no, Go, Po, co = _gram(Xo[name].float(), Yo[name].float())
+            assert no == n == accs[name].n, f'{name}: rows reference {n} oracle {no} product {accs[name].n}'
+            if Xg is not None and stage != 'spatial':
+                torch.testing.assert_close(Xo[name].float().reshape(Xg.shape), Xg, rtol=1e-6, atol=1e-7, msg=f'{name}: oracle X')
+                torch.testing.assert_close(Yo[name].float().reshape(Yg.shape), Yg, rtol=1e-5, atol=1e-6, msg=f'{name}: oracle Y')
+            eo = max(((Go - G).norm() / G.norm()).item(), ((Po - P).norm() / P.norm()).item(), abs(co.item() - c.item()) / c.item())
+            a = accs[name]
+            ep = max(((a.G.cpu() - G).norm() / G.norm()).item(), ((a.P.cpu() - P).norm() / P.norm()).item(),
+                     abs(a.c.item() - c.item()) / c.item())
+            worst_o, worst_p = max(worst_o, (eo, name)), max(worst_p, (ep, name))
+        print(f'[parity] fusion {stage} vs the REFERENCE\'s own features ({len(layers)} layers): Gram statistics worst rel err '
+              f'oracle {worst_o[0]:.2e} ({worst_o[1]}), product {worst_p[0]:.2e} ({worst_p[1]})')
+        assert worst_o[0] <= tol_oracle[stage], (stage, worst_o)
+        assert worst_p[0] <= tol_product[stage], (stage, worst_p)
