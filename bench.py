@@ -135,6 +135,45 @@ def roofline_from_profile(records):
                 algorithmic_flops_per_launch=top['flops'], algorithmic_bytes_per_launch=top['bytes'])
 
 
+def dominant_by_kernel_name(records, per):
+    """The per-(kernel, shape) record with the largest time is what `roofline` describes; the dominant kernel BY NAME (all
+    shapes of one kernel summed) can be another one (round 2: dK/dV d40 by record, conv3x3 by name): reported beside it."""
+    agg = {}
+    for r in records:
+        k = r['name'].split(' ')[0]
+        a = agg.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, calls=0))
+        a['ms'] += r['total_ms']
+        a['flops'] += r['flops'] * r['calls']
+        a['bytes'] += r['bytes'] * r['calls']
+        a['calls'] += r['calls']
+    lib_ms = sum(a['ms'] for a in agg.values())
+    out = []
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:6]:
+        sec = a['ms'] * 1e-3
+        out.append(dict(kernel=k, ms=round(a['ms'] / per, 3), launches=a['calls'] / per,
+                        share_of_library_gpu_time=round(a['ms'] / max(1e-9, lib_ms), 4),
+                        tflops=round(a['flops'] / max(1e-12, sec) / 1e12, 2), gbps=round(a['bytes'] / max(1e-12, sec) / 1e9, 1),
+                        frac_of_mfma_peak=round(a['flops'] / max(1e-12, sec) / 1e12 / PEAK_MFMA_TFLOPS, 5)))
+    return out
+
+
+# Algorithmic FLOPs of one ED-LoRA training step per image at 512^2 that are NOT seen by the library's profiler
+# (SURVEY 8(d) level table): the GEGLU feed-forward GEMMs (hipBLASLt): 153.5 GFLOP per sample-forward, x2 (forward + dX;
+# frozen weights: no dW).
+FF_GEMM_GFLOP_PER_TRAINED_IMAGE = 2 * 153.5
+
+
+def whole_step_utilisation(recs, per, images, step_ms):
+    """Algorithmic FLOPs of everything timed by the library's own profiler (attention, projections, convolutions incl. the
+    VAE encoder and the CLIP tower) + the analytic feed-forward GEMM FLOPs, over the measured step time. MIOpen's small
+    convolutions (16x16 / 8x8 levels, stride 2, conv_in / conv_out) are not counted: a lower bound."""
+    lib = sum(r['flops'] * r['calls'] for r in recs) / per / 1e12
+    ff = FF_GEMM_GFLOP_PER_TRAINED_IMAGE * images / 1e3
+    tf = (lib + ff) / max(1e-12, step_ms * 1e-3)
+    return dict(library_kernels_tflop=round(lib, 3), ff_gemm_tflop_analytic=round(ff, 3), tflop_per_step=round(lib + ff, 3),
+                achieved_tflops=round(tf, 1), frac_of_mfma_peak=round(tf / PEAK_MFMA_TFLOPS, 4))
+
+
 ATTENTION_PATH_KERNELS = ('attn_', 'region_attn', 'gemm_nt', 'lora_')
 
 
@@ -323,6 +362,8 @@ def run_train(args, rank, world, device):
                     kernel_source_sha16=kernel_source_fingerprint(), **_tuning_switches()),
         roofline=roofline_from_profile(recs) if recs else None,
         attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_TRAINED_IMAGE, B, recs, 2) if recs else None,
+        dominant_kernels_by_name=dominant_by_kernel_name(recs, 2) if recs else None,
+        whole_step=whole_step_utilisation(recs, 2, B, dt / args.steps * 1e3) if recs else None,
         kernels=_kernel_table(recs, 2), library_kernel_ms_per_step=round(lib_ms, 3))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_train(trainer, size)
@@ -360,6 +401,27 @@ def regional_prompt(height, width):
     return [(ctx, regions)], neg
 
 
+def synthetic_adapter_states(pipe, height, width, device, dtype, seed=15):
+    """SURVEY 8(d) cfg #5: the reference cannot run without an adapter input (pipeline_regionally_t2iadapter.py:484); no
+    T2I-Adapter weights exist offline, so the four feature levels an adapter would produce are seeded synthetic tensors
+    (N(0, 0.05^2)), pushed through the product's region-weight rule (`_adapter_states`, reference :488-542) with the
+    regionally_sample.sh style weights: keypose 1.0 everywhere, 0.6 inside the first region box."""
+    chans = pipe.unet.config.block_out_channels
+    g = torch.Generator().manual_seed(seed)
+    feats = [torch.randn((1, c, height // (8 << min(i, len(chans) - 1)), width // (8 << min(i, len(chans) - 1))), generator=g)
+             .mul_(0.05).to(device, dtype) for i, c in enumerate(chans)]
+
+    class _Fixed(torch.nn.Module):          # stands in for the adapter network: returns the seeded feature list
+        dtype = feats[0].dtype
+
+        def forward(self, x):
+            return feats
+
+    b = REGION_PX[0]
+    return pipe._adapter_states(_Fixed(), torch.zeros(1, 3, height, width), 1.0, f'[{b[0]}, {b[1]}, {b[2]}, {b[3]}]-0.6',
+                                height, width)
+
+
 def run_regional(args, rank, world, device, steps=None, warmup=None):
     from mixofshow.hip import profiler
     H, W = 512, 768
@@ -371,10 +433,12 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
     prompt, neg = regional_prompt(H, W)
     latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14))
     graph = None if args.regional_graph < 0 else bool(args.regional_graph)
+    adapter_states = synthetic_adapter_states(pipe, H, W, device, torch.float16)
 
     def sample(g):
         return pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50,
-                    guidance_scale=7.5, latents=latents.clone(), output_type='latent', hipgraph=g).images
+                    guidance_scale=7.5, latents=latents.clone(), output_type='latent', hipgraph=g,
+                    adapter_states=adapter_states).images
 
     for _ in range(warmup):
         sample(graph)
@@ -394,12 +458,14 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
                unit='ms', n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
                higher_is_better=False, scaling='weak', vs_baseline=None, dtype='fp16', data='synthetic',
                config=dict(workload='BASELINE.json configs[4]: 3-region (potter/hermione/thanos) 512x768, 50 '
-                                    'DPM-Solver++(2M) steps, CFG 7.5, batch 1, SD-1.5 random init (calibrated), no adapter',
+                                    'DPM-Solver++(2M) steps, CFG 7.5, batch 1, SD-1.5 random init (calibrated), seeded synthetic 4-level '
+                                    'adapter states with a region weight (SURVEY 8(d) cfg #5)',
                            replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all()),
                            hipgraph=graphed, channels_last=bool(args.channels_last), host_cores=os.cpu_count(),
                            **_tuning_switches()),
                roofline=roofline_from_profile(recs) if recs else None,
                attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_REGIONAL_CALL, 50, recs, 1) if recs else None,
+               dominant_kernels_by_name=dominant_by_kernel_name(recs, 1) if recs else None,
                kernels=_kernel_table(recs, 1), library_kernel_ms_per_sample=round(lib_ms, 3))
     del pipe
     torch.cuda.empty_cache()
@@ -554,6 +620,7 @@ def main():
             res['regional'] = dict(value_ms=reg['value'], metric=reg['metric'], steps=reg['steps'], warmup=reg['warmup'],
                                    config=reg['config'], roofline=reg['roofline'], attention_path=reg['attention_path'],
                                    cpu_baseline=reg.get('cpu_baseline'), kernels=reg['kernels'],
+                                   dominant_kernels_by_name=reg.get('dominant_kernels_by_name'),
                                    library_kernel_ms_per_sample=reg['library_kernel_ms_per_sample'])
         else:
             res['regional'] = None

@@ -76,15 +76,35 @@ _direct_grad = False
 
 
 def set_direct_grad_accumulation(flag):
-    """True (set by TrainEngine, which owns the flat gradient bucket): the backward kernel accumulates the LoRA factor
-    gradients straight into existing fp32 `.grad` tensors and autograd receives None for those inputs — no
-    per-parameter slice / transpose / scale / add kernels. False (default): gradients are returned to autograd."""
+    """True: the backward kernel accumulates the LoRA factor gradients straight into existing fp32 `.grad` tensors and
+    autograd receives None for those inputs — no per-parameter slice / transpose / scale / add kernels. False
+    (default): gradients are returned to autograd. TrainEngine (which owns the flat gradient bucket) switches it on only
+    around its own forward/backward (`direct_grad_accumulation()` below), so that other users of autograd in the
+    process (torch.autograd.grad, hooks, a second trainer without a bucket) keep the ordinary semantics."""
     global _direct_grad
     _direct_grad = bool(flag)
 
 
+class direct_grad_accumulation:
+    """with direct_grad_accumulation(): ... — scoped form of set_direct_grad_accumulation(True)."""
+
+    def __enter__(self):
+        global _direct_grad
+        self.prev, _direct_grad = _direct_grad, True
+
+    def __exit__(self, *exc):
+        global _direct_grad
+        _direct_grad = self.prev
+        return False
+
+
 class _PackGroup:
     __slots__ = ('downs', 'ups', 'alphas', 'K', 'bufs', 'vers', 'epoch', 'desc', 'elems')
+
+    def params(self):
+        """The fp32 master tensors (weak references: the registry must not keep a discarded model alive)."""
+        ps = [r() for r in (*self.downs, *self.ups)]
+        return None if any(p is None for p in ps) else (ps[:len(self.downs)], ps[len(self.downs):])
 
 
 class LoraPackRegistry:
@@ -92,29 +112,57 @@ class LoraPackRegistry:
     on first use; whenever any group's parameters changed since the last pack (tensor version counters: optimiser step,
     load_state_dict, manual edits) ALL groups are repacked by one `mos_lora_pack_all` launch — 1 launch per training step
     instead of one per projection call. Inside a captured hipGraph the launch sits where the first projection asked
-    for its operands (`invalidate()` before capture guarantees it is there)."""
+    for its operands (`invalidate()` before capture guarantees it is there).
 
-    def __init__(self, device, dtype):
+    The descriptor table lives in ONE device buffer of fixed capacity that is only ever updated IN PLACE (a captured graph
+    bakes its address and the group count into the pack launch): groups registered later are appended behind the ones
+    the graph knows, pointer / alpha changes rewrite entries where they are. Outgrowing the buffer while a graph holds
+    its address (`freeze()`, set by TrainEngine.enable_graph) raises instead of reallocating. Parameters are held
+    weakly; groups whose model is gone are dropped at the next pack (never while frozen: the captured group count
+    must stay valid — a dead group's entry then only makes the kernel rewrite operand buffers nobody reads)."""
+
+    def __init__(self, device, dtype, capacity=512):
         self.device, self.dtype = device, dtype
         self.groups = {}
         self.epoch = 0
+        self.capacity = capacity
         self.desc_dev = None
+        self.table_dirty = True
         self.max_elems = 1
+        self.frozen = 0
+
+    def freeze(self):
+        self.frozen += 1
+
+    def unfreeze(self):
+        self.frozen = max(0, self.frozen - 1)
 
     @staticmethod
-    def _vers(g):
-        return tuple(p._version for p in g.downs) + tuple(p._version for p in g.ups) + tuple(
-            p.data_ptr() for p in g.downs) + tuple(p.data_ptr() for p in g.ups) + tuple(g.alphas)
+    def _vers(g, ps):
+        downs, ups = ps
+        return tuple(p._version for p in downs) + tuple(p._version for p in ups) + tuple(
+            p.data_ptr() for p in downs) + tuple(p.data_ptr() for p in ups) + tuple(g.alphas)
 
     def invalidate(self):
         self.epoch += 1
 
+    def clear(self):
+        """Forget every group (tests / explicit model teardown). Not while a captured graph uses the table."""
+        if self.frozen:
+            raise RuntimeError('LoraPackRegistry.clear(): a captured hipGraph still packs through this registry')
+        self.groups.clear()
+        self.table_dirty = True
+
     def get(self, downs, ups, alphas, K):
+        import weakref
         key = tuple(id(p) for p in downs) + tuple(id(p) for p in ups)
         g = self.groups.get(key)
+        if g is not None and g.params() is None:      # id() of a dead tensor was recycled by a new one
+            g = None
         if g is None:
             g = _PackGroup()
-            g.downs, g.ups, g.alphas, g.K = tuple(downs), tuple(ups), tuple(alphas), K
+            g.downs, g.ups = tuple(weakref.ref(p) for p in downs), tuple(weakref.ref(p) for p in ups)
+            g.alphas, g.K = tuple(alphas), K
             N = sum(u.shape[0] for u in ups)
             dev, dt = self.device, self.dtype
             pad = ops.MOS_LORA_PAD
@@ -123,11 +171,12 @@ class LoraPackRegistry:
             g.elems = pad * max(K, N)
             g.vers, g.epoch = None, -1
             g.desc = None
+            self.groups.pop(key, None)               # (a recycled id: the stale entry goes, the new one is appended)
             self.groups[key] = g
-            self.desc_dev = None
+            self.table_dirty = True
         else:
             g.alphas = tuple(alphas)
-        if g.vers != self._vers(g):
+        if g.vers != self._vers(g, (downs, ups)):
             self.epoch += 1                      # something changed since the last pack: everything is repacked once
         if g.epoch != self.epoch:
             self._pack_all()
@@ -136,20 +185,39 @@ class LoraPackRegistry:
     def _pack_all(self):
         import ctypes
         from . import lib as _lib
+        if not self.frozen:                      # drop the groups of models that no longer exist
+            dead = [k for k, g in self.groups.items() if g.params() is None]
+            for k in dead:
+                del self.groups[k]
+            self.table_dirty = self.table_dirty or bool(dead)
         gs = list(self.groups.values())
-        stale = self.desc_dev is None
+        if len(gs) > self.capacity:
+            if self.frozen:
+                raise RuntimeError(f'LoraPackRegistry: {len(gs)} LoRA groups exceed the descriptor table ({self.capacity}) '
+                                   'that a captured hipGraph holds; build every model before TrainEngine.enable_graph')
+            self.capacity, self.desc_dev = max(2 * self.capacity, len(gs)), None
+        stale = self.table_dirty or self.desc_dev is None
         for g in gs:
-            v = self._vers(g)
-            if g.desc is None or g.vers is None or v[len(g.downs) + len(g.ups):] != g.vers[len(g.downs) + len(g.ups):]:
-                g.desc = ops.lora_group_desc(g.downs, g.ups, g.alphas, g.K, *g.bufs)   # pointers / alphas changed
+            ps = g.params()
+            if ps is None:                       # frozen registry, model gone: keep the last descriptor
+                g.epoch = self.epoch
+                continue
+            v = self._vers(g, ps)
+            nv = len(ps[0]) + len(ps[1])
+            if g.desc is None or g.vers is None or v[nv:] != g.vers[nv:]:
+                g.desc = ops.lora_group_desc(ps[0], ps[1], g.alphas, g.K, *g.bufs)   # pointers / alphas changed
                 stale = True
             g.vers = v
             g.epoch = self.epoch
         if stale:
             arr = (_lib.LoraGroup * len(gs))(*[g.desc for g in gs])
-            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
-            self.desc_dev = host.to(self.device)
-            self.max_elems = max(g.elems for g in gs)
+            raw = bytes(arr)
+            if self.desc_dev is None:
+                self.desc_dev = torch.zeros(self.capacity * ctypes.sizeof(_lib.LoraGroup), dtype=torch.uint8, device=self.device)
+            host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            self.desc_dev[:len(raw)].copy_(host)                 # in place: the buffer's address never changes
+            self.max_elems = max([self.max_elems] + [g.elems for g in gs])
+            self.table_dirty = False
         ops.lora_pack_all(self.desc_dev, len(gs), self.max_elems, self.dtype)
 
 
@@ -169,6 +237,12 @@ def invalidate_lora_packs():
     """Force a repack at the next use (call before capturing a step into a hipGraph)."""
     for r in _registries.values():
         r.invalidate()
+
+
+def freeze_lora_packs(flag=True):
+    """A captured graph holds the descriptor table's address and group count: pin both (see LoraPackRegistry)."""
+    for r in _registries.values():
+        r.freeze() if flag else r.unfreeze()
 
 
 def _lora_operands(downs, ups, alphas, K, dtype, device):

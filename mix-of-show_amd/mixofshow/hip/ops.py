@@ -453,12 +453,18 @@ def single_head_attention_nograd(q, k, v, scale):
     """softmax(scale q k^T) v for ONE head of large dim (VAE mid-block: d = 512, N = 4096), forward only: scores GEMM,
     row softmax, values GEMM per batch element on the library kernels (the (N, N) scores are materialised, 34 MB)."""
     _dev(q, k, v)
+    import math
     B, N, d = q.shape
     o = torch.empty_like(q)
     S = torch.empty((N, k.shape[1]), dtype=q.dtype, device=q.device)
+    # the scores are stored in half between the two GEMMs: q is pre-scaled by the power of two below `scale` (exact in
+    # half) so that they are stored at (nearly) their softmax scale -- unscaled d = 512 scores are 22x larger, which
+    # costs ~0.1 of a scaled logit in rounding at |logit| ~ 100 and overflows half from |logit| ~ 2900 on
+    p2 = 2.0 ** math.floor(math.log2(scale)) if scale > 0 else 1.0
+    qs = q * p2
     for i in range(B):
-        linear_fwd(q[i], k[i], out=S)
-        softmax_rows(S, scale, out=S)
+        linear_fwd(qs[i], k[i], out=S)
+        softmax_rows(S, scale / p2, out=S)
         linear_fwd(S, v[i].t().contiguous(), out=o[i])
     return o
 

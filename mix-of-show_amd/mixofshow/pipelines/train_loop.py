@@ -33,9 +33,8 @@ class TrainEngine:
             self.optimizer = torch.optim.AdamW(groups, **optim_cfg, foreach=True)
         self.base_lrs = [g['lr'] for g in self.optimizer.param_groups]
         self.bucket = dp.FlatGradBucket(trainer.trainable_parameters())
-        # the LoRA backward kernel accumulates straight into the bucket's `.grad` views (no per-parameter glue kernels)
-        from mixofshow.hip import functional as F_hip
-        F_hip.set_direct_grad_accumulation(True)
+        # the LoRA backward kernel accumulates straight into the bucket's `.grad` views (no per-parameter glue kernels):
+        # switched on only around this engine's own forward/backward (F_hip.direct_grad_accumulation)
         self.mixed_precision = mixed_precision
         self.amp_dtype = {'fp16': torch.float16, 'bf16': torch.bfloat16}.get(mixed_precision)
         self.scaler = torch.amp.GradScaler('cuda', enabled=(mixed_precision == 'fp16' and dev.type == 'cuda'))
@@ -98,14 +97,17 @@ class TrainEngine:
         self._static = st
         self._token_cache = {}
 
+        from mixofshow.hip import functional as F_hip
+
         def fwd_bwd():
             self.bucket.zero()
-            with torch.autocast(dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-                loss = tr(st.get('images'), None, st.get('masks', st['img_masks']), st['img_masks'],
-                          noise=st.get('noise'), timesteps=st.get('timesteps'), latents=st.get('latents'),
-                          latent_noise=st.get('latent_noise'),
-                          text_input_ids=st['ids'], token_positions=st['pos'])
-            self.scaler.scale(loss).backward()
+            with F_hip.direct_grad_accumulation():
+                with torch.autocast(dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                    loss = tr(st.get('images'), None, st.get('masks', st['img_masks']), st['img_masks'],
+                              noise=st.get('noise'), timesteps=st.get('timesteps'), latents=st.get('latents'),
+                              latent_noise=st.get('latent_noise'),
+                              text_input_ids=st['ids'], token_positions=st['pos'])
+                self.scaler.scale(loss).backward()
             return loss.detach()
 
         side = torch.cuda.Stream()
@@ -114,21 +116,29 @@ class TrainEngine:
             for _ in range(warmup):
                 fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
-        from mixofshow.hip import functional as F_hip
         F_hip.invalidate_lora_packs()          # the one-launch repack of all LoRA operands must be part of the graph
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
             self._static_loss = fwd_bwd()
+        self._graph = graph
+        F_hip.freeze_lora_packs(True)          # the graph holds the descriptor table's address and group count
         return self
+
+    def disable_graph(self):
+        """Back to the eager step (also releases the LoRA descriptor table)."""
+        if getattr(self, '_graph', None) is not None:
+            from mixofshow.hip import functional as F_hip
+            self._graph = None
+            F_hip.freeze_lora_packs(False)
+
+    def __del__(self):
+        try:
+            self.disable_graph()
+        except Exception:
+            pass
 
     def _graph_step(self, batch):
         tr, st = self.trainer, self._static
-        for k in ('images', 'masks', 'img_masks', 'noise', 'timesteps', 'latents', 'latent_noise'):
-            if k in st and torch.is_tensor(batch.get(k)):
-                v = batch[k]
-                # an async copy out of pageable host memory may run after the host tensor is gone: only device or
-                # pinned sources are copied without blocking
-                st[k].copy_(v, non_blocking=(v.is_cuda or v.is_pinned()))
         # token ids of a caption set are a pure function of the strings: keep them on the device (a concept's
         # training set is a handful of captions), so a steady-state step has no host->device traffic at all
         key = tuple(batch['prompts'])
@@ -139,6 +149,19 @@ class TrainEngine:
             ent = (ids.to(dev), pos.to(dev) if pos is not None else None)     # blocking uploads
             if len(self._token_cache) < 4096:
                 self._token_cache[key] = ent
+        # the graph is valid for the captured shapes only (a caption with a different number of concept tokens, a ragged
+        # last batch): such a step runs eagerly instead of silently broadcasting into the static buffers
+        same = ent[0].shape == st['ids'].shape and ((ent[1] is None) == (st['pos'] is None)) and (
+            ent[1] is None or ent[1].shape == st['pos'].shape)
+        same = same and all(batch[k].shape == st[k].shape for k in st if k in batch and torch.is_tensor(batch.get(k)))
+        if not same:
+            return self._eager_step(batch)
+        for k in ('images', 'masks', 'img_masks', 'noise', 'timesteps', 'latents', 'latent_noise'):
+            if k in st and torch.is_tensor(batch.get(k)):
+                v = batch[k]
+                # an async copy out of pageable host memory may run after the host tensor is gone: only device or
+                # pinned sources are copied without blocking
+                st[k].copy_(v, non_blocking=(v.is_cuda or v.is_pinned()))
         st['ids'].copy_(ent[0])
         if ent[1] is not None:
             st['pos'].copy_(ent[1])
@@ -153,6 +176,10 @@ class TrainEngine:
         """One micro-batch; performs the optimiser update every `grad_accum` calls. Returns a dict of device scalars."""
         if getattr(self, '_graph', None) is not None:
             return self._graph_step(batch)
+        return self._eager_step(batch)
+
+    def _eager_step(self, batch):
+        from mixofshow.hip import functional as F_hip
         tr = self.trainer
         if self._micro == 0:
             self.bucket.zero()
@@ -162,9 +189,10 @@ class TrainEngine:
         images = batch['images']
         if self.channels_last and images is not None:
             images = images.contiguous(memory_format=torch.channels_last)
-        with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
-            loss = tr(images, batch['prompts'], masks, batch['img_masks'], **extra)
-        self.scaler.scale(loss / self.grad_accum).backward()
+        with F_hip.direct_grad_accumulation():
+            with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                loss = tr(images, batch['prompts'], masks, batch['img_masks'], **extra)
+            self.scaler.scale(loss / self.grad_accum).backward()
         self._micro += 1
         if self._micro < self.grad_accum:
             return {'loss': loss.detach()}

@@ -257,8 +257,8 @@ class EDLoRATrainer(nn.Module):
                 B, H, N, T = m.shape
                 res = int(math.sqrt(N))
                 groups.setdefault(res, []).append(m.reshape(B, H, res, res, T))
-        total = 0
-        valid = None
+        total = torch.zeros((), dtype=torch.float32, device=masks.device)     # no recorded maps: 0, valid (reference: adds 0)
+        valid = torch.ones((), dtype=torch.bool, device=masks.device)
         for res in sorted(groups, reverse=True):
             cm = torch.cat(groups[res], dim=1)
             cm = cm.sum(1) / cm.shape[1]                       # mean over heads of all layers: (B, res, res, T)
@@ -269,7 +269,7 @@ class EDLoRATrainer(nn.Module):
             outside = (gt == 0).to(subj.dtype)
             n_out = outside.sum()
             ok = n_out > 0
-            valid = ok if valid is None else (valid & ok)
+            valid = valid & ok
             denom = n_out.clamp(min=1.0)              # 0/0 would poison the backward pass even under a `where`
             if self.reg_full_identity:
                 l_subj = F.mse_loss(subj.float(), gt.float(), reduction='mean')
@@ -278,7 +278,10 @@ class EDLoRATrainer(nn.Module):
             l_adj = (adj * outside).sum() / denom
             total = total + self.attn_reg_weight * (l_subj + l_adj)
         if return_valid:
-            return total, valid
+            # a non-finite regulariser from any other cause (fp16 overflow in a map) is dropped too, as the reference's
+            # `if not torch.isnan(attention_loss)` does (:257)
+            finite = torch.isfinite(total)
+            return torch.where(finite, total, torch.zeros_like(total)), valid & finite
         return torch.where(valid, total, torch.full_like(total, float('nan')))
 
     # ------------------------------------------------------------------------------------------

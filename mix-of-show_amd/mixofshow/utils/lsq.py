@@ -105,9 +105,47 @@ def lbfgs_on_gram(W0, acc, iters, solver='lean'):
     return best['W'].to(torch.float32).cpu(), best['loss']
 
 
-def update_quasi_newton(K_target, V_target, W, iters, device):
+def lbfgs_direct_form(K_target, V_target, W, iters, device, chunk=5000):
+    """PARITY / DIAGNOSTIC mode (not the fusion path): the same optimiser loop (mixofshow.utils.lbfgs) on the reference's
+    own closure arithmetic -- fp32, loss = mean((K W^T - V)^2) summed over 5000-row chunks as chunk_compute_mse does
+    (gradient_fusion.py:22-35), gradient by autograd like the reference's loss.backward() -- instead of the fp64 Gram form. Two truncated
+    L-BFGS runs on an ill-conditioned layer only agree while their closures round alike; this mode separates "Gram
+    form vs direct form" from "different features" when fused weights are compared with the reference's
+    (tests/test_fusion_cpu.py). Linear layers only (2-D W)."""
+    from mixofshow.utils import lbfgs
+    assert W.dim() == 2
+    K = K_target.detach().to(device, torch.float32)
+    V = V_target.detach().to(device, torch.float32)
+    n, cout = K.shape[0], W.shape[0]
+    best = {'loss': float('inf'), 'W': None}
+
+    def value_and_grad(x):
+        Wm = x.detach().view(W.shape).clone().requires_grad_(True)
+        with torch.enable_grad():
+            loss = 0
+            for s0 in range(0, n, chunk):      # chunk_compute_mse: F.mse_loss(F.linear(K, W), V) * rows, summed, / n
+                k, v = K[s0:s0 + chunk], V[s0:s0 + chunk]
+                loss = loss + torch.nn.functional.mse_loss(torch.nn.functional.linear(k, Wm), v) * k.shape[0]
+            loss = loss / n
+            (grad, ) = torch.autograd.grad(loss, Wm)
+        return loss.detach(), grad.reshape(-1)
+
+    def on_eval(x, lv):
+        if lv < best['loss']:
+            best['loss'], best['W'] = lv, x
+
+    x0 = W.detach().to(K.device, torch.float32).reshape(-1).contiguous().clone()
+    lbfgs.minimize(value_and_grad, x0, iters, history_size=25, lr=1.0, tolerance_grad=1e-16, tolerance_change=1e-16,
+                   on_eval=on_eval)
+    return best['W'].view(W.shape).to(torch.float32).cpu(), best['loss']
+
+
+def update_quasi_newton(K_target, V_target, W, iters, device, form='gram'):
     """Drop-in for the reference's update_quasi_newton (gradient_fusion.py:38-96); K/V may live on the CPU,
-    W is 2-D (Linear) or 4-D (1x1 conv, features (n, C, h, w))."""
+    W is 2-D (Linear) or 4-D (1x1 conv, features (n, C, h, w)). form='direct': the parity mode above."""
+    if form == 'direct':
+        return lbfgs_direct_form(K_target, V_target, W, iters, device)[0]
+    assert form == 'gram', form
     conv = W.dim() == 4
     cout, cin = W.shape[0], W.shape[1]
     acc = GramAccumulator(cin, cout, device)

@@ -248,9 +248,12 @@ def softmax_rows(x, scale, out=None):
 
 
 def single_head_attention_nograd(q, k, v, scale):
-    """scores and probabilities are rounded to the half type between the GEMMs, like the kernel sequence."""
-    s = (q.float() @ k.float().transpose(-1, -2)).to(q.dtype)
-    p = torch.softmax(s.float() * scale, -1).to(q.dtype)
+    """scores and probabilities are rounded to the half type between the GEMMs, like the kernel sequence (q pre-scaled
+    by the power of two below `scale`, exact in half)."""
+    import math
+    p2 = 2.0 ** math.floor(math.log2(scale)) if scale > 0 else 1.0
+    s = ((q * p2).float() @ k.float().transpose(-1, -2)).to(q.dtype)
+    p = torch.softmax(s.float() * (scale / p2), -1).to(q.dtype)
     return (p.float() @ v.float()).to(q.dtype)
 
 

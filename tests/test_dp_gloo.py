@@ -20,10 +20,10 @@ def _setup_emulation():
         setattr(ops, name, getattr(emu_ops, name))
 
 
-def _make_engine():
+def _make_engine(attn_reg=True):
     from tests.test_host_cpu import _trainer
     from mixofshow.pipelines.train_loop import TrainEngine
-    tr = _trainer()
+    tr = _trainer() if attn_reg else _trainer(attn_reg_weight=None)
     opt = dict(optim_g=dict(type='AdamW', lr=0.0, weight_decay=0.01, betas=[0.9, 0.999]), emb_norm_threshold=0.55)
     return tr, TrainEngine(tr, opt, total_iter=10, mixed_precision='no')
 
@@ -37,14 +37,14 @@ def _rank_batch(rank):
                 noise=torch.randn(1, 4, 16, 16, generator=g), timesteps=torch.randint(0, 1000, (1, ), generator=g))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, attn_reg=True):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     _setup_emulation()
     from mixofshow.parallel import dp
     dp.init_distributed(backend='gloo')
-    tr, engine = _make_engine()
+    tr, engine = _make_engine(attn_reg)
     # gradient of this rank's batch, reduced
     engine.bucket.zero()
     loss = tr(**_rank_batch(rank))
@@ -84,6 +84,37 @@ def test_two_rank_allreduce_matches_single_process_average(tmp_path, emulated_hi
         tr(**_rank_batch(rank)).backward()
         grads.append(engine.bucket.flat.clone())
     torch.testing.assert_close(r0['reduced'], (grads[0] + grads[1]) / 2, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('world', [4, 8])
+def test_many_rank_allreduce_equals_global_batch_gradient(tmp_path, emulated_hip, world):
+    """SURVEY 8(d) cfg #3 on CPU ranks: per-rank batches with rank-r seeds, ONE all-reduce(mean) of the flat bucket ==
+    the gradient of a single process that sees the GLOBAL batch (world samples at once). The attention regulariser is
+    off here: it normalises maps by maxima over the batch a process holds, so it is per-rank by construction (in the
+    reference's DDP too); the 2-rank test above covers it against the hand-averaged per-rank gradients."""
+    port = 33500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), False), nprocs=world, join=True)
+    rs = [torch.load(tmp_path / f'rank{r}.pt') for r in range(world)]
+    for r in rs[1:]:
+        torch.testing.assert_close(r['reduced'], rs[0]['reduced'], rtol=0, atol=0)     # identical on every rank
+        torch.testing.assert_close(r['params'], rs[0]['params'], rtol=0, atol=0)       # lock-step after AdamW
+    mean_local = torch.stack([r['local'] for r in rs]).mean(0)
+    torch.testing.assert_close(rs[0]['reduced'], mean_local, rtol=1e-6, atol=1e-9)
+    # single process, global batch of `world` samples (same per-sample tensors, concatenated)
+    tr, engine = _make_engine(attn_reg=False)
+    bs = [_rank_batch(r) for r in range(world)]
+    big = dict(images=None, prompts=[b['prompts'][0] for b in bs], masks=torch.cat([b['masks'] for b in bs]),
+               img_masks=torch.cat([b['img_masks'] for b in bs]), latents=torch.cat([b['latents'] for b in bs]),
+               noise=torch.cat([b['noise'] for b in bs]), timesteps=torch.cat([b['timesteps'] for b in bs]))
+    engine.bucket.zero()
+    tr(**big).backward()
+    g = engine.bucket.flat.clone()
+    err = ((rs[0]['reduced'] - g).norm() / g.norm()).item()
+    print(f'[parity] dp{world} (gloo): all-reduced bucket vs single-process global-batch-{world} gradient: rel L2 {err:.2e}')
+    # (the emulated kernels round activations to half like the HIP ones: a batch of `world` changes the fp32 summation order
+    # inside the GEMMs, which flips half roundings -> ~1e-3 rel L2 of rounding noise, no systematic term)
+    assert err <= 3e-3
 
 
 def _cli_worker(rank, world, port, root, recipe):

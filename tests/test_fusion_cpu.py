@@ -345,3 +345,41 @@ def test_feature_collection_vs_reference_golden(emulated_hip, tmp_path, monkeypa
               f'oracle {worst_o[0]:.2e} ({worst_o[1]}), product {worst_p[0]:.2e} ({worst_p[1]})')
         assert worst_o[0] <= tol_oracle[stage], (stage, worst_o)
         assert worst_p[0] <= tol_product[stage], (stage, worst_p)
+
+
+def test_solver_direct_form_reproduces_the_reference_fused_weights(emulated_hip):
+    """Golden G8 also holds what the REFERENCE's update_quasi_newton returned for the cross-attention K/V layers (12 rows x 768
+    inputs: under-determined, the hard case for iterate-level agreement). The product's optimiser loop on the reference's
+    closure arithmetic (`form='direct'`) stays on the reference's trajectory as far as fp32 rounding defines one (1e-3 ..
+    4e-2 of the update after 30 iterations: compact-form direction vs two-loop recursion); the shipped fp64 Gram form ends
+    further away (2e-2 .. 1e-1) because it solves the same problem BETTER -- a loss two to five orders of magnitude lower
+    in the same number of iterations. Asserted: the direct run stays near the reference, the Gram run's loss <= the
+    reference's."""
+    import gradient_fusion as gf
+    from mixofshow.utils import lsq
+    from oracle import fusion_ref as FR
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_fusion_golden.pt'),
+                   weights_only=False)
+    pipe, _, _ = gf.init_stable_diffusion(f"synthetic://{g['preset']}?seed=0", torch.device('cpu'))
+    sd = pipe.unet.state_dict()
+    layers = g['stages']['cross_kv']
+    worst_d = worst_g = 0.0
+    for name in sorted(layers):
+        e = layers[name]
+        X = e['X'] if not isinstance(e['X'], tuple) else layers[e['X'][1]]['X']
+        X, Y, W0, Wref = X.float(), e['Y'].float(), sd[name].float(), e['W']
+        assert abs((Wref - W0).norm().item() - e['dW_norm']) <= 1e-5 * e['dW_norm'], 'pretrained weight differs from the fixture'
+        Wd = lsq.update_quasi_newton(X, Y, W0.clone(), g['iters_te'], torch.device('cpu'), form='direct')
+        Wg = lsq.update_quasi_newton(X, Y, W0.clone(), g['iters_te'], torch.device('cpu'))
+        step = (Wref - W0).norm()
+        rd, rg = ((Wd - Wref).norm() / step).item(), ((Wg - Wref).norm() / step).item()
+        ld, lg, lr = (FR.lsq_loss_ref(X.double(), Y.double(), w.double()).item() for w in (Wd, Wg, Wref))
+        worst_d, worst_g = max(worst_d, rd), max(worst_g, rg)
+        # fp32 rounding alone (compact-form direction vs two-loop recursion, same pairs) moves a 30-iteration iterate of
+        # this 12 x 768 problem by ~2e-3 of the update
+        print(f'   {name}: |W-W_ref|/|W_ref-W0| direct {rd:.2e}, Gram {rg:.2e}; loss reference {lr:.3e}, direct {ld:.3e}, Gram {lg:.3e}')
+        assert rd <= 0.1 and ld <= 3 * lr, f'{name}: direct-form run left the reference trajectory ({rd:.2e}, loss {ld:.3e} vs {lr:.3e})'
+        assert abs(lr - e['loss']) <= 2e-3 * e['loss'] + 1e-12       # (fixture: the reference's fp32 chunk_compute_mse)
+        assert lg <= lr * (1 + 1e-3) + 1e-12, f'{name}: Gram-form loss {lg:.3e} vs reference {lr:.3e}'
+    print(f'[parity] fusion solver vs the REFERENCE fused weights, {len(layers)} cross-K/V layers (12 x 768, 30 iterations): '
+          f'|W - W_ref| / |W_ref - W0| worst: direct fp32 form {worst_d:.2e}, shipped fp64 Gram form {worst_g:.2e}')

@@ -204,6 +204,14 @@ def test_attn_reg_full_mask_nan_guard(emulated_hip):
     tr(**{**b, 'masks': b['masks']})
     v = tr.cal_attn_reg({'x': [torch.rand(2, 2, 16, 2)]}, torch.ones(2, 1, 8, 8))
     assert torch.isnan(v)
+    # no recorded maps at all (round-2 advice): zero and valid, like the reference's `+ 0`
+    v0, ok0 = tr.cal_attn_reg({}, torch.ones(2, 1, 8, 8), return_valid=True)
+    assert v0.item() == 0.0 and bool(ok0)
+    # a non-finite map (fp16 overflow) drops the regulariser instead of reaching the loss (reference :257)
+    bad = torch.rand(2, 2, 16, 2)
+    bad[0, 0, 3, 0] = float('inf')
+    vb, okb = tr.cal_attn_reg({'x': [bad]}, torch.zeros(2, 1, 8, 8), return_valid=True)
+    assert torch.isfinite(vb) and not bool(okb)
 
 
 def test_concept_rows_equal_full_table_adamw():

@@ -148,14 +148,19 @@ def gram_case(n, cin, cout, dtype, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--only', default='')
+    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas")
     ap.add_argument('--dtype', default='f16')
     ap.add_argument('--legacy', type=int, default=0, help='gemm: also time the round-1 multi-launch LoRA path')
     ap.add_argument('--ref', type=int, default=1, help='0: skip the MIOpen / hipBLASLt reference timings')
     args = ap.parse_args()
     dt = torch.float16 if args.dtype == 'f16' else torch.bfloat16
+    only = [t for t in args.only.split(',') if t]
+
+    def want(what):
+        return not only or what in only
+
     cases = []
-    if args.only in ('', 'attn'):
+    if want('attn'):
         cases += [lambda: attn_case(4, 8, 4096, 4096, 40, dt, args.iters), lambda: attn_case(4, 8, 1024, 1024, 80, dt, args.iters),
                   lambda: attn_case(4, 8, 256, 256, 160, dt, args.iters), lambda: attn_case(4, 8, 64, 64, 160, dt, args.iters),
                   lambda: attn_case(4, 8, 4096, 77, 40, dt, args.iters, pcols=True),
@@ -163,23 +168,23 @@ def main():
                   lambda: attn_case(4, 8, 256, 77, 160, dt, args.iters, pcols=True),
                   lambda: attn_case(2, 8, 6144, 6144, 40, dt, args.iters, bwd=False),
                   lambda: attn_case(2, 8, 1536, 1536, 80, dt, args.iters, bwd=False)]
-    if args.only in ('', 'gemm'):
+    if want('gemm'):
         for shp in ((16384, 960, 320), (16384, 320, 320), (4096, 1920, 640), (4096, 640, 640), (1024, 3840, 1280),
                     (1024, 1280, 1280), (256, 1280, 1280), (4928, 768, 768), (4928, 2304, 768), (4928, 768, 2304),
                     (308, 640, 768)):
             cases.append(lambda shp=shp: gemm_case(*shp, dt, args.iters, legacy=args.legacy))
-    if args.only in ('', 'region'):
+    if want('region'):
         cases += [lambda: region_case(64, 96, 40, dt, args.iters), lambda: region_case(32, 48, 80, dt, args.iters),
                   lambda: region_case(16, 24, 160, dt, args.iters)]
-    if args.only in ('', 'gram'):
+    if want('gram'):
         cases += [lambda: gram_case(81920, 320, 320, dt, 5), lambda: gram_case(20480, 1280, 1280, dt, 5)]
-    if args.only in ('', 'conv'):
+    if want('conv'):
         conv_reference([(4, 320, 320, 64, 64), (4, 640, 320, 64, 64), (4, 960, 320, 64, 64), (4, 640, 640, 32, 32),
                         (4, 1280, 640, 32, 32), (4, 1920, 640, 32, 32), (4, 1280, 1280, 16, 16), (4, 2560, 1280, 16, 16),
                         (4, 1280, 1280, 8, 8), (4, 2560, 1280, 8, 8), (4, 128, 128, 512, 512), (4, 256, 256, 256, 256),
                         (4, 512, 512, 128, 128), (4, 512, 512, 64, 64), (2, 320, 320, 64, 96), (2, 1280, 1280, 16, 24)],
                        dt, args.iters, ref=bool(args.ref))
-    if args.only in ('', 'gemm', 'blas') and args.ref:
+    if (want('gemm') or want('blas')) and args.ref:
         blas_reference([(16384, 320, 320), (16384, 960, 320), (4096, 640, 640), (4096, 1920, 640), (1024, 1280, 1280),
                         (1024, 3840, 1280), (256, 1280, 1280), (4928, 768, 768), (4928, 2304, 768), (12288, 320, 320),
                         (3072, 640, 640), (768, 1280, 1280)], dt, args.iters)

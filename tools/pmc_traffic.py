@@ -36,9 +36,14 @@ def collect(d, counter):
 
 # tools/bench_kernels.py --only attn launches these shapes; grid sizes identify them (threads = blocks * 256)
 NAMES = {
-    ('attn_bwd_dkdv_kernel', 'f16', 40): ('attn_bwd_dkdv f16 d40 B4 H8 Nq4096 Nkv4096', 4 * 8 * (4096 // 128) * 256),
-    ('attn_bwd_dq_kernel', 'f16', 40): ('attn_bwd_dq f16 d40 B4 H8 Nq4096 Nkv4096', 4 * 8 * (4096 // 128) * 256),
-    ('attn_fwd_kernel', 'f16', 40): ('attn_fwd f16 d40 B4 H8 Nq4096 Nkv4096', 4 * 8 * (4096 // 256) * 256),
+    ('attn_bwd_dkdv_kernel', 'f16', 40): [('attn_bwd_dkdv f16 d40 B4 H8 Nq4096 Nkv4096', 4 * 8 * (4096 // 128) * 256)],
+    ('attn_bwd_dq_kernel', 'f16', 40): [('attn_bwd_dq f16 d40 B4 H8 Nq4096 Nkv4096', 4 * 8 * (4096 // 128) * 256)],
+    ('attn_fwd_kernel', 'f16', 40): [('attn_fwd f16 d40 B4 H8 Nq4096 Nkv4096', 4 * 8 * (4096 // 256) * 256),
+                                     # regional sampling, CFG pair at 512x768: < 512 workgroups of 256 queries -> 128-query blocks
+                                     ('attn_fwd f16 d40 B2 H8 Nq6144 Nkv6144', 2 * 8 * (6144 // 128) * 256)],
+    ('region_attn_kernel', 'f16', 40): [('region_attn f16 d40 B2 H8 Nq6144 Nkv77 R3', 2 * 8 * (6144 // 128) * 256)],
+    ('region_attn_kernel', 'f16', 80): [('region_attn f16 d80 B2 H8 Nq1536 Nkv77 R3', 2 * 8 * (1536 // 128) * 256)],
+    ('region_attn_kernel', 'f16', 160): [('region_attn f16 d160 B2 H8 Nq384 Nkv77 R3', 2 * 8 * (384 // 128) * 256)],
 }
 
 
@@ -47,15 +52,15 @@ def main(fetch_dir, write_dir):
     fetch, write = collect(fetch_dir, 'FETCH_SIZE'), collect(write_dir, 'WRITE_SIZE')
     kernels = {}
     for (sym, dt, d, grid), fv in fetch.items():
-        ent = NAMES.get((sym, dt, d))
-        if ent is None or str(ent[1]) != str(grid):
+        ent = next((e for e in NAMES.get((sym, dt, d), []) if str(e[1]) == str(grid)), None)
+        if ent is None:
             continue
         wv = write.get((sym, dt, d, grid))
         rd = fv * 1024 * 2                 # FETCH_SIZE is in KB; x2 = the gfx950 correction of the guide
         wr = wv * 1024 if wv is not None else None
         kernels[ent[0]] = dict(read=rd, write=wr, total=rd + (wr or 0.0), grid=grid)
     print(json.dumps(dict(
-        _comment='HBM bytes per launch from rocprofv3 --pmc passes over tools/bench_kernels.py --only attn (FETCH_SIZE and '
+        _comment='HBM bytes per launch from rocprofv3 --pmc passes over tools/bench_kernels.py --only attn,region (FETCH_SIZE and '
                  'WRITE_SIZE in separate passes; FETCH_SIZE KB x1024 x2 gfx950 correction, WRITE_SIZE KB x1024). '
                  'Valid only for the kernel sources with this fingerprint (bench.py checks it).',
         source_sha16=bench.kernel_source_fingerprint(), kernels=kernels), indent=1))

@@ -76,9 +76,13 @@ def train(root_path, args):
     while engine.global_step < total_iter:
         batch = _to_device(next(it), device)
         if use_graph and getattr(engine, '_graph', None) is None:
-            engine.enable_graph(batch)       # fixed batch shape: the loader drops ragged tails in this mode
-            if rank == 0:
-                logger.info('forward+backward captured in a hipGraph')
+            try:
+                engine.enable_graph(batch)   # steps whose shapes differ from this batch run eagerly (TrainEngine._graph_step)
+                if rank == 0:
+                    logger.info('forward+backward captured in a hipGraph')
+            except Exception as e:           # e.g. DEBUG_CLR_GRAPH_PACKET_CAPTURE preset in the environment: train eagerly
+                use_graph = False
+                logger.warning(f'hipGraph capture unavailable ({type(e).__name__}: {e}); training eagerly')
         out = engine.step(batch)
         if 'Norm_mean' not in out:
             continue
