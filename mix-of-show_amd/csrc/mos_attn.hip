@@ -474,7 +474,8 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
 // ---- regional cross-attention: sum over covering sources of attention / count ---------------------
 // One LDS residency per pass: the K rows and the transposed V of up to NSP sources (context prompt + regions, 65..96
 // keys each: CLIP's 77-token context in three 32-key sub-tiles) are staged together -- every global load of the pass is in
-// flight at once, ONE barrier, then each wave walks only the sources that cover one of ITS 32 queries, with no further
+// flight at once (which ones is read off the box table: no vote), ONE barrier, then each wave walks only the sources that
+// cover one of ITS 32 queries, with no further
 // block-wide synchronisation (the previous kernel walked the sources serially: a full memory round trip, two 64-key
 // tiles and three barriers per source, and a block-wide vote before each).
 //   * softmax over all keys of a source at once (no running max / rescale);
@@ -495,7 +496,7 @@ template <int D> struct RG {
     static constexpr bool PREFETCH = NSP < 4;                   // next pass's loads fly under this pass's MFMAs
     static constexpr int NK = (KEYS * HD<D>::DCH + 255) / 256;  // 16-byte chunks per thread: K rows
     static constexpr int NV = (KEYS / 2 * HD<D>::DCH + 255) / 256;   // row PAIRS x chunks per thread: V
-    static constexpr size_t lds_bytes(size_t es) { return (size_t)NSP * (K_ELEMS + V_ELEMS) * es + 16; }
+    static constexpr size_t lds_bytes(size_t es) { return (size_t)NSP * (K_ELEMS + V_ELEMS) * es; }
 };
 
 template <typename T, int D>
@@ -509,9 +510,8 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(Att
     typedef RG<D> G;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS, DCH = HD<D>::DCH, TS3 = G::TS3, NSP = G::NSP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Vt_ = reinterpret_cast<T*>(smem_raw);                  // [NSP] V^T images, then [NSP] K images, then the need word
+    T* Vt_ = reinterpret_cast<T*>(smem_raw);                  // [NSP] V^T images, then [NSP] K images
     T* Ks_ = Vt_ + NSP * G::V_ELEMS;
-    unsigned* need_w = reinterpret_cast<unsigned*>(Ks_ + NSP * G::K_ELEMS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
     const int h = blockIdx.x % a.H;
     const int rest = blockIdx.x / a.H;
@@ -533,8 +533,23 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(Att
     const float wreg = cnt > 0 ? 1.f / (float)cnt : 1.f;      // weight of every source this query uses
     unsigned wave_need = 0;
     for (int j = 0; j < S; ++j) wave_need |= (__ballot((inbits >> j) & 1u) != 0ull) ? (1u << j) : 0u;
-    if (tid == 0) *need_w = 0u;
-    // constant parts of the images: K pad columns [D, DK) = 0, V^T ones row (row sums), for every resident slot
+    // Sources this BLOCK stages: decided from the box table alone (scalar arithmetic, no vote / barrier before the loads are
+    // issued): the block's queries are feature rows y_first..y_last (columns x_first..x_last when it sits in one row); a
+    // region is staged when its box meets that range -- a superset of what the waves use (they skip per wave below) --
+    // and the context prompt always.
+    unsigned need = 1u;
+    {
+        const int qf0 = qb * 128, ql0 = min(qb * 128 + 127, a.Nq - 1);
+        const int y_first = qf0 / reg.feat_w, y_last = ql0 / reg.feat_w;
+        const int x_first = qf0 - y_first * reg.feat_w, x_last = ql0 - y_last * reg.feat_w;
+        for (int r = 0; r < reg.n_regions; ++r) {
+            bool hit = reg.box[r][0] <= y_last && reg.box[r][2] > y_first && reg.box[r][3] > reg.box[r][1];
+            if (y_first == y_last) hit = hit && reg.box[r][1] <= x_last && reg.box[r][3] > x_first;
+            need |= hit ? (2u << r) : 0u;
+        }
+    }
+    // constant parts of the images: K pad columns [D, DK) = 0, V^T ones row (row sums), for every resident slot (disjoint
+    // from what the staging stores write: made visible by the barrier that follows the first staging)
     for (int sl = 0; sl < NSP; ++sl) {
         T* Ki = Ks_ + sl * G::K_ELEMS;
         if constexpr (HD<D>::DK > D) {
@@ -546,10 +561,6 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(Att
             if (tid < G::KEYS) ones[tid] = (T)1.0f;
         }
     }
-    __syncthreads();
-    if (lane == 0 && wave_need) atomicOr(need_w, wave_need);
-    __syncthreads();
-    unsigned need = __builtin_amdgcn_readfirstlane(*need_w);    // block-uniform
 
     const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
     T* op = (T*)a.o + (int64_t)b * a.o_bs + h * D;

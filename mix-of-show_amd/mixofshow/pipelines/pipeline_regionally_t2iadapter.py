@@ -53,8 +53,12 @@ class RegionT2I_AttnProcessor:
         if key != self._kv_key:
             stacked = torch.stack([s.to(cd) for s in srcs])                     # (S, B, 77, Cc)
             S, B, M, Cc = stacked.shape
-            kv = project(attn, 'kv', [attn.to_k, attn.to_v], stacked.reshape(S * B, M, Cc), cd)
-            self._kv = kv.reshape(S, B, M, -1)
+            kv = project(attn, 'kv', [attn.to_k, attn.to_v], stacked.reshape(S * B, M, Cc), cd).reshape(S, B, M, -1)
+            if self._kv is not None and self._kv.shape == kv.shape and self._kv.dtype == kv.dtype:
+                self._kv.copy_(kv)               # in place: a captured graph may hold this address (the pipeline's graph
+                                                 # cache re-attaches the buffer, stale, before step 0 of a call)
+            else:
+                self._kv = kv
             self._kv_key = key
         return self._kv
 
@@ -275,19 +279,6 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
                 adapter_states = kp if kp is not None else sk
         if adapter_states is not None and do_cfg:
             adapter_states = [torch.cat([s] * 2, dim=0) if s.shape[0] == batch_size else s for s in adapter_states]
-        cak = {'region_list': region_list, 'height': height, 'width': width}
-        # the per-layer source K/V caches are keyed on tensor identity (address / version / shape); a new call with new
-        # prompts can re-use the very same addresses (caching allocator), so every call starts with empty caches
-        for m in self.unet.modules():
-            proc = getattr(m, 'processor', None)
-            if isinstance(proc, RegionT2I_AttnProcessor):
-                proc.reset_cache()
-
-        def unet_call(x, t):
-            residuals = [s.clone() for s in adapter_states] if adapter_states is not None else None
-            return self.unet(x, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak,
-                             down_block_additional_residuals=residuals).sample
-
         # hipGraph replay (`hipgraph=None` -> hipgraph_util.sampling_default(), on): step 0 runs eagerly (it fills the
         # per-layer source K/V caches), the UNet call is captured at step 1 and replayed from then on: 544 vs 774 ms per
         # 50-step sample. Not with forward hooks on the UNet (they would only run at capture time).
@@ -295,16 +286,65 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
             hipgraph = hipgraph_util.sampling_default()
         hipgraph = (bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
                     and not hipgraph_util.has_forward_hooks(self.unet))
+        # The captured graph is kept ACROSS calls of the same shape (prompts of the same layout, same boxes, same
+        # resolution): everything it reads besides (latents, t) -- prompt embeddings, region embeddings, adapter features,
+        # the processors' K/V caches -- lives in static tensors that a later call refreshes in place (step 0 of every call
+        # still runs eagerly: it recomputes the K/V caches into the buffers the graph holds).
         graphed = None
-        self.last_call_graphed = False
+        ent = None
+        if hipgraph:
+            gkey = (tuple(prompt_embeds.shape), prompt_embeds.dtype, height, width, bool(do_cfg),
+                    tuple((tuple(r[0].shape), tuple(float(v) for v in r[1])) for r in region_list),
+                    None if adapter_states is None else tuple(tuple(a.shape) for a in adapter_states),
+                    tuple(latents.shape), self.unet.conv_in.weight.data_ptr(), self.unet.conv_in.weight.dtype)
+            cache = self.__dict__.setdefault('_sampling_graphs', {})
+            ent = cache.get(gkey)
+            if ent is None:
+                ent = SimpleNamespace(pe=prompt_embeds.clone(), rl=[(r[0].clone(), r[1]) for r in region_list],
+                                      ad=None if adapter_states is None else [a.clone() for a in adapter_states], graphed=None)
+                while len(cache) >= 2:                       # at most two shapes resident (graphs pin their memory pools)
+                    cache.pop(next(iter(cache)))
+                cache[gkey] = ent
+            else:
+                ent.pe.copy_(prompt_embeds)
+                for (dst, _), (src, _) in zip(ent.rl, region_list):
+                    dst.copy_(src)
+                if ent.ad is not None:
+                    for dst, src in zip(ent.ad, adapter_states):
+                        dst.copy_(src)
+            prompt_embeds, region_list, adapter_states, graphed = ent.pe, ent.rl, ent.ad, ent.graphed
+        cak = {'region_list': region_list, 'height': height, 'width': width}
+        # the per-layer source K/V caches are keyed on tensor identity (address / version / shape); a new call with new
+        # prompts can re-use the very same addresses (caching allocator), so every call starts with stale caches
+        procs = [m.processor for m in self.unet.modules() if isinstance(getattr(m, 'processor', None), RegionT2I_AttnProcessor)]
+        for proc in procs:
+            proc.reset_cache()
+        if graphed is not None:
+            # the graph reads the K/V buffers it was captured with (an eager call in between gave the processors new ones):
+            # hand them back, stale, so that step 0 of this call refreshes exactly those
+            for proc, buf in ent.kv:
+                proc._kv = buf
+
+        def unet_call(x, t):
+            residuals = [s.clone() for s in adapter_states] if adapter_states is not None else None
+            return self.unet(x, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak,
+                             down_block_additional_residuals=residuals).sample
+
+        self.last_call_graphed = graphed is not None
         for i, t in enumerate(timesteps):
             model_in = torch.cat([latents] * 2) if do_cfg else latents
             model_in = self.scheduler.scale_model_input(model_in, t)
-            if hipgraph and i == 1:
+            if hipgraph and i == 1 and graphed is None:
                 graphed = hipgraph_util.try_capture(unet_call, model_in, t)
                 hipgraph = graphed is not None
                 self.last_call_graphed = hipgraph
-            noise_pred = graphed(model_in, t) if graphed is not None else unet_call(model_in, t)
+                if ent is not None:
+                    ent.graphed = graphed
+                    ent.kv = [(proc, proc._kv) for proc in procs if proc._kv is not None]   # owned by the entry
+                    if graphed is None:
+                        self._sampling_graphs.pop(gkey, None)
+            use_graph = graphed is not None and i >= 1
+            noise_pred = graphed(model_in, t) if use_graph else unet_call(model_in, t)
             if do_cfg:
                 uncond, text = noise_pred.chunk(2)
                 noise_pred = uncond + guidance_scale * (text - uncond)

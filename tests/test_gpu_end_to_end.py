@@ -257,14 +257,17 @@ def _hot_path_error(name, setup, regional, residuals_fn=None):
 
 def _fp16_pipeline_band(name, setup, regional):
     """fp16 pipeline (the benchmarked dtype): HIP no further from exact attention than the reference's fp16 path.
-    The shared (non-attention) operators are made run-to-run deterministic for this test -- MIOpen in deterministic mode
-    (no split-K atomics) -- so that "reference vs itself" is the noise floor the other differences are read against."""
-    det = torch.backends.cudnn.deterministic
-    torch.backends.cudnn.deterministic = True
+    The shared (non-attention) 3x3 convolutions ALL run on the library's deterministic implicit-GEMM kernel for this test
+    (product default: MIOpen below 4096 output pixels, whose split-K kernels accumulate with atomics), so that "reference
+    vs itself" is the noise floor the other differences are read against. (MIOpen's own deterministic mode was tried:
+    > 4 minutes per 50-step loop on this box.)"""
+    from mixofshow.hip import functional as F_hip
+    saved = F_hip._conv_min_pixels
+    F_hip._conv_min_pixels = 0
     try:
         _fp16_pipeline_band_body(name, setup, regional)
     finally:
-        torch.backends.cudnn.deterministic = det
+        F_hip._conv_min_pixels = saved
 
 
 def _fp16_pipeline_band_body(name, setup, regional):
@@ -272,6 +275,10 @@ def _fp16_pipeline_band_body(name, setup, regional):
     hip_procs = {n: m.processor for n, m in pipe.unet.named_modules() if m.__class__.__name__ == 'Attention'}
     rec_free = _denoise_loop(pipe, emb, latents, cak=cak)
     _install_oracle(pipe, regional)
+    # one discarded call first: the FIRST evaluation of a convolution shape goes through MIOpen's find step, which may
+    # return the result of another algorithm than the one used afterwards (that, not atomics, is what made "two runs of
+    # the same loop" differ by ~3 ulp)
+    _denoise_loop(pipe, emb, latents, cak=cak, steps=2)
     rec_ref = _denoise_loop(pipe, emb, latents, cak=cak)                        # the reference path, fp16
     forced = [r[0] for r in rec_ref]
     rec_ref2 = _denoise_loop(pipe, emb, latents, cak=cak, forced=forced)       # same path again: run-to-run noise
@@ -294,6 +301,11 @@ def _fp16_pipeline_band_body(name, setup, regional):
     assert hr <= 1.15 * rr + 1e-5, f'{name}: HIP rms error {hr:.3e} vs reference path {rr:.3e} (both against exact)'
     assert he <= 1.5 * re_ + ulp and hx <= 1.5 * rx + 14 * ulp, f'{name}: HIP max error outside the reference band'
     assert he <= 5e-3 and free <= 1e-1
+    if ne == 0.0 and nx == 0.0:
+        # deterministic yardstick: HIP against the reference's fp16 path DIRECTLY, in ulps of epsilon's top binade (both
+        # paths round every operator to half; they differ where the attention arithmetic differs)
+        assert pe <= re_ + he + ulp, f'{name}: HIP vs reference {pe:.3e} exceeds the sum of their distances to exact'
+        assert pr <= 1.5 * max(rr, hr), f'{name}: HIP vs reference rms {pr:.3e}'
 
 
 def test_edlora_sd15_hot_path_error_teacher_forced():
@@ -341,6 +353,36 @@ def test_edlora_sd15_fp16_pipeline_inside_reference_band():
 
 def test_regional_sd15_fp16_pipeline_inside_reference_band():
     _fp16_pipeline_band('regional sd15 512x768', lambda dt: _regional_setup('sd15', dt), True)
+
+
+def test_regional_sampling_graph_is_reused_across_calls_and_refreshed():
+    """The captured UNet graph is kept across `pipe(...)` calls of the same shape; prompt / region embeddings, adapter
+    features and the processors' K/V caches are refreshed IN PLACE (step 0 of every call runs eagerly). A second call with
+    OTHER prompts must reproduce the eager result of those prompts -- not the first call's."""
+    from bench import regional_prompt, synthetic_adapter_states
+    pipe, _, _, latents = _regional_setup('small')
+    H, W = 512, 768
+    p1, neg = regional_prompt(H, W)
+    p2 = [('two wizards in a forest, oil painting', [(r[0].replace('castle', 'lake'), r[1], r[2]) for r in p1[0][1]])]
+    ad = synthetic_adapter_states(pipe, H, W, DEV, torch.float16)
+
+    def run(prompt, g):
+        return pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=12, guidance_scale=7.5,
+                    latents=latents.clone().cpu(), output_type='latent', hipgraph=g, adapter_states=ad).images.float()
+
+    a_graph = run(p1, True)
+    assert pipe.last_call_graphed and len(pipe._sampling_graphs) == 1
+    b_graph = run(p2, True)                      # cache hit: no new capture, statics refreshed
+    assert pipe.last_call_graphed and len(pipe._sampling_graphs) == 1
+    b_eager = run(p2, False)
+    a_eager = run(p1, False)
+    a_again = run(p1, True)
+    scale = max(1.0, _absmax(b_eager))
+    d_b, d_a, d_ab = _absmax(b_graph - b_eager) / scale, _absmax(a_again - a_eager) / scale, _absmax(a_eager - b_eager) / scale
+    print(f'[parity] regional graph reuse (small, 12 steps): replayed vs eager, prompts B {d_b:.3e}, prompts A again {d_a:.3e}; '
+          f'prompts A vs B differ by {d_ab:.3e}')
+    assert d_ab > 20 * max(d_a, d_b, 1e-4), 'fixture: the two prompt sets should give clearly different latents'
+    assert d_b <= 0.05 and d_a <= 0.05 and _absmax(a_graph - a_again) / scale <= 0.05
 
 
 def test_pipeline_call_equals_written_out_loop():

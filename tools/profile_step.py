@@ -22,6 +22,8 @@ def main():
     ap.add_argument('--mode', default='train')
     ap.add_argument('--precision', default='fp16')
     ap.add_argument('--rows', type=int, default=70)
+    ap.add_argument('--ops', type=int, default=0, help='also attribute the ATen elementwise / copy / fill kernels to the Python '
+                    'source lines that launched them (top N rows)')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     if args.mode == 'train':
@@ -46,7 +48,7 @@ def main():
         fn()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / n
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=bool(args.ops)) as prof:
         fn()
         torch.cuda.synchronize()
     # device-side kernel records only (operator rows double count their kernels)
@@ -96,6 +98,29 @@ def main():
     print()
     for t, c, k in rows[:args.rows]:
         print(f'{t / 1e3:9.3f} ms {100 * t / busy:5.1f}%  x{c:<5d} {k[:150]}')
+    if args.ops:
+        # ATen ops (not this library's kernels): device time by operator and by the innermost frames inside this repository
+        want = ('aten::add', 'aten::add_', 'aten::copy_', 'aten::mul', 'aten::mul_', 'aten::fill_', 'aten::zero_', 'aten::cat',
+                'aten::sub', 'aten::div', 'aten::where', 'aten::sum', 'aten::mean', 'aten::neg', 'aten::sigmoid', 'aten::silu',
+                'aten::clone', 'aten::_to_copy', 'aten::contiguous', 'aten::zeros', 'aten::zeros_like', 'aten::empty_like')
+        agg2 = {}
+        for e in prof.key_averages(group_by_stack_n=12):
+            if e.key not in want:
+                continue
+            t = getattr(e, 'self_device_time_total', None)
+            if t is None:
+                t = e.self_cuda_time_total
+            if t <= 0:
+                continue
+            frames = [f for f in (e.stack or []) if ('mixofshow' in f or 'bench.py' in f or 'train_loop' in f) and 'profile_step' not in f]
+            where = ' <- '.join(f.split('/')[-1].strip() for f in frames[:3]) or '(torch internals / autograd engine)'
+            a = agg2.setdefault((e.key, where), [0.0, 0])
+            a[0] += t
+            a[1] += e.count
+        print()
+        print('ATen operator device time by launching source line (self device time):')
+        for (op, where), (t, c) in sorted(agg2.items(), key=lambda kv: -kv[1][0])[:args.ops]:
+            print(f'{t / 1e3:9.3f} ms  x{c:<5d} {op:18s} {where[:170]}')
 
 
 if __name__ == '__main__':
