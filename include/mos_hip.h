@@ -146,6 +146,27 @@ int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64
                               const mos_lora_grad_out* grads_host, void* ws,
                               int M, int N, int K, int lora_cols, int dtype, void* stream);
 
+/* Batched form of the last step of mos_lora_linear_fused_bwd. `_deferred` runs dx + dt and the token reduction of both
+ * factor gradients but NOT the ordered final sum: it fills *rec_host with what that sum needs (pointers into `ws`, which the
+ * caller keeps alive, and the gradient targets). After the backward pass the caller uploads the records of all groups
+ * (block_begin = running sum of n_blocks) and ONE mos_lora_grad_final_all launch (total_blocks = sum of n_blocks) writes /
+ * accumulates every LoRA factor gradient of the step (edlora.py:244-246 has ~100 such layers in SD-1.5 + CLIP): same
+ * summation order as the per-group form, bit-identical results. */
+typedef struct {
+    const float* partial[2];
+    int C[2], cb[2];
+    int nchunk, nj, block_begin, n_blocks;
+    mos_lora_grad_out out;
+} mos_lora_final_rec;
+int mos_lora_linear_fused_bwd_deferred(const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                                       const void* Wt, int64_t ldwt, const void* t,
+                                       const void* A16T, const void* BpT,
+                                       void* dt, void* dx, int64_t lddx,
+                                       const mos_lora_grad_out* grads_host, void* ws,
+                                       int M, int N, int K, int lora_cols, int dtype, void* stream,
+                                       mos_lora_final_rec* rec_host);
+int mos_lora_grad_final_all(const mos_lora_final_rec* recs_dev, int n_recs, int total_blocks, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused attention core: softmax(scale * Q K^T) V with online softmax, no materialised P.
  * Replaces attn.get_attention_scores + torch.bmm / xformers.memory_efficient_attention in
@@ -208,7 +229,8 @@ int mos_cross_attn_fwd(const void* q, const void* k, const void* v, void* o, flo
  *          = sum_{r covers q} attn(q, K_r, V_r) / count(q)   otherwise (replace_ratio = 1.0)
  * Source 0 is the context prompt (base attention); sources 1..n_regions are regions with
  * integer feature-map boxes [h0,h1) x [w0,w1) (already ceil/floor-rounded per :38-39 by host).
- *   k_src / v_src: [n_src][B, Nkv, H*d] with strides src_stride (between sources), k_bs, k_rs.
+ *   k_src / v_src: [n_src][B, Nkv, H*d] with strides src_stride (between sources), k_bs, k_rs;
+ *   65 <= Nkv <= 96 (CLIP's 77-token context: three 32-key sub-tiles of one LDS residency).
  * Inference only (no backward in the reference: pipeline __call__ is @torch.no_grad, :301).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -301,6 +323,11 @@ int mos_geglu_fwd(const void* h, void* y, int64_t rows, int F, int dtype, void* 
  * mid-block attention (single head, d = 512, N = 4096) as scores GEMM -> this -> values GEMM on the library's GEMM. */
 int mos_softmax_rows(const void* x, void* y, int rows, int N, float scale, int dtype, void* stream);
 int mos_geglu_bwd(const void* dy, const void* h, void* dh, int64_t rows, int F, int dtype, void* stream);
+/* quick-GELU of the CLIP text tower MLP (transformers `quick_gelu`, the activation of SD-1.5's text encoder that
+ * EDLoRATrainer.forward runs under LoRA, trainer_edlora.py:216-223): y = x * sigmoid(1.702 x) over n contiguous elements
+ * (n % 8 == 0), and dx = dy * d/dx[x sigmoid(1.702 x)]. */
+int mos_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int mos_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -689,6 +689,66 @@ __global__ __launch_bounds__(256) void lora_grad_final_kernel(const LoraGradArgs
     }
 }
 
+// The same ordered final sum for EVERY LoRA group of a backward pass in ONE launch (records in device memory, like
+// lora_pack_all): ~90 final-sum launches per training step become one. Block -> record by the records' block_begin.
+__global__ __launch_bounds__(256) void lora_grad_final_all_kernel(const mos_lora_final_rec* __restrict__ recs, int n_recs) {
+    __shared__ mos_lora_final_rec rec;
+    __shared__ int which;
+    if (threadIdx.x == 0) {
+        int w = 0;
+        for (int i = 1; i < n_recs; ++i)
+            if ((int)blockIdx.x >= recs[i].block_begin) w = i;
+        which = w;
+    }
+    __syncthreads();
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(recs + which);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&rec);
+        for (int i = threadIdx.x; i < (int)(sizeof(mos_lora_final_rec) / 4); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int blk = (int)blockIdx.x - rec.block_begin;
+    const int job = blk >= rec.cb[0] ? 1 : 0;
+    const int colblk = blk - (job ? rec.cb[0] : 0);
+    const int C = rec.C[job], NJ = rec.nj, r = rec.out.rank;
+    const float* part = rec.partial[job];
+    for (int idx = threadIdx.x; idx < NJ * 64; idx += 256) {
+        const int j = idx >> 6, c = idx & 63;
+        const int col = colblk * 64 + c;
+        if (col >= C) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        const float* pp = part + (int64_t)j * C + col;
+        const int64_t cs = (int64_t)NJ * C;
+        int ch = 0;
+        for (; ch + 4 <= rec.nchunk; ch += 4) {
+            s0 += pp[(ch + 0) * cs];
+            s1 += pp[(ch + 1) * cs];
+            s2 += pp[(ch + 2) * cs];
+            s3 += pp[(ch + 3) * cs];
+        }
+        for (; ch < rec.nchunk; ++ch) s0 += pp[ch * cs];
+        const float s = (s0 + s1) + (s2 + s3);     // same association as lora_grad_final_kernel: bit-identical results
+        const int g = j / r;
+        if (g >= rec.out.n_sites) continue;
+        const int jj = j - g * r;
+        if (job == 0) {
+            float* dst = rec.out.down_grad[g];
+            if (dst != nullptr) {
+                float* q = dst + (int64_t)jj * C + col;
+                *q = rec.out.accumulate_down[g] ? (*q + s) : s;
+            }
+        } else {
+            float* dst = rec.out.up_grad[g];
+            const int nn = col - rec.out.n_begin[g];
+            if (dst != nullptr && nn >= 0 && nn < rec.out.n_rows[g]) {
+                float* q = dst + (int64_t)nn * r + jj;
+                const float v = rec.out.alpha[g] * s;
+                *q = rec.out.accumulate_up[g] ? (*q + v) : v;
+            }
+        }
+    }
+}
+
 inline void lora_grad_plan(int M, int N, int K, int* rpc, int* nchunk) {
     const int cbt = (K + 63) / 64 + (N + 63) / 64;
     int nc = (MOS_GRAD_TARGET_WG + cbt - 1) / cbt;
@@ -704,7 +764,7 @@ inline void lora_grad_plan(int M, int N, int K, int* rpc, int* nchunk) {
 template <typename T>
 int launch_lora_grad(const void* dt, const void* x, int64_t ldx, const void* t, const void* dy, int64_t lddy, float* rawA,
                      float* rawB, const mos_lora_grad_out* out, float* ws, int M, int N, int K, int cols,
-                     hipStream_t st) {
+                     hipStream_t st, mos_lora_final_rec* defer = nullptr) {
     LoraGradArgs a;
     a.P[0] = dt; a.Z[0] = x; a.ldz[0] = ldx; a.C[0] = K; a.cb[0] = (K + 63) / 64;
     a.P[1] = t; a.Z[1] = dy; a.ldz[1] = lddy; a.C[1] = N; a.cb[1] = (N + 63) / 64;
@@ -720,6 +780,19 @@ int launch_lora_grad(const void* dt, const void* x, int64_t ldx, const void* t, 
     MosProfScope prof(st, "lora_grad", key, 2.0 * M * (double)nj * ((double)K + N), 2.0 * ((double)M * ((double)K + N) + 32.0 * M));
     dim3 grid(a.nchunk, a.cb[0] + a.cb[1]);
     dim3 fgrid(a.cb[0] + a.cb[1]);
+    if (defer != nullptr) {      // token reduction only; the caller batches the final sums (mos_lora_grad_final_all)
+        switch (nj) {
+            case 4: hipLaunchKernelGGL((lora_grad_kernel<T, 4>), grid, dim3(256), 0, st, a); break;
+            case 8: hipLaunchKernelGGL((lora_grad_kernel<T, 8>), grid, dim3(256), 0, st, a); break;
+            case 12: hipLaunchKernelGGL((lora_grad_kernel<T, 12>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((lora_grad_kernel<T, 16>), grid, dim3(256), 0, st, a); break;
+        }
+        defer->partial[0] = a.partial[0]; defer->partial[1] = a.partial[1];
+        defer->C[0] = a.C[0]; defer->C[1] = a.C[1]; defer->cb[0] = a.cb[0]; defer->cb[1] = a.cb[1];
+        defer->nchunk = a.nchunk; defer->nj = nj; defer->block_begin = 0; defer->n_blocks = a.cb[0] + a.cb[1];
+        defer->out = a.out;
+        return mos_check_launch("lora_grad");
+    }
     switch (nj) {
         case 4: hipLaunchKernelGGL((lora_grad_kernel<T, 4>), grid, dim3(256), 0, st, a);
                 hipLaunchKernelGGL((lora_grad_final_kernel<4>), fgrid, dim3(256), 0, st, a); break;
@@ -947,10 +1020,10 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
     return MOS_OK;
 }
 
-int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
-                              const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
-                              const mos_lora_grad_out* grads_host, void* ws, int M, int N, int K,
-                              int lora_cols, int dtype, void* stream) {
+static int fused_bwd_impl(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
+                          const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
+                          const mos_lora_grad_out* grads_host, void* ws, int M, int N, int K,
+                          int lora_cols, int dtype, void* stream, mos_lora_final_rec* defer) {
     MOS_REQUIRE(dy && x && t && A16T && BpT && dt, "mos_lora_linear_fused_bwd: NULL argument");
     MOS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0,
                 "mos_lora_linear_fused_bwd: M=%d N=%d K=%d lddy=%lld ldx=%lld", M, N, K, (long long)lddy, (long long)ldx);
@@ -974,8 +1047,36 @@ int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64
     }
     if (rc) return rc;
     if (grads_host == nullptr) return MOS_OK;
-    return h ? launch_lora_grad<f16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st)
-             : launch_lora_grad<bf16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st);
+    return h ? launch_lora_grad<f16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st, defer)
+             : launch_lora_grad<bf16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st, defer);
 }
+
+int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
+                              const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
+                              const mos_lora_grad_out* grads_host, void* ws, int M, int N, int K,
+                              int lora_cols, int dtype, void* stream) {
+    return fused_bwd_impl(dy, lddy, x, ldx, Wt, ldwt, t, A16T, BpT, dt, dx, lddx, grads_host, ws, M, N, K, lora_cols, dtype,
+                          stream, nullptr);
+}
+
+int mos_lora_linear_fused_bwd_deferred(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
+                                       const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
+                                       const mos_lora_grad_out* grads_host, void* ws, int M, int N, int K,
+                                       int lora_cols, int dtype, void* stream, mos_lora_final_rec* rec_host) {
+    MOS_REQUIRE(rec_host && grads_host, "mos_lora_linear_fused_bwd_deferred: needs grads_host and rec_host");
+    return fused_bwd_impl(dy, lddy, x, ldx, Wt, ldwt, t, A16T, BpT, dt, dx, lddx, grads_host, ws, M, N, K, lora_cols, dtype,
+                          stream, rec_host);
+}
+
+int mos_lora_grad_final_all(const mos_lora_final_rec* recs_dev, int n_recs, int total_blocks, void* stream) {
+    MOS_REQUIRE(recs_dev && n_recs > 0 && total_blocks > 0, "mos_lora_grad_final_all: n_recs=%d total_blocks=%d", n_recs, total_blocks);
+    hipStream_t st = (hipStream_t)stream;
+    char key[48];
+    snprintf(key, sizeof(key), "groups%d blocks%d", n_recs, total_blocks);
+    MosProfScope prof(st, "lora_grad_final_all", key, 0.0, 0.0);
+    hipLaunchKernelGGL(lora_grad_final_all_kernel, dim3(total_blocks), dim3(256), 0, st, recs_dev, n_recs);
+    return mos_check_launch("lora_grad_final_all");
+}
+
 
 }  // extern "C"

@@ -85,16 +85,84 @@ def set_direct_grad_accumulation(flag):
     _direct_grad = bool(flag)
 
 
+class _DeferredFinals:
+    """The ordered final sums of the LoRA factor gradients of one backward pass, batched into ONE launch
+    (mos_lora_grad_final_all) instead of one per projection group (~90 per SD-1.5 training step). Workspaces are persistent
+    per group, so the record table is identical from step to step: it is uploaded once (in place, fixed-capacity buffer) and
+    a captured hipGraph replays the single launch with the table it was captured with."""
+
+    def __init__(self):
+        self.ws = {}
+        self.pending = []
+        self.used = set()
+        self.table = None
+        self.table_bytes = None
+        self.capacity = 512
+
+    def workspace(self, key, n_floats, device):
+        t = self.ws.get(key)
+        if t is None or t.numel() < n_floats or t.device != device:
+            t = torch.empty(n_floats, dtype=torch.float32, device=device)
+            self.ws[key] = t
+        return t
+
+    def flush(self):
+        import ctypes
+        from . import lib as _lib
+        recs, self.pending = self.pending, []
+        if not recs:
+            return
+        assert len(recs) <= self.capacity, 'too many deferred LoRA gradient groups'
+        begin = 0
+        for r in recs:
+            r.block_begin = begin
+            begin += r.n_blocks
+        raw = bytes((_lib.LoraFinalRec * len(recs))(*recs))
+        dev = torch.device('cuda', torch.cuda.current_device())
+        if self.table is None or self.table.device != dev:
+            self.table = torch.zeros(self.capacity * ctypes.sizeof(_lib.LoraFinalRec), dtype=torch.uint8, device=dev)
+            self.table_bytes = None
+        if raw != self.table_bytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('LoRA gradient record table changed during hipGraph capture (warm-up steps must precede it)')
+            self.table[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            self.table_bytes = raw
+        ops.lora_grad_final_all(self.table, len(recs), begin)
+
+
+_deferred_finals = None      # a _DeferredFinals while a direct_grad_accumulation(defer_finals=True) scope is open
+
+
 class direct_grad_accumulation:
-    """with direct_grad_accumulation(): ... — scoped form of set_direct_grad_accumulation(True)."""
+    """with direct_grad_accumulation(): ... — scoped form of set_direct_grad_accumulation(True). `defer_finals` (HIP device
+    only): the per-group final sums of the LoRA factor gradients are collected during the backward pass and issued as one
+    launch when the scope closes (the caller runs forward AND backward inside the scope)."""
+    _store = None
+
+    def __init__(self, defer_finals=False):
+        self.defer = bool(defer_finals)
 
     def __enter__(self):
-        global _direct_grad
+        global _direct_grad, _deferred_finals
         self.prev, _direct_grad = _direct_grad, True
+        self.prev_def = _deferred_finals
+        if self.defer:
+            if direct_grad_accumulation._store is None:
+                direct_grad_accumulation._store = _DeferredFinals()
+            _deferred_finals = direct_grad_accumulation._store
+            _deferred_finals.pending = []
+            _deferred_finals.used = set()
+        return self
 
-    def __exit__(self, *exc):
-        global _direct_grad
-        _direct_grad = self.prev
+    def __exit__(self, exc_type, *exc):
+        global _direct_grad, _deferred_finals
+        store = _deferred_finals if self.defer else None
+        _direct_grad, _deferred_finals = self.prev, self.prev_def
+        if store is not None:
+            if exc_type is None:
+                store.flush()
+            else:
+                store.pending = []
         return False
 
 
@@ -318,7 +386,18 @@ class _LoRALinear(torch.autograd.Function):
                             pair.append(gt)
                             accs.append(False)
                     targets.append((pair[0], pair[1], ctx.alphas[g], ctx.params[2 * g + 1].shape[0], accs[0], accs[1]))
-            dx = ops.linear_fused_bwd(dy2, x2, Wt16, t, A16T, BpT, targets, ctx.rank, need_dx=need_dx)
+            st = _deferred_finals
+            wkey = (BpT.data_ptr(), dy2.shape[0], dy2.shape[1], x2.shape[1])
+            if st is not None and targets is not None and all(a and b for (_, _, _, _, a, b) in targets) \
+                    and all(d is not None and u is not None for (d, u, *_r) in targets) and wkey not in st.used:
+                st.used.add(wkey)        # (a layer called twice inside one scope: its second call sums immediately)
+                # every gradient of this group is accumulated in place into an existing `.grad`: its final sum can wait
+                dx, rec = ops.linear_fused_bwd(dy2, x2, Wt16, t, A16T, BpT, targets, ctx.rank, need_dx=need_dx,
+                                               defer=lambda key, n: st.workspace(key, n, dy2.device))
+                if rec is not None:
+                    st.pending.append(rec)
+            else:
+                dx = ops.linear_fused_bwd(dy2, x2, Wt16, t, A16T, BpT, targets, ctx.rank, need_dx=need_dx)
         if dx is not None:
             dx = dx.view(ctx.x_shape)
             if dx.dtype != ctx.x_dtype:
@@ -535,6 +614,30 @@ class _GEGLU(torch.autograd.Function):
         if d2.dtype != h2.dtype or not d2.is_contiguous():
             d2 = d2.to(h2.dtype).contiguous()
         return ops.geglu_bwd(d2, h2).view(*dy.shape[:-1], h2.shape[-1])
+
+
+class _QuickGELU(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x):
+        xc = x if x.is_contiguous() else x.contiguous()
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(xc)
+        return ops.quick_gelu_fwd(xc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc, ) = ctx.saved_tensors
+        d = dy if (dy.dtype == xc.dtype and dy.is_contiguous()) else dy.to(xc.dtype).contiguous()
+        return ops.quick_gelu_bwd(d, xc)
+
+
+def quick_gelu(x):
+    """x * sigmoid(1.702 x) (CLIP text tower MLP). HIP path for half device tensors: one kernel each way instead of three
+    elementwise launches forward and five backward."""
+    if x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.numel() % 8 == 0:
+        return _QuickGELU.apply(x)
+    return x * torch.sigmoid(1.702 * x)
 
 
 def geglu(h):

@@ -59,6 +59,16 @@ class LoraGradOut(ctypes.Structure):
     ]
 
 
+class LoraFinalRec(ctypes.Structure):          # mos_lora_final_rec
+    _fields_ = [
+        ('partial', ctypes.c_void_p * 2),
+        ('C', ctypes.c_int * 2),
+        ('cb', ctypes.c_int * 2),
+        ('nchunk', ctypes.c_int), ('nj', ctypes.c_int), ('block_begin', ctypes.c_int), ('n_blocks', ctypes.c_int),
+        ('out', LoraGradOut),
+    ]
+
+
 class AttnShape(ctypes.Structure):
     _fields_ = [
         ('B', ctypes.c_int), ('H', ctypes.c_int), ('Nq', ctypes.c_int), ('Nkv', ctypes.c_int), ('d', ctypes.c_int),
@@ -105,6 +115,10 @@ SIGNATURES = {
     'mos_lora_linear_fused_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     'mos_lora_linear_fused_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
                                        ctypes.POINTER(LoraGradOut), _vp, _i, _i, _i, _i, _i, _vp]),
+    'mos_lora_linear_fused_bwd_deferred': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
+                                                ctypes.POINTER(LoraGradOut), _vp, _i, _i, _i, _i, _i, _vp,
+                                                ctypes.POINTER(LoraFinalRec)]),
+    'mos_lora_grad_final_all': (_i, [_vp, _i, _i, _vp]),
     'mos_lora_down': (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
     'mos_lora_linear_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     'mos_lora_bwd_workspace_bytes': (_i64, [_i, _i, _i]),
@@ -132,6 +146,8 @@ SIGNATURES = {
     'mos_geglu_fwd': (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     'mos_softmax_rows': (_i, [_vp, _vp, _i, _i, _f, _i, _vp]),
     'mos_geglu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    'mos_quick_gelu_fwd': (_i, [_vp, _vp, _i64, _i, _vp]),
+    'mos_quick_gelu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     'mos_lsq_workspace_bytes': (_i64, [_i, _i]),
     'mos_lsq_loss_grad_gram': (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),
 }

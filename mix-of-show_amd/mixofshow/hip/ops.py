@@ -136,10 +136,12 @@ def linear_fused_fwd(x, W, A16, Bp16, bias=None, need_t=True):
     return y, t
 
 
-def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True):
+def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True, defer=None):
     """Backward of linear_fused_fwd in three launches (dx+dt; token reduction of both factor gradients; ordered final sum). grad_targets: None (LoRA factors frozen) or a list with one
     (down_grad, up_grad, alpha, n_rows, accumulate_down, accumulate_up) per site — fp32 contiguous tensors shaped like the parameters (either
-    may be None); the kernel writes / accumulates into them directly. Returns dx | None."""
+    may be None); the kernel writes / accumulates into them directly. Returns dx | None.
+    defer: None, or a callable (ws_key, nbytes) -> persistent fp32 workspace tensor; then the final sum is NOT launched and
+    the (LoraFinalRec, ws) pair is returned as the second value for lora_grad_final_all."""
     _dev(dy, x, Wt, t, A16T, BpT)
     M, N = dy.shape
     K = x.shape[1]
@@ -168,12 +170,27 @@ def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True):
             n0 += int(n_rows)
         assert n0 == N
         cols = g.n_sites * g.rank
-        ws = torch.empty((L.mos_lora_bwd_workspace_bytes(M, N, K) + 3) // 4, dtype=torch.float32, device=dev)
+        nws = (L.mos_lora_bwd_workspace_bytes(M, N, K) + 3) // 4
+        if defer is not None:
+            ws = defer((BpT.data_ptr(), M, N, K), nws)
+            rec = _lib.LoraFinalRec()
+            _lib.check(L.mos_lora_linear_fused_bwd_deferred(
+                _p(dy), _rows(dy), _p(x), _rows(x), _p(Wt), _rows(Wt) if Wt is not None else 0, _p(t), _p(A16T), _p(BpT), _p(dt),
+                _p(dx), _rows(dx) if dx is not None else 0, ctypes.byref(g), _p(ws), M, N, K, int(cols), _dt(dy), _stream(),
+                ctypes.byref(rec)), 'mos_lora_linear_fused_bwd_deferred')
+            return dx, rec
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
     _lib.check(L.mos_lora_linear_fused_bwd(_p(dy), _rows(dy), _p(x), _rows(x), _p(Wt), _rows(Wt) if Wt is not None else 0,
                                            _p(t), _p(A16T), _p(BpT), _p(dt), _p(dx), _rows(dx) if dx is not None else 0,
                                            ctypes.byref(g) if g is not None else None, _p(ws), M, N, K, int(cols),
                                            _dt(dy), _stream()), 'mos_lora_linear_fused_bwd')
-    return dx
+    return (dx, None) if defer is not None else dx
+
+
+def lora_grad_final_all(recs_dev, n_recs, total_blocks):
+    """ONE launch: the ordered final sums of every deferred LoRA gradient group (records uploaded by the caller)."""
+    L = _lib.load()
+    _lib.check(L.mos_lora_grad_final_all(_p(recs_dev), int(n_recs), int(total_blocks), _stream()), 'mos_lora_grad_final_all')
 
 
 def lora_down(x, A16):
@@ -436,6 +453,25 @@ def geglu_bwd(dy, h):
     L = _lib.load()
     _lib.check(L.mos_geglu_bwd(_p(dy), _p(h), _p(dh), rows, F2 // 2, _dt(h), _stream()), 'mos_geglu_bwd')
     return dh
+
+
+def quick_gelu_fwd(x):
+    """x * sigmoid(1.702 x) of a contiguous half tensor (numel % 8 == 0): the CLIP text tower's MLP activation."""
+    _dev(x)
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    y = torch.empty_like(x)
+    L = _lib.load()
+    _lib.check(L.mos_quick_gelu_fwd(_p(x), _p(y), x.numel(), _dt(x), _stream()), 'mos_quick_gelu_fwd')
+    return y
+
+
+def quick_gelu_bwd(dy, x):
+    _dev(dy, x)
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape == x.shape and dy.dtype == x.dtype
+    dx = torch.empty_like(x)
+    L = _lib.load()
+    _lib.check(L.mos_quick_gelu_bwd(_p(dy), _p(x), _p(dx), x.numel(), _dt(x), _stream()), 'mos_quick_gelu_bwd')
+    return dx
 
 
 def softmax_rows(x, scale, out=None):

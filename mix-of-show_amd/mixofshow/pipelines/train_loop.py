@@ -101,7 +101,7 @@ class TrainEngine:
 
         def fwd_bwd():
             self.bucket.zero()
-            with F_hip.direct_grad_accumulation():
+            with F_hip.direct_grad_accumulation(defer_finals=dev.type == 'cuda'):
                 with torch.autocast(dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                     loss = tr(st.get('images'), None, st.get('masks', st['img_masks']), st['img_masks'],
                               noise=st.get('noise'), timesteps=st.get('timesteps'), latents=st.get('latents'),
@@ -189,7 +189,7 @@ class TrainEngine:
         images = batch['images']
         if self.channels_last and images is not None:
             images = images.contiguous(memory_format=torch.channels_last)
-        with F_hip.direct_grad_accumulation():
+        with F_hip.direct_grad_accumulation(defer_finals=dev_type == 'cuda'):
             with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                 loss = tr(images, batch['prompts'], masks, batch['img_masks'], **extra)
             self.scaler.scale(loss / self.grad_accum).backward()

@@ -9,7 +9,7 @@ import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
             'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd',
-            'geglu_fwd', 'geglu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
+            'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
 PAD = 16
 
 
@@ -237,6 +237,17 @@ def geglu_bwd(dy, h):
     pdf = 0.3989422804014327 * torch.exp(-0.5 * g * g)
     d = dy.float()
     return torch.cat([d * g * cdf, d * a * (cdf + g * pdf)], -1).to(h.dtype)
+
+
+def quick_gelu_fwd(x):
+    z = x.float()
+    return (z * torch.sigmoid(1.702 * z)).to(x.dtype)
+
+
+def quick_gelu_bwd(dy, x):
+    z = x.float()
+    sg = torch.sigmoid(1.702 * z)
+    return (dy.float() * sg * (1 + 1.702 * z * (1 - sg))).to(x.dtype)
 
 
 def softmax_rows(x, scale, out=None):

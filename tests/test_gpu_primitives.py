@@ -414,6 +414,63 @@ def test_layernorm(ops, emu, dtype, rows, C):
     _check('layernorm.dx (emulation formula)', emu.layernorm_bwd(dy, x, gamma, stats_ref), dx_ref, dtype, ulps=3.0)
 
 
+def test_lora_gradient_finals_deferred_equal_immediate():
+    """TrainEngine's scope batches the ordered final sums of all LoRA gradient groups into ONE launch
+    (mos_lora_grad_final_all): bit-identical `.grad`s to the per-group final sums, also on a second pass (persistent
+    workspaces, unchanged record table) and with accumulation into existing gradients."""
+    from mixofshow.hip import functional as F_hip
+    torch.manual_seed(3)
+    dev = 'cuda'
+    layers = []
+    for (K, N) in ((320, 960), (768, 2304), (640, 640)):
+        W = (torch.randn(N, K, device=dev) / K**0.5).half()
+        sites, n_sites = [], 3 if N % 3 == 0 and N != K else 1
+        for _ in range(n_sites):
+            down = torch.nn.Parameter(torch.randn(4, K, device=dev) * 0.05)
+            up = torch.nn.Parameter(torch.randn(N // n_sites, 4, device=dev) * 0.05)
+            sites.append((down, up, 0.7))
+        layers.append((W, W.t().contiguous(), sites))
+    xs = [torch.randn(2, 300, W.shape[1], device=dev).half().requires_grad_(True) for W, _, _ in layers]
+
+    def run(deferred, passes):
+        for _, _, sites in layers:
+            for d, u, _ in sites:
+                d.grad, u.grad = torch.full_like(d, 0.25), torch.full_like(u, -0.5)     # accumulate on top of these
+        for _ in range(passes):
+            scope = F_hip.direct_grad_accumulation(defer_finals=deferred)
+            with scope:
+                loss = 0
+                for (W, Wt, sites), x in zip(layers, xs):
+                    loss = loss + F_hip.lora_linear(x, W, Wt, None, sites).float().square().mean()
+                loss.backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for _, _, sites in layers for d, u, _ in sites for p in (d, u)]
+
+    for passes in (1, 2):
+        a, b = run(False, passes), run(True, passes)
+        assert all(torch.equal(x, y) for x, y in zip(a, b)), f'deferred final sums differ after {passes} pass(es)'
+        assert all(torch.isfinite(x).all() and (x != 0.25).any() for x in a)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(64, 77, 3072), (3, 5, 24), (1, 8)])
+def test_quick_gelu(ops, emu, dtype, shape):
+    """CLIP text tower MLP activation x * sigmoid(1.702 x): forward and backward vs fp32 torch autograd (+ the emulation)."""
+    g = torch.Generator(device='cpu').manual_seed(21)
+    x = (torch.randn(*shape, generator=g) * 2.0).to('cuda', dtype)
+    dy = torch.randn(*shape, generator=g).to('cuda', dtype)
+    xr = x.float().requires_grad_(True)
+    y_ref = xr * torch.sigmoid(1.702 * xr)
+    (dx_ref, ) = torch.autograd.grad(y_ref, xr, dy.float())
+    _check(f'quick_gelu.y{list(shape)}', ops.quick_gelu_fwd(x), y_ref.detach(), dtype, ulps=1.0)
+    _check('quick_gelu.dx', ops.quick_gelu_bwd(dy, x), dx_ref, dtype, ulps=1.0)
+    _check('quick_gelu.dx (emulation formula)', emu.quick_gelu_bwd(dy, x), dx_ref, dtype, ulps=1.0)
+    from mixofshow.hip import functional as F_hip
+    xa = x.clone().requires_grad_(True)
+    F_hip.quick_gelu(xa).backward(dy)
+    _check('quick_gelu autograd', xa.grad, dx_ref, dtype, ulps=1.0)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('rows,F', [(16384, 1280), (4096, 2560), (1024, 5120), (256, 5120), (100, 1280)])
 def test_geglu(ops, emu, dtype, rows, F):
