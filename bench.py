@@ -90,12 +90,17 @@ def synthetic_batch(B, size, device, seed):
 
 
 # ---- roofline helpers ---------------------------------------------------------------------------------------------
-def kernel_source_fingerprint():
-    """sha256 (16 hex) over the kernel sources + build recipe: the identity of the code the PMC passes profiled."""
+# the translation unit, shared header and build recipe of every kernel profiles/pmc_traffic.json covers (the attention and
+# regional kernels all live in mos_attn.hip): the PMC numbers stay valid exactly as long as these files are unchanged
+PMC_SOURCE_FILES = ('mos_attn.hip', 'mos_common.h', 'build.sh')
+
+
+def kernel_source_fingerprint(files=PMC_SOURCE_FILES):
+    """sha256 (16 hex) over the sources + build recipe of the kernels the PMC passes profiled (files=None: all of csrc/)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, 'mix-of-show_amd', 'csrc')
     for fn in sorted(os.listdir(d)):
-        if fn.endswith(('.hip', '.h', '.inc', '.sh')):
+        if fn.endswith(('.hip', '.h', '.inc', '.sh')) and (files is None or fn in files):
             with open(os.path.join(d, fn), 'rb') as f:
                 h.update(fn.encode() + b'\0' + f.read())
     return h.hexdigest()[:16]

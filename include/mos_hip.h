@@ -291,6 +291,12 @@ int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* 
 int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamma, const float* beta,
                                 const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu,
                                 int dtype, void* stream);
+/* The same with the gradient `ds` (x's shape / layout / dtype) of a residual connection that bypasses the norm:
+ * dx = round(GN_bwd(dy)) + ds -- what autograd's accumulation of the two gradients yields, without the extra elementwise
+ * launch (the inputs of ResnetBlock2D and Transformer2DModel feed both a GroupNorm and a skip path). */
+int mos_groupnorm_silu_bwd_nhwc_res(const void* dy, const void* ds, const void* x, const float* gamma, const float* beta,
+                                    const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu, int dtype,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolution on channels-last activations as an implicit GEMM (the ResnetBlock2D, Upsample2D
@@ -318,6 +324,18 @@ int mos_layernorm_fwd(const void* x, const float* gamma, const float* beta, void
                       float eps, int dtype, void* stream);
 int mos_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* stats, void* dx, int rows, int C,
                       int dtype, void* stream);
+/* Residual add fused into the LayerNorm that consumes it (transformer blocks are `x = x + f(LN(x))`; reference: the `+`
+ * of diffusers BasicTransformerBlock / transformers CLIPEncoderLayer followed by nn.LayerNorm, each a separate kernel):
+ *   forward   s = x + r (written to s_out),  y = LN(s) * gamma + beta;   r == NULL: y = LN(x), s_out ignored
+ *   backward  dx = LN_bwd(dy; s, gamma, stats) + ds;   ds == NULL: no bypass gradient;
+ *             dx_half (optional, only with stream_fp32): the same gradient rounded to `dtype` for the half branch r
+ * x / s_out / ds / s / dx live in the RESIDUAL STREAM dtype: `dtype` itself (stream_fp32 = 0, the UNet: bit-identical to
+ * add + layernorm as separate kernels) or fp32 (stream_fp32 = 1, the CLIP tower under autocast: statistics and gradient
+ * from the fp32 sum, like the reference's fp32 layer_norm). r, y, dy, dx_half are `dtype`. Shapes as mos_layernorm_*. */
+int mos_add_layernorm_fwd(const void* x, const void* r, const float* gamma, const float* beta, void* s_out, void* y,
+                          float* stats, int rows, int C, float eps, int dtype, int stream_fp32, void* stream);
+int mos_add_layernorm_bwd(const void* dy, const void* ds, const void* s, const float* gamma, const float* stats, void* dx,
+                          void* dx_half, int rows, int C, int dtype, int stream_fp32, void* stream);
 int mos_geglu_fwd(const void* h, void* y, int64_t rows, int F, int dtype, void* stream);
 /* y[r, :] = softmax(scale * x[r, :]), x / y (rows, N) contiguous in `dtype` (may alias), N % 8 == 0, N <= 8192: the VAE
  * mid-block attention (single head, d = 512, N = 4096) as scores GEMM -> this -> values GEMM on the library's GEMM. */

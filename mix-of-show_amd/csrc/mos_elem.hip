@@ -121,6 +121,160 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
 }
 
+// ---- residual add fused into LayerNorm ------------------------------------------------------------------------------
+// A transformer block is `x = x + f(LN(x))` three times over: the residual sum is an input of the NEXT LayerNorm only, and in
+// backward the LayerNorm's input gradient is added to the gradient that bypasses it. As separate kernels that is one ATen add
+// per residual forward and one per LayerNorm backward (2 x 48 launches per SD-1.5 UNet step, 4 x 24 + casts in the CLIP tower
+// whose residual stream is fp32 under autocast). Here:
+//     forward   s = x + r  (written once, stream dtype S),   y = LN(s)          (RES; without RES: y = LN(x), nothing else)
+//     backward  dx = LN_bwd(dy) + ds  (stream dtype S)  [+ a half copy of dx for the half branch of an fp32 stream]
+// S == T (half stream, UNet): s and dx are rounded exactly where the unfused kernels round (s = half(x + r); dx =
+// half(half(LN_bwd) + ds)), so results are bit-identical to add + layernorm. S == float (CLIP): statistics and gradient
+// are taken from the fp32 sum itself, as the reference's fp32 layer_norm under autocast does.
+template <typename S> struct Row8;
+template <> struct Row8<float> {
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[i + 4] = b[i]; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        f32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[i + 4]; }
+        *reinterpret_cast<f32x4*>(p) = a;
+        *reinterpret_cast<f32x4*>(p + 4) = b;
+    }
+    static __device__ __forceinline__ float round(float v) { return v; }
+};
+template <typename T> struct Row8 {
+    typedef typename MT<T>::v8 v8;
+    static __device__ __forceinline__ void load(const T* p, float* v) {
+        const v8 t = as_v8<T>(ld16(p));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+    static __device__ __forceinline__ void store(T* p, const float* v) {
+        v8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (T)v[i];
+        st16(p, from_v8<T>(o));
+    }
+    static __device__ __forceinline__ float round(float v) { return (float)(T)v; }
+};
+
+template <typename T, typename S, int NCH, bool RES>
+__global__ __launch_bounds__(256) void add_layernorm_fwd_kernel(const S* __restrict__ x, const T* __restrict__ r,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                S* __restrict__ s_out, T* __restrict__ y,
+                                                                float* __restrict__ stats, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = C >> 3;
+    const S* xr = x + (int64_t)row * C;
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < nch) {
+            Row8<S>::load(xr + ch * 8, v[k]);
+            if constexpr (RES) {
+                float rv[8];
+                Row8<T>::load(r + (int64_t)row * C + ch * 8, rv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[k][i] = Row8<S>::round(v[k][i] + rv[i]);
+                Row8<S>::store(s_out + (int64_t)row * C + ch * 8, v[k]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sum += v[k][i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[k][i] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (lane + 64 * k < nch) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = v[k][i] - mean; ss += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+    if (stats != nullptr && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    T* yr = y + (int64_t)row * C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < nch) {
+            float g[8], b[8], o[8];
+            Row8<float>::load(gamma + ch * 8, g);
+            Row8<float>::load(beta + ch * 8, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (v[k][i] - mean) * rstd * g[i] + b[i];
+            Row8<T>::store(yr + ch * 8, o);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ ds),  g = dy * gamma, xhat from the saved sum s and (mean, rstd)
+template <typename T, typename S, int NCH, bool HAS_DS, bool HALF_COPY>
+__global__ __launch_bounds__(256) void add_layernorm_bwd_kernel(const T* __restrict__ dy, const S* __restrict__ ds,
+                                                                const S* __restrict__ s, const float* __restrict__ gamma,
+                                                                const float* __restrict__ stats, S* __restrict__ dx,
+                                                                T* __restrict__ dx_half, int rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = C >> 3;
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const int64_t base = (int64_t)row * C;
+    float g[NCH][8], xh[NCH][8];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < nch) {
+            float sv[8], dv[8], gm[8];
+            Row8<S>::load(s + base + ch * 8, sv);
+            Row8<T>::load(dy + base + ch * 8, dv);
+            Row8<float>::load(gamma + ch * 8, gm);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xh[k][i] = (sv[i] - mean) * rstd;
+                g[k][i] = dv[i] * gm[i];
+                sg += g[k][i];
+                sgx += g[k][i] * xh[k][i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { g[k][i] = 0.f; xh[k][i] = 0.f; }
+        }
+    }
+    const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < nch) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = rstd * (g[k][i] - mg - xh[k][i] * mgx);
+            if constexpr (HAS_DS) {
+                float dsv[8];
+                Row8<S>::load(ds + base + ch * 8, dsv);
+                // half stream: the unfused path rounds LN_bwd to half before autograd adds the bypass gradient
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = Row8<S>::round(o[i]) + dsv[i];
+            }
+            Row8<S>::store(dx + base + ch * 8, o);
+            if constexpr (HALF_COPY) Row8<T>::store(dx_half + base + ch * 8, o);
+        }
+    }
+}
+
 __device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
 // d/dz [z * Phi(z)] = Phi(z) + z * phi(z)
 __device__ __forceinline__ float gelu_grad_f(float z) {
@@ -259,6 +413,47 @@ int ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats
     return mos_check_launch("layernorm_bwd");
 }
 
+template <typename T, typename S>
+int add_ln_fwd(const void* x, const void* r, const float* gamma, const float* beta, void* s_out, void* y, float* stats, int rows,
+               int C, float eps, hipStream_t st) {
+    const int nch = (C / 8 + 63) / 64;
+    const dim3 grid((rows + 3) / 4);
+    char key[64];
+    snprintf(key, sizeof(key), "rows%d C%d s%d", rows, C, (int)sizeof(S));
+    const double sb = (double)sizeof(S), tb = (double)sizeof(T);
+    MosProfScope prof(st, "add_layernorm_fwd", key, 9.0 * rows * C, rows * (double)C * (r ? 2 * sb + 2 * tb : sb + tb));
+#define ALN_F(N, R) hipLaunchKernelGGL((add_layernorm_fwd_kernel<T, S, N, R>), grid, dim3(256), 0, st, (const S*)x, (const T*)r, \
+                                       gamma, beta, (S*)s_out, (T*)y, stats, rows, C, eps)
+#define ALN_FN(N) do { if (r != nullptr) ALN_F(N, true); else ALN_F(N, false); } while (0)
+    switch (nch) { case 1: ALN_FN(1); break; case 2: ALN_FN(2); break; case 3: ALN_FN(3); break; default: ALN_FN(4); break; }
+#undef ALN_FN
+#undef ALN_F
+    return mos_check_launch("add_layernorm_fwd");
+}
+
+template <typename T, typename S>
+int add_ln_bwd(const void* dy, const void* ds, const void* s, const float* gamma, const float* stats, void* dx, void* dx_half,
+               int rows, int C, hipStream_t st) {
+    const int nch = (C / 8 + 63) / 64;
+    const dim3 grid((rows + 3) / 4);
+    char key[64];
+    snprintf(key, sizeof(key), "rows%d C%d s%d", rows, C, (int)sizeof(S));
+    const double sb = (double)sizeof(S), tb = (double)sizeof(T);
+    MosProfScope prof(st, "add_layernorm_bwd", key, 13.0 * rows * C,
+                      rows * (double)C * (tb + 2 * sb + (ds ? sb : 0.0) + (dx_half ? tb : 0.0)));
+#define ALN_B(N, D, H) hipLaunchKernelGGL((add_layernorm_bwd_kernel<T, S, N, D, H>), grid, dim3(256), 0, st, (const T*)dy, \
+                                          (const S*)ds, (const S*)s, gamma, stats, (S*)dx, (T*)dx_half, rows, C)
+#define ALN_BN(N) do { \
+        if (ds != nullptr && dx_half != nullptr) ALN_B(N, true, true); \
+        else if (ds != nullptr) ALN_B(N, true, false); \
+        else if (dx_half != nullptr) ALN_B(N, false, true); \
+        else ALN_B(N, false, false); } while (0)
+    switch (nch) { case 1: ALN_BN(1); break; case 2: ALN_BN(2); break; case 3: ALN_BN(3); break; default: ALN_BN(4); break; }
+#undef ALN_BN
+#undef ALN_B
+    return mos_check_launch("add_layernorm_bwd");
+}
+
 // quick-GELU of the CLIP text tower MLP (transformers `quick_gelu`: x * sigmoid(1.702 x)); the reference runs it as three
 // elementwise torch kernels forward and ~five backward per layer. One thread = 8 elements.
 __device__ __forceinline__ float sigmoid_f(float z) { return 1.f / (1.f + __expf(-z)); }
@@ -323,6 +518,35 @@ int mos_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
     if (dtype == MOS_F16) return ln_bwd<f16_t>(dy, x, gamma, stats, dx, rows, C, (hipStream_t)stream);
     if (dtype == MOS_BF16) return ln_bwd<bf16_t>(dy, x, gamma, stats, dx, rows, C, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_layernorm_bwd: dtype %d", dtype);
+}
+
+int mos_add_layernorm_fwd(const void* x, const void* r, const float* gamma, const float* beta, void* s_out, void* y,
+                          float* stats, int rows, int C, float eps, int dtype, int stream_fp32, void* stream) {
+    MOS_REQUIRE(x && gamma && beta && y && (r == nullptr || s_out != nullptr), "mos_add_layernorm_fwd: NULL argument");
+    MOS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAX_CHUNKS, "mos_add_layernorm_fwd: rows=%d C=%d", rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MOS_F16)
+        return stream_fp32 ? add_ln_fwd<f16_t, float>(x, r, gamma, beta, s_out, y, stats, rows, C, eps, st)
+                           : add_ln_fwd<f16_t, f16_t>(x, r, gamma, beta, s_out, y, stats, rows, C, eps, st);
+    if (dtype == MOS_BF16)
+        return stream_fp32 ? add_ln_fwd<bf16_t, float>(x, r, gamma, beta, s_out, y, stats, rows, C, eps, st)
+                           : add_ln_fwd<bf16_t, bf16_t>(x, r, gamma, beta, s_out, y, stats, rows, C, eps, st);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_add_layernorm_fwd: dtype %d", dtype);
+}
+
+int mos_add_layernorm_bwd(const void* dy, const void* ds, const void* s, const float* gamma, const float* stats, void* dx,
+                          void* dx_half, int rows, int C, int dtype, int stream_fp32, void* stream) {
+    MOS_REQUIRE(dy && s && gamma && stats && dx, "mos_add_layernorm_bwd: NULL argument");
+    MOS_REQUIRE(dx_half == nullptr || stream_fp32, "mos_add_layernorm_bwd: dx_half only with an fp32 residual stream");
+    MOS_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAX_CHUNKS, "mos_add_layernorm_bwd: rows=%d C=%d", rows, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MOS_F16)
+        return stream_fp32 ? add_ln_bwd<f16_t, float>(dy, ds, s, gamma, stats, dx, dx_half, rows, C, st)
+                           : add_ln_bwd<f16_t, f16_t>(dy, ds, s, gamma, stats, dx, dx_half, rows, C, st);
+    if (dtype == MOS_BF16)
+        return stream_fp32 ? add_ln_bwd<bf16_t, float>(dy, ds, s, gamma, stats, dx, dx_half, rows, C, st)
+                           : add_ln_bwd<bf16_t, bf16_t>(dy, ds, s, gamma, stats, dx, dx_half, rows, C, st);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_add_layernorm_bwd: dtype %d", dtype);
 }
 
 int mos_quick_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {

@@ -256,6 +256,7 @@ struct GnNhwcArgs {
     float* partial;                                // [B][nsplit][G][2]
     int B, C, HW, G, cpg, nsplit, V, TP, R, ppb;   // V = C/8 vectors per pixel, TP threads per pixel, R pixel rows per block
     float eps;
+    const void* ds;                                // backward only: gradient that bypasses the norm (added to dx), or NULL
 };
 
 template <typename T, int VT, bool BWD, bool SILU>
@@ -346,8 +347,11 @@ __global__ __launch_bounds__(256) void gn_nhwc_reduce_kernel(GnNhwcArgs a) {
     }
 }
 
-template <typename T, int VT, bool BWD, bool SILU>
+// DS (backward): out = half(dx) + ds -- the gradient of a residual connection that bypasses this norm, added where autograd
+// would otherwise launch a separate accumulation kernel (same rounding points: dx rounded to T, then the half add)
+template <typename T, int VT, bool BWD, bool SILU, bool DS = false>
 __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
+    static_assert(BWD || !DS, "the bypass gradient exists in backward only");
     typedef typename MT<T>::v8 v8;
     __shared__ float u_s[64], w_s[64], m_s[64], r_s[64];   // fwd: mean, rstd ; bwd: mean(g), mean(g xhat), mean, rstd
     const int tid = threadIdx.x;
@@ -409,9 +413,11 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     const T* xb = (const T*)a.x + (int64_t)b * a.HW * a.C;
     const T* db = BWD ? (const T*)a.dy + (int64_t)b * a.HW * a.C : nullptr;
     T* ob = (T*)a.out + (int64_t)b * a.HW * a.C;
+    [[maybe_unused]] const T* sb = DS ? (const T*)a.ds + (int64_t)b * a.HW * a.C : nullptr;
     constexpr int U = 4;
     for (int p = p0 + r; p < p1; p += U * a.R) {
         u32x4 xr[U][VT], dr[U][VT];
+        [[maybe_unused]] u32x4 sr[U][VT];
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
                 const int64_t off = (int64_t)min(p + u * a.R, p1 - 1) * a.C + v * 8;
                 xr[u][k] = ld16(xb + off);
                 if (BWD) dr[u][k] = ld16(db + off);
+                if constexpr (DS) sr[u][k] = ld16(sb + off);
             }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -450,6 +457,11 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
                             dz *= sig * (1.f + z * (1.f - sig));
                         }
                         o[i] = (T)(c1[k][i] * (dz * c2[k][i] - c4[k][i] - xh * c5[k][i]));
+                    }
+                    if constexpr (DS) {
+                        const v8 sv = as_v8<T>(sr[u][k]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[i] = (T)((float)o[i] + (float)sv[i]);
                     }
                 }
                 st16(ob + off, from_v8<T>(o));
@@ -495,6 +507,18 @@ int gn_nhwc_run(GnNhwcArgs a, int silu, hipStream_t st) {
     int rc = mos_check_launch("gn_nhwc_reduce");
     if (rc) return rc;
     MosProfScope prof(st, BWD ? "groupnorm_bwd_apply" : "groupnorm_apply", key, (BWD ? 14.0 : 8.0) * n, (BWD ? 6.0 : 4.0) * n);
+    if constexpr (BWD) {
+        if (a.ds != nullptr) {
+            if (vt == 1) {
+                if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, true, true, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, true, false, true>), grid, block, 0, st, a);
+            } else {
+                if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 2, true, true, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 2, true, false, true>), grid, block, 0, st, a);
+            }
+            return mos_check_launch("gn_nhwc_apply");
+        }
+    }
     if (vt == 1) {
         if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, BWD, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, BWD, false>), grid, block, 0, st, a);
@@ -577,6 +601,23 @@ int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamm
     if (dtype == MOS_F16) return gn_nhwc_run<f16_t, true>(a, silu, (hipStream_t)stream);
     if (dtype == MOS_BF16) return gn_nhwc_run<bf16_t, true>(a, silu, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_bwd_nhwc: dtype %d", dtype);
+}
+
+/* mos_groupnorm_silu_bwd_nhwc plus the gradient `ds` (x's shape, layout and dtype) of a residual connection that bypasses
+ * the norm: dx = half(GN_bwd(dy)) + ds, i.e. exactly what autograd's accumulation of the two gradients yields, without the
+ * extra elementwise launch (ResnetBlock2D / Transformer2DModel inputs feed both a GroupNorm and a skip path). */
+int mos_groupnorm_silu_bwd_nhwc_res(const void* dy, const void* ds, const void* x, const float* gamma, const float* beta,
+                                    const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu, int dtype,
+                                    void* stream) {
+    GnNhwcArgs a = {};
+    a.x = x; a.dy = dy; a.out = dx; a.gamma = gamma; a.beta = beta; a.stats = const_cast<float*>(stats); a.partial = (float*)ws;
+    a.B = B; a.C = C; a.HW = HW; a.G = G; a.eps = 0.f; a.ds = ds;
+    int rc = gn_nhwc_check(x, dx, gamma, beta, ws, a, "mos_groupnorm_silu_bwd_nhwc_res");
+    if (rc) return rc;
+    MOS_REQUIRE(dy && stats && ds, "mos_groupnorm_silu_bwd_nhwc_res: NULL dy / ds / stats");
+    if (dtype == MOS_F16) return gn_nhwc_run<f16_t, true>(a, silu, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return gn_nhwc_run<bf16_t, true>(a, silu, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_bwd_nhwc_res: dtype %d", dtype);
 }
 
 }  // extern "C"

@@ -431,17 +431,19 @@ class _Attention(torch.autograd.Function):
         o, lse, pcols = ops.attn_fwd(q, k, v, heads, scale, tok_idx=tok_idx, need_lse=need_grad, causal=causal)
         ctx.mode, ctx.heads, ctx.scale, ctx.causal = mode, heads, scale, causal
         ctx.has_pcols = pcols is not None
+        # (no zero-filled stand-ins: without tok_idx the second output is None, and a probability-column output nobody
+        # consumed arrives in backward as None instead of a materialised zero tensor -- 2 fills per layer and step)
+        ctx.set_materialize_grads(False)
         if need_grad:
             ctx.save_for_backward(a, b, c, o, lse, tok_idx, pcols)
-        if pcols is None:
-            pcols = o.new_zeros((), dtype=torch.float32)
-            ctx.mark_non_differentiable(pcols)
         return o, pcols
 
     @staticmethod
-    def backward(ctx, dO, dpcols):
+    def backward(ctx, dO, dpcols=None):
         a, b, c, o, lse, tok_idx, pcols = ctx.saved_tensors
         mode = ctx.mode
+        if dO is None:
+            dO = torch.zeros_like(o)
         if dO.stride(-1) != 1 or dO.stride(1) % 8 != 0 or dO.dtype != o.dtype:
             dO = dO.to(o.dtype).contiguous()
         da = torch.empty_like(a)
@@ -519,6 +521,44 @@ class _GroupNormSiLU(torch.autograd.Function):
         return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
 
 
+class _GroupNormSiLUTap(torch.autograd.Function):
+    """(x, y) = (x passed through, GroupNorm(+SiLU)(x)): callers route the skip path that bypasses the norm through the first
+    output, so its gradient meets the norm's input gradient inside the backward kernel (mos_groupnorm_silu_bwd_nhwc_res)
+    instead of in a separate autograd accumulation launch."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        xc = _dense_format(x)
+        y, stats = ops.groupnorm_silu_fwd(xc, gamma, beta, groups, eps, silu)
+        ctx.save_for_backward(xc, gamma, beta, stats)
+        ctx.groups, ctx.silu = groups, silu
+        ctx.set_materialize_grads(False)
+        return x, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        if dy is None:
+            return ds, None, None, None, None, None
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        if dy.stride() != x.stride():
+            dy = dy.contiguous(memory_format=torch.channels_last) if ops._is_nhwc(x) else dy.contiguous()
+        if ds is None:
+            return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
+        if ops._is_nhwc(x) and ds.dtype == x.dtype and ds.shape == x.shape:
+            if ds.stride() != x.stride():              # e.g. a channel slice of a concatenated gradient
+                ds = ds.contiguous(memory_format=torch.channels_last)
+            return (ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu, ds=ds), None, None, None, None,
+                    None)
+        return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu) + ds, None, None, None, None, None
+
+
+def _os_env(name, default):
+    import os
+    return os.environ.get(name, default)
+
+
 def _frozen(*params):
     """True when no gradient will be asked for these parameters: they are frozen, or autograd is off (sampling pipelines run
     under no_grad with ordinary requires_grad=True modules)."""
@@ -538,8 +578,10 @@ def _affine32(norm):
     return ent[1], ent[2]
 
 
-def group_norm_act(norm, x, silu):
-    """`silu(norm(x))` (or `norm(x)`) for an nn.GroupNorm `norm`.
+def group_norm_act(norm, x, silu, tap=False):
+    """`silu(norm(x))` (or `norm(x)`) for an nn.GroupNorm `norm`. tap=True returns (x, y): use the returned x for the skip
+    path around the norm (residual / shortcut) -- on the HIP path that routes the skip's gradient into the norm's backward
+    kernel (_GroupNormSiLUTap); elsewhere it is x itself.
 
     HIP path: half-precision device tensors with frozen affine parameters and HW % 8 == 0 — one fused kernel pair
     instead of autocast's cast / fp32 group_norm / fp32 silu / cast chain. Anything else (CPU oracle runs, fp32
@@ -550,9 +592,13 @@ def group_norm_act(norm, x, silu):
                and norm.weight is not None and norm.bias is not None and _frozen(norm.weight, norm.bias))
     if use_hip:
         gamma, beta = _affine32(norm)
-        return _GroupNormSiLU.apply(x, gamma, beta, norm.num_groups, norm.eps, bool(silu))
+        if tap and _fuse_gn_res and torch.is_grad_enabled() and x.requires_grad:
+            return _GroupNormSiLUTap.apply(x, gamma, beta, norm.num_groups, norm.eps, bool(silu))
+        y = _GroupNormSiLU.apply(x, gamma, beta, norm.num_groups, norm.eps, bool(silu))
+        return (x, y) if tap else y
     y = norm(x)
-    return torch.nn.functional.silu(y) if silu else y
+    y = torch.nn.functional.silu(y) if silu else y
+    return (x, y) if tap else y
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -594,6 +640,82 @@ def layer_norm(norm, x):
         x = x.to(torch.get_autocast_dtype('cuda'))
     gamma, beta = _affine32(norm)
     return _LayerNorm.apply(x, gamma, beta, norm.eps)
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """(s, y) = (x + r, LN(x + r)) in one kernel; r None: s is x itself, passed through so that the gradient which bypasses
+    the norm (the residual connection) meets the norm's input gradient inside the backward kernel instead of in a
+    separate autograd accumulation launch."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps, half_dtype):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r2 = None
+        if r is not None:
+            r2 = r.reshape(-1, C)
+            if not r2.is_contiguous():
+                r2 = r2.contiguous()
+        need = ctx.needs_input_grad[0] or (r is not None and ctx.needs_input_grad[1])
+        s2, y, stats = ops.add_layernorm_fwd(x2, r2, gamma, beta, eps, need_stats=need, half_dtype=half_dtype)
+        if need:
+            ctx.save_for_backward(s2, gamma, stats)
+        ctx.has_r, ctx.half_dtype = r is not None, y.dtype
+        ctx.set_materialize_grads(False)
+        return (s2.view(x.shape) if r is not None else x), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s2, gamma, stats = ctx.saved_tensors
+        stream32 = s2.dtype == torch.float32
+        want_r = ctx.has_r and ctx.needs_input_grad[1]
+        if dy is None:                                   # the normalised output was not used: only the bypass gradient
+            dr = None
+            if ds is not None and want_r:
+                dr = ds.to(ctx.half_dtype) if stream32 else ds
+            return ds, dr, None, None, None, None
+        d2 = dy.reshape(s2.shape)
+        if d2.dtype != ctx.half_dtype or not d2.is_contiguous():
+            d2 = d2.to(ctx.half_dtype).contiguous()
+        ds2 = None
+        if ds is not None:
+            ds2 = ds.reshape(s2.shape)
+            if ds2.dtype != s2.dtype or not ds2.is_contiguous():
+                ds2 = ds2.to(s2.dtype).contiguous()
+        dx, dxh = ops.add_layernorm_bwd(d2, ds2, s2, gamma, stats, half_copy=want_r and stream32)
+        dx = dx.view(ds.shape if ds is not None else dy.shape)
+        dr = None
+        if want_r:
+            dr = dxh.view(dx.shape) if stream32 else dx
+        return dx, dr, None, None, None, None
+
+
+_fuse_add_ln = _os_env('MOS_FUSE_ADD_LN', '1') != '0'
+_fuse_gn_res = _os_env('MOS_FUSE_GN_RES', '1') != '0'
+
+
+def add_layer_norm(norm, x, r=None):
+    """(s, y) with s = x + r (s is x when r is None) and y = norm(s): the residual add of a transformer block fused into the
+    LayerNorm that consumes the sum, forward and backward (ops.add_layernorm_fwd / _bwd). Always use the returned `s` as the
+    residual stream downstream -- that is what routes its bypass gradient into the norm's backward kernel.
+
+    HIP path: like layer_norm, plus r in the half dtype and x either the same half dtype (UNet blocks) or fp32 under half
+    autocast (the CLIP tower's residual stream). Anything else: the two plain ops."""
+    C = x.shape[-1]
+    half = x.dtype in (torch.float16, torch.bfloat16)
+    ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
+    hd = x.dtype if half else (torch.get_autocast_dtype('cuda') if ac else None)
+    use_hip = (_fuse_add_ln and x.is_cuda and hd is not None and (half or x.dtype == torch.float32)
+               and (r is None or (r.dtype == hd and r.shape == x.shape))
+               and len(norm.normalized_shape) == 1 and norm.weight is not None and norm.bias is not None
+               and _frozen(norm.weight, norm.bias) and C % 8 == 0 and C <= 2048)
+    if not use_hip:
+        s = x if r is None else x + r
+        return s, layer_norm(norm, s)
+    gamma, beta = _affine32(norm)
+    return _AddLayerNorm.apply(x, r, gamma, beta, norm.eps, hd)
 
 
 class _GEGLU(torch.autograd.Function):

@@ -140,9 +140,12 @@ SIGNATURES = {
     'mos_groupnorm_nhwc_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'mos_groupnorm_silu_fwd_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'mos_groupnorm_silu_bwd_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mos_groupnorm_silu_bwd_nhwc_res': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_conv3x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     'mos_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'mos_add_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp]),
+    'mos_add_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'mos_geglu_fwd': (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     'mos_softmax_rows': (_i, [_vp, _vp, _i, _i, _f, _i, _vp]),
     'mos_geglu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),

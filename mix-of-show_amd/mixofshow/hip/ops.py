@@ -388,9 +388,10 @@ def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
     return y, stats
 
 
-def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu):
-    """dy must have x's memory format."""
-    _dev(dy, x, gamma, beta, stats)
+def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None):
+    """dy must have x's memory format. ds (channels_last x only): gradient of a skip path around the norm, same format and
+    dtype as x; the result is round(GN_bwd(dy)) + ds in one kernel."""
+    _dev(dy, x, gamma, beta, stats, ds)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     dx = torch.empty_like(x)
@@ -398,10 +399,16 @@ def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu):
     if _is_nhwc(x):
         assert dy.stride() == x.stride()
         ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
+        if ds is not None:
+            assert ds.stride() == x.stride() and ds.dtype == x.dtype and ds.shape == x.shape
+            _lib.check(L.mos_groupnorm_silu_bwd_nhwc_res(_p(dy), _p(ds), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws),
+                                                         B, C, HW, groups, int(bool(silu)), _dt(x), _stream()),
+                       'mos_groupnorm_silu_bwd_nhwc_res')
+            return dx
         _lib.check(L.mos_groupnorm_silu_bwd_nhwc(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, C, HW,
                                                  groups, int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_bwd_nhwc')
         return dx
-    assert x.is_contiguous() and dy.is_contiguous()
+    assert x.is_contiguous() and dy.is_contiguous() and ds is None, 'the bypass gradient is fused for channels_last only'
     ws = torch.empty((L.mos_groupnorm_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
     _lib.check(L.mos_groupnorm_silu_bwd(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, C, HW, groups,
                                         int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_bwd')
@@ -432,6 +439,44 @@ def layernorm_bwd(dy, x, gamma, stats):
     L = _lib.load()
     _lib.check(L.mos_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(stats), _p(dx), rows, C, _dt(x), _stream()), 'mos_layernorm_bwd')
     return dx
+
+
+def add_layernorm_fwd(x, r, gamma, beta, eps, need_stats=True, half_dtype=None):
+    """s = x + r, y = LayerNorm(s) (mos_add_layernorm_fwd). x (rows, C) contiguous in the residual-stream dtype (half, or
+    fp32 for a half branch on an fp32 stream); r (rows, C) half or None (then s is x itself). y is half: r's dtype, else
+    x's, else `half_dtype` (fp32 stream without r). Returns (s, y, stats)."""
+    _dev(x, r, gamma, beta)
+    rows, C = x.shape
+    stream32 = x.dtype == torch.float32
+    assert x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    assert r is None or (r.is_contiguous() and r.shape == x.shape and r.dtype in (torch.float16, torch.bfloat16))
+    assert stream32 or r is None or r.dtype == x.dtype
+    hd = r.dtype if r is not None else (x.dtype if not stream32 else (half_dtype or torch.float16))
+    y = torch.empty((rows, C), dtype=hd, device=x.device)
+    s = torch.empty_like(x) if r is not None else x
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if need_stats else None
+    L = _lib.load()
+    _lib.check(L.mos_add_layernorm_fwd(_p(x), _p(r), _p(gamma), _p(beta), _p(s) if r is not None else None, _p(y), _p(stats),
+                                       rows, C, float(eps), _dt(y), int(stream32), _stream()), 'mos_add_layernorm_fwd')
+    return s, y, stats
+
+
+def add_layernorm_bwd(dy, ds, s, gamma, stats, half_copy=False):
+    """dx = LN_bwd(dy) + ds in the stream dtype of s (ds None: no bypass gradient); half_copy (fp32 stream only): also the
+    half rounding of dx for the branch input. Returns (dx, dx_half | None)."""
+    _dev(dy, ds, s, gamma, stats)
+    rows, C = s.shape
+    stream32 = s.dtype == torch.float32
+    assert s.is_contiguous() and dy.is_contiguous() and dy.shape == s.shape and dy.dtype in (torch.float16, torch.bfloat16)
+    assert stream32 or dy.dtype == s.dtype
+    assert ds is None or (ds.is_contiguous() and ds.dtype == s.dtype and ds.shape == s.shape)
+    assert not half_copy or stream32
+    dx = torch.empty_like(s)
+    dxh = torch.empty_like(dy) if half_copy else None
+    L = _lib.load()
+    _lib.check(L.mos_add_layernorm_bwd(_p(dy), _p(ds), _p(s), _p(gamma), _p(stats), _p(dx), _p(dxh), rows, C, _dt(dy),
+                                       int(stream32), _stream()), 'mos_add_layernorm_bwd')
+    return dx, dxh
 
 
 def geglu_fwd(h):

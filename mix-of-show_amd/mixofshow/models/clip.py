@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mixofshow.hip.functional import layer_norm, quick_gelu
+from mixofshow.hip.functional import add_layer_norm, layer_norm, quick_gelu
 
 
 class CLIPTextEmbeddings(nn.Module):
@@ -62,6 +62,11 @@ class CLIPAttention(nn.Module):
             qkv = project(self, 'qkv', [self.q_proj, self.k_proj, self.v_proj], x if x.dtype == cd else x.to(cd), cd)
             if not (torch.is_autocast_enabled('cuda') or x.dtype == cd):
                 qkv = qkv.to(x.dtype)
+            if x.is_cuda and self.head_dim in (40, 64, 80, 160) and qkv.dtype in (torch.float16, torch.bfloat16):
+                # the kernels read q/k/v as column blocks of the fused projection and write ONE (B, 77, 3C) gradient:
+                # slicing here would cost autograd three zero-filled buffers, three scatters and two adds per layer
+                o = F_hip.attention_qkv(qkv, self.num_heads, self.head_dim**-0.5, causal=True)
+                return self.out_proj(o)
             q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
         else:
             q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
@@ -103,6 +108,13 @@ class CLIPEncoderLayer(nn.Module):
         x = x + self.self_attn(layer_norm(self.layer_norm1, x))
         return x + self.mlp(layer_norm(self.layer_norm2, x))
 
+    def forward_deferred(self, x, pending=None):
+        """The same layer with its residual sums formed inside the LayerNorm kernels that consume them: `pending` is the
+        previous layer's MLP output, not yet added to the stream x; returns (stream, this layer's pending MLP output)."""
+        x, n = add_layer_norm(self.layer_norm1, x, pending)
+        x, n = add_layer_norm(self.layer_norm2, x, self.self_attn(n))
+        return x, self.mlp(n)
+
 
 class CLIPEncoder(nn.Module):
 
@@ -115,6 +127,16 @@ class CLIPEncoder(nn.Module):
             x = l(x)
         return x
 
+    def forward_deferred(self, x):
+        pending = None
+        for l in self.layers:
+            if l._forward_hooks or l._forward_pre_hooks:          # someone observes layer outputs: materialise them
+                x = l(x if pending is None else x + pending)
+                pending = None
+            else:
+                x, pending = l.forward_deferred(x, pending)
+        return x, pending
+
 
 class CLIPTextTransformer(nn.Module):
 
@@ -125,7 +147,11 @@ class CLIPTextTransformer(nn.Module):
         self.final_layer_norm = nn.LayerNorm(hidden)
 
     def forward(self, input_ids):
-        return layer_norm(self.final_layer_norm, self.encoder(self.embeddings(input_ids)))
+        enc = self.encoder
+        if enc._forward_hooks or enc._forward_pre_hooks:
+            return layer_norm(self.final_layer_norm, enc(self.embeddings(input_ids)))
+        x, pending = enc.forward_deferred(self.embeddings(input_ids))
+        return add_layer_norm(self.final_layer_norm, x, pending)[1]
 
 
 SD15_CLIP_CONFIG = dict(vocab_size=49408, hidden_size=768, num_attention_heads=12, intermediate_size=3072,

@@ -33,9 +33,29 @@ def remove_edlora_unet_attention_forward(unet):
     visit(unet)
 
 
+def attach_layer_major_states(states):
+    """ED-LoRA's (B, L, 77, C) layer-wise text states get a LAYER-major copy attached (`states._mos_layers`, one contiguous
+    (B, 77, C) tensor per cross-attention layer) for the processors of this module; the tensor itself is passed on unchanged,
+    so processors written against the diffusers protocol keep indexing it.
+
+    Indexing the batch-major tensor per layer (`states[:, k]`, reference :56-59) costs, per layer, a strided gather in front of
+    the K/V projection GEMM and -- in training -- a zero-filled (B, L, 77, C) gradient buffer, a strided scatter and an
+    accumulation (3 launches x 16 layers + 16 gathers per step). One transpose copy makes every layer's slice contiguous and
+    `unbind` gives autograd ONE stack for the gradient of all slices. Cached on the tensor (sampling loops pass the same
+    prompt embedding every step) and keyed by its version counter."""
+    ent = getattr(states, '_mos_layers', None)
+    if ent is None or ent[0] != states._version or ent[2] != (states.requires_grad and torch.is_grad_enabled()):
+        ent = (states._version, states.transpose(0, 1).contiguous().unbind(0), states.requires_grad and torch.is_grad_enabled())
+        states._mos_layers = ent
+    return states
+
+
 def _select_layer_states(encoder_hidden_states, idx):
     # (B, 16, 77, 768) layer-wise ED-LoRA embedding -> this layer's slice (reference :56-59, :130-133)
     if encoder_hidden_states is not None and encoder_hidden_states.dim() == 4:
+        ent = getattr(encoder_hidden_states, '_mos_layers', None)
+        if ent is not None and ent[0] == encoder_hidden_states._version:
+            return ent[1][idx]
         return encoder_hidden_states[:, idx]
     return encoder_hidden_states
 

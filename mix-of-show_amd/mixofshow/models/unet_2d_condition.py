@@ -13,13 +13,14 @@ PyTorch-ROCm (MIOpen / hipBLASLt); every `Attention` goes through its processor 
 (T2I-Adapter features) are consumed in the diffusers 0.19 order (pipeline_regionally_t2iadapter.py:556-566).
 """
 import math
+import weakref
 from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mixofshow.hip.functional import conv1x1, conv3x3, geglu, group_norm_act, layer_norm
+from mixofshow.hip.functional import add_layer_norm, conv1x1, conv3x3, geglu, group_norm_act
 from mixofshow.models.attention import Attention
 
 
@@ -46,6 +47,21 @@ class TimestepEmbedding(nn.Module):
         return self.linear_2(self.act(self.linear_1(sample)))
 
 
+_act_memo = [None, None, None]
+
+
+def _act_once(act, temb):
+    """`act(temb)` for the time embedding that all 22 ResNet blocks of one UNet call share: computed by the first block, reused
+    by the others (diffusers: one SiLU launch per block)."""
+    ref, ver, out = _act_memo
+    if ref is not None and ref() is temb and ver == temb._version and out.requires_grad == (
+            temb.requires_grad and torch.is_grad_enabled()):
+        return out
+    out = act(temb)
+    _act_memo[:] = [weakref.ref(temb), temb._version, out]
+    return out
+
+
 class ResnetBlock2D(nn.Module):
 
     def __init__(self, in_channels, out_channels, temb_channels=1280, groups=32, eps=1e-5):
@@ -64,8 +80,10 @@ class ResnetBlock2D(nn.Module):
         # the residual add in their epilogues (diffusers: conv, + temb[:, :, None, None], ..., x + h as separate kernels)
         tb = None
         if self.time_emb_proj is not None and temb is not None:
-            tb = self.time_emb_proj(self.nonlinearity(temb))
-        h = conv3x3(self.conv1, group_norm_act(self.norm1, x, True), tbias=tb)
+            tb = self.time_emb_proj(_act_once(self.nonlinearity, temb))
+        # (x feeds norm1 AND the skip path: taking the skip from the norm's tap adds its gradient inside the norm's backward)
+        x, h = group_norm_act(self.norm1, x, True, tap=True)
+        h = conv3x3(self.conv1, h, tbias=tb)
         if self.conv_shortcut is not None:
             x = conv1x1(self.conv_shortcut, x)
         return conv3x3(self.conv2, self.dropout(group_norm_act(self.norm2, h, True)), residual=x)
@@ -129,9 +147,14 @@ class BasicTransformerBlock(nn.Module):
 
     def forward(self, x, encoder_hidden_states=None, cross_attention_kwargs=None):
         cak = cross_attention_kwargs if cross_attention_kwargs is not None else {}
-        x = self.attn1(layer_norm(self.norm1, x), encoder_hidden_states=None, **cak) + x
-        x = self.attn2(layer_norm(self.norm2, x), encoder_hidden_states=encoder_hidden_states, **cak) + x
-        return self.ff(layer_norm(self.norm3, x)) + x
+        # x = attn1(norm1(x)) + x; x = attn2(norm2(x)) + x; x = ff(norm3(x)) + x  with each residual sum formed inside the
+        # LayerNorm kernel that consumes it, and each bypass gradient added inside that norm's backward kernel
+        x, n = add_layer_norm(self.norm1, x)
+        a = self.attn1(n, encoder_hidden_states=None, **cak)
+        x, n = add_layer_norm(self.norm2, x, a)
+        a = self.attn2(n, encoder_hidden_states=encoder_hidden_states, **cak)
+        x, n = add_layer_norm(self.norm3, x, a)
+        return self.ff(n) + x
 
 
 class Transformer2DModel(nn.Module):
@@ -146,8 +169,8 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, encoder_hidden_states=None, cross_attention_kwargs=None):
         b, c, h, w = x.shape
-        residual = x
-        x = conv1x1(self.proj_in, group_norm_act(self.norm, x, False))
+        residual, x = group_norm_act(self.norm, x, False, tap=True)
+        x = conv1x1(self.proj_in, x)
         x = x.permute(0, 2, 3, 1).reshape(b, h * w, -1)
         for blk in self.transformer_blocks:
             x = blk(x, encoder_hidden_states=encoder_hidden_states, cross_attention_kwargs=cross_attention_kwargs)
@@ -344,6 +367,10 @@ class UNet2DConditionModel(nn.Module):
         timestep = timestep.expand(sample.shape[0])
         t_emb = get_timestep_embedding(timestep, self._time_dim).to(dtype=sample.dtype)
         emb = self.time_embedding(t_emb)
+
+        if torch.is_tensor(encoder_hidden_states) and encoder_hidden_states.dim() == 4 and sample.is_cuda:
+            from mixofshow.models.edlora import attach_layer_major_states
+            attach_layer_major_states(encoder_hidden_states)          # one transpose instead of 16 strided gathers
 
         if getattr(self, 'channels_last', False):
             sample = sample.contiguous(memory_format=torch.channels_last)

@@ -254,35 +254,53 @@ class EDLoRATrainer(nn.Module):
         groups = {}
         for maps in attention_maps.values():
             for m in maps:
-                B, H, N, T = m.shape
-                res = int(math.sqrt(N))
-                groups.setdefault(res, []).append(m.reshape(B, H, res, res, T))
+                N = m.shape[2]
+                groups.setdefault(int(math.sqrt(N)), []).append(m)
         total = torch.zeros((), dtype=torch.float32, device=masks.device)     # no recorded maps: 0, valid (reference: adds 0)
         valid = torch.ones((), dtype=torch.bool, device=masks.device)
-        for res in sorted(groups, reverse=True):
-            cm = torch.cat(groups[res], dim=1)
-            cm = cm.sum(1) / cm.shape[1]                       # mean over heads of all layers: (B, res, res, T)
-            adj, subj = cm[..., 0], cm[..., 1]
-            subj = subj / subj.max()
-            adj = adj / adj.max()
-            gt = F.interpolate(masks.float(), size=subj.shape[1:], mode='nearest').squeeze(1)
-            outside = (gt == 0).to(subj.dtype)
-            n_out = outside.sum()
-            ok = n_out > 0
-            valid = valid & ok
-            denom = n_out.clamp(min=1.0)              # 0/0 would poison the backward pass even under a `where`
+        if groups:
+            # Both token columns and all resolutions go through the same few kernels (the reference loops over columns and
+            # resolutions with ~25 scalar-sized launches each, and as many again in backward):
+            #   * c / c.max() is invariant to the scale of c, so the division by the head count of the reference's mean over
+            #     heads (:281) is dropped -- the sum over heads is normalised directly;
+            #   * nearest-neighbour down-sampling of the mask by an integer factor is a strided view;
+            #   * the per-resolution scalars are stacked and combined once.
+            mf = masks.float()
+            sums, n_outs, ident = [], [], []
+            for res in sorted(groups, reverse=True):
+                g = groups[res]
+                B, _, _, T = g[0].shape
+                c = (torch.cat(g, dim=1) if len(g) > 1 else g[0]).sum(1).reshape(B, res, res, T)
+                n = c / c.amax(dim=(0, 1, 2))                       # [..., 0] adjective, [..., 1] subject, each / its max
+                gt = self._mask_at(mf, res)
+                outside = gt == 0
+                n_outs.append(outside.sum())
+                sums.append((n * outside[..., None]).sum((0, 1, 2)))            # (T,): sum over pixels outside the mask
+                if self.reg_full_identity:
+                    ident.append(F.mse_loss(n[..., 1].float(), gt, reduction='mean'))
+            S = torch.stack(sums).float()                            # (R, T)
+            n_out = torch.stack(n_outs)
+            valid = (n_out > 0).all()
+            denom = n_out.clamp(min=1).to(S.dtype)       # 0/0 would poison the backward pass even under a `where`
             if self.reg_full_identity:
-                l_subj = F.mse_loss(subj.float(), gt.float(), reduction='mean')
+                total = self.attn_reg_weight * ((S[:, 0] / denom).sum() + torch.stack(ident).sum())
             else:
-                l_subj = (subj * outside).sum() / denom
-            l_adj = (adj * outside).sum() / denom
-            total = total + self.attn_reg_weight * (l_subj + l_adj)
+                total = self.attn_reg_weight * (S[:, :2].sum(1) / denom).sum()
         if return_valid:
             # a non-finite regulariser from any other cause (fp16 overflow in a map) is dropped too, as the reference's
             # `if not torch.isnan(attention_loss)` does (:257)
             finite = torch.isfinite(total)
             return torch.where(finite, total, torch.zeros_like(total)), valid & finite
         return torch.where(valid, total, torch.full_like(total, float('nan')))
+
+    @staticmethod
+    def _mask_at(mask, res):
+        """`F.interpolate(mask, size=(res, res), mode='nearest').squeeze(1)` (reference :289): index floor(i * in / out), which
+        for an integer down-sampling factor is the strided view mask[..., ::k, ::k] (no kernel)."""
+        h, w = mask.shape[-2:]
+        if h % res == 0 and w % res == 0:
+            return mask[:, 0, ::h // res, ::w // res]
+        return F.interpolate(mask, size=(res, res), mode='nearest').squeeze(1)
 
     # ------------------------------------------------------------------------------------------
     def delta_state_dict(self):

@@ -85,6 +85,8 @@ class AttentionStore(AttentionControl):
         self.step_store = self.get_empty_store()
 
     def get_average_attention(self):
+        if self.cur_step == 1:      # x / 1 == x exactly: the training loop resets the store every step (16 + 16 launches saved)
+            return {key: list(self.attention_store[key]) for key in self.attention_store}
         return {key: [item / self.cur_step for item in self.attention_store[key]] for key in self.attention_store}
 
     def reset(self):

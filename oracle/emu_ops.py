@@ -8,7 +8,7 @@ Emulations compute in fp32 from the (possibly half) inputs and round the result 
 import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
-            'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd',
+            'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
             'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
 PAD = 16
 
@@ -188,7 +188,7 @@ def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
     return y.to(x.dtype), stats
 
 
-def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu):
+def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None):
     """Closed-form GroupNorm(+SiLU) input gradient from the saved (mean, rstd); checked against autograd in
     tests/test_host_cpu.py."""
     B, C = x.shape[0], x.shape[1]
@@ -206,7 +206,10 @@ def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu):
     g = (dz * gamma.reshape(shape)).reshape(B, groups, -1)
     xg = xh.reshape(B, groups, -1)
     dx = rstd * (g - g.mean(-1, keepdim=True) - xg * (g * xg).mean(-1, keepdim=True))
-    return dx.reshape(x.shape).to(x.dtype)
+    dx = dx.reshape(x.shape).to(x.dtype)
+    if ds is not None:            # mos_groupnorm_silu_bwd_nhwc_res: the rounded norm gradient + the bypass gradient, rounded
+        dx = (dx.float() + ds.float()).to(x.dtype)
+    return dx
 
 
 def layernorm_fwd(x, gamma, beta, eps, need_stats=True):
@@ -224,6 +227,34 @@ def layernorm_bwd(dy, x, gamma, stats):
     xh = (x.float() - mean) * rstd
     g = dy.float() * gamma
     return (rstd * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))).to(x.dtype)
+
+
+def add_layernorm_fwd(x, r, gamma, beta, eps, need_stats=True, half_dtype=None):
+    """mos_add_layernorm_fwd: s = x + r rounded to the stream dtype of x, y = LN(s) in the half dtype."""
+    if r is not None:
+        s = (x.float() + r.float()).to(x.dtype)
+        hd = r.dtype
+    else:
+        s = x
+        hd = x.dtype if x.dtype != torch.float32 else (half_dtype or torch.float16)
+    sf = s.float()
+    mean = sf.mean(-1, keepdim=True)
+    var = ((sf - mean) ** 2).mean(-1, keepdim=True)
+    rstd = torch.rsqrt(var + eps)
+    y = ((sf - mean) * rstd * gamma + beta).to(hd)
+    return s, y, (torch.cat([mean, rstd], -1) if need_stats else None)
+
+
+def add_layernorm_bwd(dy, ds, s, gamma, stats, half_copy=False):
+    """mos_add_layernorm_bwd: LN_bwd rounded to the stream dtype (as the unfused kernel does), + ds, rounded again."""
+    mean, rstd = stats[:, :1].float(), stats[:, 1:].float()
+    xh = (s.float() - mean) * rstd
+    g = dy.float() * gamma
+    dx = rstd * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+    if ds is not None:
+        dx = dx.to(s.dtype).float() + ds.float()
+    dx = dx.to(s.dtype)
+    return dx, (dx.to(dy.dtype) if half_copy else None)
 
 
 def geglu_fwd(h):

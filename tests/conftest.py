@@ -30,3 +30,20 @@ def emulated_hip(monkeypatch):
         monkeypatch.setattr(ops, name, getattr(emu_ops, name))
     monkeypatch.setenv('MOS_TEST_ALLOW_CPU', '1')
     yield
+
+
+@pytest.fixture()
+def gpu_branches(emulated_hip):
+    """CPU tests of the HOST code on the branches it takes on the GPU box: on top of `emulated_hip`, `Tensor.is_cuda`
+    answers True and the 'cuda' autocast queries report the CPU autocast state, so mixofshow.hip.functional and the models
+    route through their kernel-backed autograd Functions (whose kernels are the oracle's emulation here)."""
+    import torch
+    real_enabled, real_dtype = torch.is_autocast_enabled, torch.get_autocast_dtype
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.is_autocast_enabled = lambda device_type=None: real_enabled('cpu')
+    torch.get_autocast_dtype = lambda device_type=None: real_dtype('cpu')
+    try:
+        yield
+    finally:
+        del torch.Tensor.is_cuda                      # the C-level descriptor of the base class is visible again
+        torch.is_autocast_enabled, torch.get_autocast_dtype = real_enabled, real_dtype

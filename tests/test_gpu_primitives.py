@@ -414,6 +414,107 @@ def test_layernorm(ops, emu, dtype, rows, C):
     _check('layernorm.dx (emulation formula)', emu.layernorm_bwd(dy, x, gamma, stats_ref), dx_ref, dtype, ulps=3.0)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('silu', [True, False])
+@pytest.mark.parametrize('B,C,H,W', [(2, 320, 64, 64), (4, 640, 32, 32), (2, 1280, 8, 8), (1, 2560, 8, 8), (3, 64, 5, 7)])
+def test_groupnorm_bwd_with_bypass_gradient(ops, emu, dtype, silu, B, C, H, W):
+    """mos_groupnorm_silu_bwd_nhwc_res: dx = round(GN_bwd(dy)) + ds must equal the plain backward kernel followed by torch's
+    half add (autograd's accumulation) -- same rounding points; and both vs the emulation's closed form."""
+    g = torch.Generator(device='cpu').manual_seed(41)
+    cl = torch.channels_last
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to('cuda', dtype).contiguous(memory_format=cl)
+    dy = torch.randn(B, C, H, W, generator=g).to('cuda', dtype).contiguous(memory_format=cl)
+    ds = torch.randn(B, C, H, W, generator=g).to('cuda', dtype).contiguous(memory_format=cl)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    _, stats = ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, silu)
+    plain = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu)
+    fused = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu, ds=ds)
+    assert fused.stride() == x.stride()
+    exact = torch.equal(fused, plain + ds)
+    print(f'[parity] groupnorm_bwd_res[{B}x{C}x{H}x{W} silu={silu}] bit-identical to kernel + add: {exact}')
+    if not exact:
+        _check('groupnorm_bwd_res vs kernel + add', fused, plain + ds, dtype, ulps=1.0)
+    _check('groupnorm_bwd_res vs emulation', fused, emu.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu, ds=ds), dtype,
+           ulps=4.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,C', [(8192, 320), (2048, 640), (512, 1280), (2464, 768), (7, 24), (33, 2048)])
+def test_add_layernorm_half_stream_bit_identical_to_add_then_layernorm(ops, emu, dtype, rows, C):
+    """mos_add_layernorm_*: residual add fused into LayerNorm on a HALF stream (UNet blocks). s, y, stats and dx must equal
+    the separate torch add + mos_layernorm_* kernels BIT FOR BIT (same rounding points), with and without r / ds."""
+    g = torch.Generator(device='cpu').manual_seed(31)
+    x = (torch.randn(rows, C, generator=g) * 2.0 + 0.5).to('cuda', dtype)
+    r = torch.randn(rows, C, generator=g).to('cuda', dtype)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    dy = torch.randn(rows, C, generator=g).to('cuda', dtype)
+    ds = torch.randn(rows, C, generator=g).to('cuda', dtype)
+    def same(name, a, b):
+        # the two kernels evaluate the same expressions with the same rounding points; identical machine code is expected,
+        # a differing FMA contraction by the compiler would show up as a last-place difference: report, and bound it
+        exact = torch.equal(a, b)
+        print(f'[parity] add_layernorm[{rows}x{C}] {name}: bit-identical to the unfused kernels: {exact}')
+        if not exact:
+            _check(f'add_layernorm.{name} vs unfused', a, b, dtype, ulps=1.0)
+
+    s_ref = x + r
+    y_ref, st_ref = ops.layernorm_fwd(s_ref, gamma, beta, 1e-5)
+    s, y, st = ops.add_layernorm_fwd(x, r, gamma, beta, 1e-5)
+    assert torch.equal(s, s_ref)
+    same('y', y, y_ref)
+    _check('add_layernorm.stats', st, st_ref, torch.float16, ulps=0.01)
+    s0, y0, st0 = ops.add_layernorm_fwd(s_ref, None, gamma, beta, 1e-5)
+    assert s0 is s_ref
+    same('y (no r)', y0, y_ref)
+    _, y1, st1 = ops.add_layernorm_fwd(x, r, gamma, beta, 1e-5, need_stats=False)
+    assert st1 is None and torch.equal(y1, y)
+    dx_ln = ops.layernorm_bwd(dy, s_ref, gamma, st_ref)
+    dx, dxh = ops.add_layernorm_bwd(dy, None, s, gamma, st_ref)
+    assert dxh is None
+    same('dx', dx, dx_ln)
+    dx2, _ = ops.add_layernorm_bwd(dy, ds, s, gamma, st_ref)
+    assert torch.equal(dx2, dx + ds)                 # half(LN_bwd) + ds rounded once more: exactly autograd's accumulation
+    e_s, e_y, e_st = emu.add_layernorm_fwd(x, r, gamma, beta, 1e-5)
+    assert torch.equal(e_s, s)
+    _check(f'add_layernorm.y[{rows}x{C}] vs emulation', y, e_y, dtype, ulps=2.0)
+    _check('add_layernorm.dx vs emulation', dx2, emu.add_layernorm_bwd(dy, ds, s, gamma, st_ref)[0], dtype, ulps=3.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('rows,C', [(2464, 768), (77, 768), (5, 64), (130, 2048)])
+def test_add_layernorm_fp32_stream_vs_fp32_torch(ops, emu, dtype, rows, C):
+    """fp32 residual stream + half branch (the CLIP tower under autocast): s = x32 + r, statistics / y / dx from the fp32
+    sum, plus the half copy of dx for the branch -- vs torch fp32 autograd of the same expression."""
+    g = torch.Generator(device='cpu').manual_seed(32)
+    x = (torch.randn(rows, C, generator=g) * 2.0 + 0.5).cuda()
+    r = torch.randn(rows, C, generator=g).to('cuda', dtype)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    dy = torch.randn(rows, C, generator=g).to('cuda', dtype)
+    ds = torch.randn(rows, C, generator=g).cuda()
+    s, y, st = ops.add_layernorm_fwd(x, r, gamma, beta, 1e-5)
+    assert s.dtype == torch.float32 and y.dtype == dtype and torch.equal(s, x + r.float())
+    sf = s.clone().requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(sf, (C, ), gamma, beta, 1e-5)
+    _check(f'add_layernorm32.y[{rows}x{C}]', y, y_ref.detach(), dtype, ulps=1.0)
+    (dln_ref, ) = torch.autograd.grad(y_ref, sf, dy.float())
+    dx, dxh = ops.add_layernorm_bwd(dy, ds, s, gamma, st, half_copy=True)
+    assert dx.dtype == torch.float32 and dxh.dtype == dtype
+    ref = dln_ref + ds
+    assert ((dx - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-5).item(), (dx - ref).abs().max().item()
+    assert torch.equal(dxh, dx.to(dtype))
+    dx0, dxh0 = ops.add_layernorm_bwd(dy, None, s, gamma, st, half_copy=True)
+    assert ((dx0 - dln_ref).abs().max() <= 2e-5 * dln_ref.abs().max() + 1e-5).item() and torch.equal(dxh0, dx0.to(dtype))
+    # stream without a pending branch (first CLIP layer: the embeddings themselves), half dtype named by the caller
+    s1, y1, _ = ops.add_layernorm_fwd(x, None, gamma, beta, 1e-5, half_dtype=dtype)
+    assert s1 is x and y1.dtype == dtype
+    _check('add_layernorm32.y (no branch)', y1, torch.nn.functional.layer_norm(x, (C, ), gamma, beta, 1e-5), dtype, ulps=1.0)
+    e_dx, e_dxh = emu.add_layernorm_bwd(dy, ds, s, gamma, st, half_copy=True)
+    assert ((dx - e_dx).abs().max() <= 2e-5 * ref.abs().max() + 1e-5).item()
+
+
 def test_lora_gradient_finals_deferred_equal_immediate():
     """TrainEngine's scope batches the ordered final sums of all LoRA gradient groups into ONE launch
     (mos_lora_grad_final_all): bit-identical `.grad`s to the per-group final sums, also on a second pass (persistent

@@ -7,6 +7,11 @@ TAG="${1:-r03}"
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$ROOT"
 O="$ROOT/gpurun_out"; mkdir -p "$O"
+# the HBM-traffic PMC passes belong to the attention kernel sources (bench.PMC_SOURCE_FILES): re-collected only when those changed
+if python -c "import json,bench,sys; sys.exit(0 if json.load(open('profiles/pmc_traffic.json')).get('source_sha16') == bench.kernel_source_fingerprint() else 1)" 2>/dev/null \
+   && [ -z "${FORCE_PMC:-}" ]; then
+  echo "== PMC: profiles/pmc_traffic.json matches the attention kernel sources in the tree, passes not repeated"
+else
 echo "== PMC (attn,region): sq1 sq2 fetch write"
 PMC_BENCH_ARGS="--ref 0" bash tools/pmc_collect.sh attn,region > "$O/${TAG}_pmc_run.log" 2>&1
 cp "$O/pmc_attn,region.txt" "$O/${TAG}_pmc_attention_region_kernels.txt" 2>/dev/null
@@ -14,6 +19,7 @@ python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write > "$O/${TAG}_pmc_traff
 if python -c "import json,sys; d=json.load(open('$O/${TAG}_pmc_traffic.json')); sys.exit(0 if d.get('kernels') else 1)"; then
   cp "$O/${TAG}_pmc_traffic.json" profiles/pmc_traffic.json; echo "pmc_traffic.json refreshed: $(python -c "import json; print(list(json.load(open('profiles/pmc_traffic.json'))['kernels']))")"
 else echo "PMC FAILED"; tail -5 "$O/${TAG}_pmc_run.log"; fi
+fi
 echo "== default bench"
 timeout 900 python bench.py --steps 20 --warmup 5 > "$O/${TAG}_bench_train_n1.json" 2> "$O/${TAG}_bench_train_n1.err"
 tail -2 "$O/${TAG}_bench_train_n1.err"; cut -c1-260 "$O/${TAG}_bench_train_n1.json"

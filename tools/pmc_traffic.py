@@ -62,7 +62,7 @@ def main(fetch_dir, write_dir):
     print(json.dumps(dict(
         _comment='HBM bytes per launch from rocprofv3 --pmc passes over tools/bench_kernels.py --only attn,region (FETCH_SIZE and '
                  'WRITE_SIZE in separate passes; FETCH_SIZE KB x1024 x2 gfx950 correction, WRITE_SIZE KB x1024). '
-                 'Valid only for the kernel sources with this fingerprint (bench.py checks it).',
+                 'Valid only for the attention kernel sources with this fingerprint (bench.PMC_SOURCE_FILES; bench.py checks it).',
         source_sha16=bench.kernel_source_fingerprint(), kernels=kernels), indent=1))
 
 
