@@ -238,7 +238,7 @@ def _cpu_threads():
     return threads
 
 
-def cpu_baseline_train(trainer, size, budget_s=45.0):
+def cpu_baseline_train(trainer, size, budget_s=30.0):
     """Oracle path (plain torch fp32, full (B*H,N,77) maps, 3 launches per LoRA site) on the host cores, batch 1:
     1 warm-up + up to 4 timed forward+backward steps, median."""
     from oracle import trainer_ref
@@ -274,7 +274,7 @@ def cpu_baseline_train(trainer, size, budget_s=45.0):
                        'oracle (oracle/trainer_ref.py: full probability maps, 3-GEMM LoRA); optimiser step excluded')
 
 
-def cpu_baseline_regional(preset, H, W, budget_s=40.0):
+def cpu_baseline_regional(preset, H, W, budget_s=28.0):
     """One regional UNet call (CFG pair, oracle region processors, fp32) on the host cores, extrapolated x50."""
     from oracle import region_ref
     threads = _cpu_threads()

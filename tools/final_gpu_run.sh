@@ -40,3 +40,9 @@ cd "$ROOT"
 grep -E "attn_bwd_dkdv_kernelIDF16_Li40|conv3x3_nhwc_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_train.csv" | cut -c1-160 | head -6
 grep -E "attn_fwd_kernelIDF16_Li40|region_attn_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_regional.csv" | cut -c1-160 | head -6
 cut -c1-200 "$O/${TAG}_bench_train_under_rocprof.json"; cut -c1-200 "$O/${TAG}_bench_regional_under_rocprof.json"
+
+# last, if the box still has time: the end-to-end tests the validation call did not cover (regional parity, fusion on GPU)
+echo "== remaining end-to-end tests (time-capped)"
+timeout ${TAIL_TESTS_TIMEOUT:-100} python -m pytest tests/test_gpu_end_to_end.py -m gpu -q -x -s \
+  -k "regional_sd15_hot_path_error_teacher_forced or fusion_feature_collection or hipgraph_regional" > "$O/${TAG}_tail_tests.log" 2>&1
+echo "rc=$?"; grep -E "^\[parity\]|passed|failed" "$O/${TAG}_tail_tests.log" | cut -c1-300 | tail -8
