@@ -153,7 +153,7 @@ def dominant_by_kernel_name(records, per):
         a['calls'] += r['calls']
     lib_ms = sum(a['ms'] for a in agg.values())
     out = []
-    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:6]:
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]:
         sec = a['ms'] * 1e-3
         out.append(dict(kernel=k, ms=round(a['ms'] / per, 3), launches=a['calls'] / per,
                         share_of_library_gpu_time=round(a['ms'] / max(1e-9, lib_ms), 4),

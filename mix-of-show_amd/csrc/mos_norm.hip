@@ -8,6 +8,7 @@
 // gamma/beta are frozen in ED-LoRA training (no affine gradients are produced).
 #include <cstdio>
 #include <type_traits>
+#include <cstdlib>
 #include "mos_common.h"
 
 namespace {
@@ -349,7 +350,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_reduce_kernel(GnNhwcArgs a) {
 
 // DS (backward): out = half(dx) + ds -- the gradient of a residual connection that bypasses this norm, added where autograd
 // would otherwise launch a separate accumulation kernel (same rounding points: dx rounded to T, then the half add)
-template <typename T, int VT, bool BWD, bool SILU, bool DS = false>
+// FIN: the per-group constants were combined once per image by gn_nhwc_finalize_kernel (a.partial + fin_off); otherwise every
+// block combines the nsplit slice partials itself (the original scheme: at the UNet's sizes that prologue -- up to 128 x G x 2
+// partials per block -- moves more L2 traffic per block than the block's own slice of the activation).
+template <typename T, int VT, bool BWD, bool SILU, bool DS = false, bool FIN = false>
 __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     static_assert(BWD || !DS, "the bypass gradient exists in backward only");
     typedef typename MT<T>::v8 v8;
@@ -361,6 +365,14 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     // second-stage combine of the nsplit slice partials, by ALL threads (a single thread per group walking nsplit
     // dependent loads cost 40 us at nsplit = 128): coalesced loads, double accumulation in LDS
     __shared__ double acc_s[128];
+    if constexpr (FIN) {
+        if (tid < a.G) {
+            const float* fin = a.partial + (int64_t)a.B * a.nsplit * a.G * 2 + ((int64_t)b * a.G + tid) * 2;
+            u_s[tid] = fin[0]; w_s[tid] = fin[1];
+            if (BWD) { m_s[tid] = a.stats[(b * a.G + tid) * 2]; r_s[tid] = a.stats[(b * a.G + tid) * 2 + 1]; }
+        }
+        __syncthreads();
+    } else {
     for (int i = tid; i < 2 * a.G; i += blockDim.x) acc_s[i] = 0.0;
     __syncthreads();
     {
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
         }
     }
     __syncthreads();
+    }   // !FIN
     // per-channel constants of this thread's vectors
     float c0[VT][8], c1[VT][8], c2[VT][8], c3[VT][8], c4[VT][8], c5[VT][8];
 #pragma unroll
@@ -470,6 +483,51 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     }
 }
 
+// One block per image: the nsplit slice partials of every group -> the per-group constants the apply kernel needs (forward: mean,
+// rstd, also written to `stats`; backward: mean(g), mean(g xhat)). Each of the 2G (group, moment) columns is summed by two threads
+// (even / odd slices, independent coalesced loads, double accumulation, fixed order: deterministic).
+template <bool BWD>
+__global__ __launch_bounds__(256) void gn_nhwc_finalize_kernel(GnNhwcArgs a) {
+    __shared__ double part[2][128];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int e = tid & 127, q = tid >> 7, n2 = 2 * a.G;
+    double acc = 0.0;
+    if (e < n2) {
+        const float* pb = a.partial + (int64_t)b * a.nsplit * n2 + e;
+        int s = q;
+        for (; s + 14 < a.nsplit; s += 16) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pb[(int64_t)(s + 2 * j) * n2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (double)v[j];
+        }
+        for (; s < a.nsplit; s += 2) acc += (double)pb[(int64_t)s * n2];
+    }
+    part[q][e] = acc;
+    __syncthreads();
+    if (tid < a.G) {
+        const double t0 = part[0][tid * 2] + part[1][tid * 2], t1 = part[0][tid * 2 + 1] + part[1][tid * 2 + 1];
+        const double n = (double)a.cpg * a.HW;
+        float* fin = a.partial + (int64_t)a.B * a.nsplit * n2 + ((int64_t)b * a.G + tid) * 2;
+        if (!BWD) {
+            const double m = t0 / n;
+            double var = t1 / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            fin[0] = mean; fin[1] = rstd;
+            if (a.stats != nullptr) { a.stats[(b * a.G + tid) * 2] = mean; a.stats[(b * a.G + tid) * 2 + 1] = rstd; }
+        } else {
+            fin[0] = (float)(t0 / n); fin[1] = (float)(t1 / n);
+        }
+    }
+}
+
+bool gn_finalize_enabled() {
+    static const bool v = [] { const char* e = getenv("MOS_GN_FINALIZE"); return e == nullptr || atoi(e) != 0; }();
+    return v;
+}
+
 bool gn_nhwc_plan(GnNhwcArgs& a) {
     a.V = a.C / 8;
     const int vt = (a.V + 255) / 256;
@@ -506,6 +564,30 @@ int gn_nhwc_run(GnNhwcArgs a, int silu, hipStream_t st) {
     }
     int rc = mos_check_launch("gn_nhwc_reduce");
     if (rc) return rc;
+    if (gn_finalize_enabled()) {
+        {
+            MosProfScope prof(st, BWD ? "groupnorm_bwd_finalize" : "groupnorm_finalize", key, 2.0 * a.B * a.nsplit * a.G,
+                              8.0 * a.B * a.nsplit * a.G);
+            hipLaunchKernelGGL((gn_nhwc_finalize_kernel<BWD>), dim3(a.B), dim3(256), 0, st, a);
+        }
+        rc = mos_check_launch("gn_nhwc_finalize");
+        if (rc) return rc;
+        MosProfScope prof(st, BWD ? "groupnorm_bwd_apply" : "groupnorm_apply", key, (BWD ? 14.0 : 8.0) * n, (BWD ? 6.0 : 4.0) * n);
+#define GN_APPLY_FIN(VTN, S, D) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, VTN, BWD, S, D, true>), grid, block, 0, st, a)
+        bool has_ds = false;
+        if constexpr (BWD) has_ds = a.ds != nullptr;
+        if constexpr (BWD) {
+            if (has_ds) {
+                if (vt == 1) { if (silu) GN_APPLY_FIN(1, true, true); else GN_APPLY_FIN(1, false, true); }
+                else { if (silu) GN_APPLY_FIN(2, true, true); else GN_APPLY_FIN(2, false, true); }
+                return mos_check_launch("gn_nhwc_apply");
+            }
+        }
+        if (vt == 1) { if (silu) GN_APPLY_FIN(1, true, false); else GN_APPLY_FIN(1, false, false); }
+        else { if (silu) GN_APPLY_FIN(2, true, false); else GN_APPLY_FIN(2, false, false); }
+#undef GN_APPLY_FIN
+        return mos_check_launch("gn_nhwc_apply");
+    }
     MosProfScope prof(st, BWD ? "groupnorm_bwd_apply" : "groupnorm_apply", key, (BWD ? 14.0 : 8.0) * n, (BWD ? 6.0 : 4.0) * n);
     if constexpr (BWD) {
         if (a.ds != nullptr) {
@@ -575,7 +657,7 @@ int64_t mos_groupnorm_nhwc_workspace_bytes(int B, int C, int HW, int G) {
     if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G || C % 8) return 0;
     a.cpg = C / G;
     if (!gn_nhwc_plan(a)) return 0;
-    return (int64_t)B * a.nsplit * G * 2 * (int64_t)sizeof(float);
+    return ((int64_t)B * a.nsplit * G * 2 + (int64_t)B * G * 2) * (int64_t)sizeof(float);   // slice partials + finalised constants
 }
 
 int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* beta, void* y, float* stats, void* ws,

@@ -369,8 +369,13 @@ class UNet2DConditionModel(nn.Module):
         emb = self.time_embedding(t_emb)
 
         if torch.is_tensor(encoder_hidden_states) and encoder_hidden_states.dim() == 4 and sample.is_cuda:
-            from mixofshow.models.edlora import attach_layer_major_states
-            attach_layer_major_states(encoder_hidden_states)          # one transpose instead of 16 strided gathers
+            from mixofshow.models import edlora
+            attn2 = self.__dict__.get('_attn2_modules')
+            if attn2 is None:
+                attn2 = [m for n, m in self.named_modules() if isinstance(m, Attention) and n.endswith('attn2')]
+                object.__setattr__(self, '_attn2_modules', attn2)
+            if any(isinstance(m.processor, (edlora.EDLoRA_AttnProcessor, edlora.EDLoRA_Control_AttnProcessor)) for m in attn2):
+                edlora.attach_layer_major_states(encoder_hidden_states)   # one transpose instead of 16 strided gathers
 
         if getattr(self, 'channels_last', False):
             sample = sample.contiguous(memory_format=torch.channels_last)
