@@ -284,7 +284,9 @@ int mos_groupnorm_silu_bwd(const void* dy, const void* x, const float* gamma, co
 /* Same operator on channels-last activations: x, y, dy, dx are (B, HW, C) contiguous — the layout of the token-major
  * attention path and of MIOpen's fp16 NHWC implicit-GEMM convolutions, so a UNet kept in channels_last needs no
  * NCHW<->NHWC transposes around convolutions and no permute copies around the transformer blocks. C % 8 == 0,
- * C <= 4096, G <= 64. ws: mos_groupnorm_nhwc_workspace_bytes() bytes. */
+ * C <= 4096, G <= 64. ws: mos_groupnorm_nhwc_workspace_bytes() bytes (per-slice partial sums + the per-group constants
+ * one block per image folds them into; environment MOS_GN_FINALIZE=0: every apply block folds the partials itself, the
+ * round-2 scheme, same results). */
 int64_t mos_groupnorm_nhwc_workspace_bytes(int B, int C, int HW, int G);
 int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                 void* ws, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);

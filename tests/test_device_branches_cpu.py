@@ -150,3 +150,123 @@ def test_trainer_step_on_gpu_branches_fused_vs_unfused_and_vs_plain_cpu_path(emu
           f'grad rel L2 fused/plain {rel(gf, gp):.2e} unfused/plain {rel(gu, gp):.2e} fused/unfused {rel(gf, gu):.2e}')
     assert abs(lf - lp) <= 2e-3 * abs(lp) and abs(lu - lp) <= 2e-3 * abs(lp)
     assert rel(gf, gp) <= 1.5e-2 and rel(gu, gp) <= 1.5e-2 and rel(gf, gu) <= 1.5e-2
+
+
+# ---- host logic introduced with the launch reduction (plain CPU: no fixtures needed) ----------------------------------------
+@pytest.mark.parametrize('identity', [False, True])
+@pytest.mark.parametrize('mask_hw', [32, 24, 16])
+def test_vectorised_attention_regulariser_equals_the_reference_loop(identity, mask_hw):
+    """EDLoRATrainer.cal_attn_reg (both token columns and all resolutions through shared kernels, strided-view mask
+    down-sampling, no division by the head count) against the oracle's restatement of the reference loop
+    (trainer_edlora.py:263-313) on random maps: value and gradient w.r.t. every map. mask 24 px: 16-px maps take the
+    F.interpolate branch (24 % 16 != 0), 8-px maps the strided view."""
+    import types
+    from mixofshow.pipelines.trainer_edlora import EDLoRATrainer
+    from oracle import edlora_ref as R
+    g = torch.Generator().manual_seed(17)
+    B, H, pos = 2, 4, [3, 5]
+    full, cols = {'down_cross': [], 'up_cross': []}, {'down_cross': [], 'up_cross': []}
+    leaves = []
+    for place, res in (('down_cross', 16), ('down_cross', 8), ('up_cross', 8), ('up_cross', 16), ('up_cross', 16)):
+        m = torch.softmax(torch.randn(B * H, res * res, 77, generator=g) * 2, -1).requires_grad_(True)
+        leaves.append(m)
+        full[place].append(m)
+        cols[place].append(m.reshape(B, H, res * res, 77)[..., pos])
+    masks = (torch.rand(B, 1, mask_hw, mask_hw, generator=g) > 0.4).float()
+    ids = torch.zeros(B * 16, 77, dtype=torch.long)
+    ids[:, pos[0]], ids[:, pos[1]] = 11, 12
+    ref = R.cal_attn_reg_ref(full, masks, ids, {11, 12}, 0.01, identity, strict_resolutions=False)
+    g_ref = torch.autograd.grad(ref, leaves)
+    me = types.SimpleNamespace(attn_reg_weight=0.01, reg_full_identity=identity, _mask_at=EDLoRATrainer._mask_at)
+    got = EDLoRATrainer.cal_attn_reg(me, cols, masks)
+    g_got = torch.autograd.grad(got, leaves)
+    assert abs(got.item() - ref.item()) <= 1e-6 * abs(ref.item()) + 1e-9
+    for a, b in zip(g_got, g_ref):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-12
+    # the (finite value, valid flag) form the training step uses
+    val, ok = EDLoRATrainer.cal_attn_reg(me, cols, masks, return_valid=True)
+    assert bool(ok) and abs(val.item() - ref.item()) <= 1e-6 * abs(ref.item()) + 1e-9
+
+
+def test_layer_major_text_states_cache_and_gradient():
+    """attach_layer_major_states: the per-layer slices equal states[:, k]; their gradient is the gradient of slicing; the
+    attachment is refreshed when the tensor changes in place or the grad mode differs, and processors fall back to slicing
+    when it is stale or absent."""
+    from mixofshow.models import edlora
+    torch.manual_seed(2)
+    st = torch.randn(2, 16, 7, 8, requires_grad=True)
+    w = torch.randn(16, 2, 7, 8)
+    edlora.attach_layer_major_states(st)
+    layers = [edlora._select_layer_states(st, k) for k in range(16)]
+    assert all(l.is_contiguous() and torch.equal(l, st[:, k]) for k, l in enumerate(layers))
+    sum((l * w[k]).sum() for k, l in enumerate(layers)).backward()
+    assert torch.allclose(st.grad, w.transpose(0, 1))
+    # detached tensor: cached across calls of a sampling loop, recomputed after an in-place update
+    pe = torch.randn(2, 16, 7, 8)
+    edlora.attach_layer_major_states(pe)
+    first = pe._mos_layers
+    edlora.attach_layer_major_states(pe)
+    assert pe._mos_layers is first
+    pe.mul_(2.0)
+    assert torch.equal(edlora._select_layer_states(pe, 3), pe[:, 3])          # stale attachment: falls back to slicing
+    edlora.attach_layer_major_states(pe)
+    assert pe._mos_layers is not first and torch.equal(pe._mos_layers[1][3], pe[:, 3])
+    # attached under no_grad, used with grad: re-attached so that gradients flow
+    q = torch.randn(1, 16, 3, 8, requires_grad=True)
+    with torch.no_grad():
+        edlora.attach_layer_major_states(q)
+    edlora.attach_layer_major_states(q)
+    edlora._select_layer_states(q, 0).sum().backward()
+    assert q.grad is not None and float(q.grad[:, 0].sum()) == 24.0 and float(q.grad[:, 1:].abs().sum()) == 0.0
+
+
+def test_time_embedding_activation_is_computed_once_per_embedding():
+    from mixofshow.models import unet_2d_condition as U
+    act = torch.nn.SiLU()
+    calls = []
+    spy = lambda t: (calls.append(1), act(t))[1]
+    e = torch.randn(2, 8)
+    a, b = U._act_once(spy, e), U._act_once(spy, e)
+    assert a is b and len(calls) == 1
+    e.add_(1.0)                                             # in-place change: recomputed
+    c = U._act_once(spy, e)
+    assert len(calls) == 2 and torch.equal(c, act(e))
+    e2 = e.clone().requires_grad_(True)                     # another tensor: recomputed, graph attached
+    d = U._act_once(spy, e2)
+    assert len(calls) == 3 and d.requires_grad
+    with torch.no_grad():
+        f = U._act_once(spy, e2)                            # same tensor, grad mode differs: not the cached graph-carrying one
+    assert len(calls) == 4 and not f.requires_grad
+
+
+def test_edlora_sampling_on_gpu_branches_fp16_vs_fp32_plain_path(emulated_hip):
+    """The ED-LoRA sampling pipeline in fp16 through the kernel-backed branches (no grad: add+LayerNorm forward fusion,
+    GroupNorm / conv Functions, layer-major text states under CFG) against the same pipeline in fp32 on the plain CPU branches.
+    4 steps on the tiny model: the difference is the fp16 rounding of weights and activations."""
+    from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline
+    from tests.test_pipelines_cpu import _concept_cfg
+    kw = dict(prompt=['a <potter1> <potter2> in the park', 'a photo of a dog'], negative_prompt=['blurry', ''],
+              height=64, width=64, num_inference_steps=4, guidance_scale=7.5, output_type='latent')
+    latents = torch.randn((2, 4, 8, 8), generator=torch.manual_seed(1))
+
+    def build(dtype):
+        pipe = EDLoRAPipeline.from_pretrained('synthetic://tiny?seed=0', torch_dtype=dtype)
+        pipe.set_new_concept_cfg(_concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>']))
+        return pipe
+
+    ref = build(torch.float32)(latents=latents.clone(), **kw).images
+    pipe = build(torch.float16)
+    real_enabled, real_dtype = torch.is_autocast_enabled, torch.get_autocast_dtype
+    torch.Tensor.is_cuda = property(lambda self: True)
+    torch.is_autocast_enabled = lambda device_type=None: real_enabled('cpu')
+    torch.get_autocast_dtype = lambda device_type=None: real_dtype('cpu')
+    try:
+        out = pipe(latents=latents.clone().half(), **kw).images
+    finally:
+        del torch.Tensor.is_cuda
+        torch.is_autocast_enabled, torch.get_autocast_dtype = real_enabled, real_dtype
+    assert out.dtype == torch.float16 and torch.isfinite(out).all()
+    err = (out.float() - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    print(f'[parity] tiny EDLoRA sampling, fp16 on GPU branches (emulated) vs fp32 plain path, 4 steps: max|d| = {err:.3e} on scale {scale:.2f}')
+    assert err <= 3e-2 * scale
