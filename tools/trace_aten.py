@@ -147,6 +147,64 @@ def patch_device_queries():
     torch.get_autocast_dtype = lambda device_type=None: real_dtype('cpu')
 
 
+def report(tracer, header, top, out):
+    rows = sorted(tracer.rows.items(), key=lambda kv: -kv[1])
+    lines = [header]
+    by_op, by_mos = collections.Counter(), collections.Counter()
+    for (phase, name, desc, site), n in rows:
+        (by_mos if name.startswith('mos::') else by_op)[(phase, name.split('::')[1])] += n
+    lines.append(f'# launches: library {sum(by_mos.values())}, ATen {sum(by_op.values())}')
+    lines.append('# ATen launches by op: ' + ', '.join(f'{p}:{o}={n}' for (p, o), n in by_op.most_common(40)))
+    lines.append('# library launches by primitive: ' + ', '.join(f'{p}:{o}={n}' for (p, o), n in by_mos.most_common()))
+    shown = 0
+    for (phase, name, desc, site), n in rows:
+        if name.startswith('mos::'):
+            continue
+        lines.append(f'{n:5d} {phase} {name[6:]:22s} {desc:60s} {site}')
+        shown += 1
+        if shown >= top:
+            break
+    text = '\n'.join(lines)
+    print(text)
+    if out:
+        with open(out, 'w') as f:
+            f.write(text + '\n')
+
+
+def trace_regional(args, tracer, bench):
+    """One UNet call (CFG pair) of the regional sampling pipeline in fp16, third step of a 3-step run (caches warm)."""
+    from mixofshow.hip import functional as F_hip
+    H, W = args.size, args.size * 3 // 2
+    pipe = bench.build_regional_pipe(args.preset, 'cpu')
+    pipe.unet.to(memory_format=torch.channels_last)
+    px = [[int(b[0] * H / 512), int(b[1] * W / 768), int(b[2] * H / 512), int(b[3] * W / 768)] for b in bench.REGION_PX]
+    ctx = 'three people near the castle, 4K, high quality, high resolution, best quality'
+    neg = 'longbody, lowres, bad anatomy'
+    regs = ['a <potter1> <potter2>, in Hogwarts uniform', 'a <hermione1> <hermione2>, girl', 'a <thanos1> <thanos2>, purple armor']
+    prompt = [(ctx, [(p, neg, [b[0] / H, b[1] / W, b[2] / H, b[3] / W]) for p, b in zip(regs, px)])]
+    real_px, bench.REGION_PX = bench.REGION_PX, px
+    adapter_states = bench.synthetic_adapter_states(pipe, H, W, 'cpu', torch.float16)
+    bench.REGION_PX = real_px
+    latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14))
+    patch_device_queries()
+    F_hip._conv_min_pixels = 0
+    calls = {'n': 0}
+    real_forward = pipe.unet.forward
+
+    def forward(*a, **k):
+        calls['n'] += 1
+        if calls['n'] == 3:
+            with tracer:
+                return real_forward(*a, **k)
+        return real_forward(*a, **k)
+
+    pipe.unet.forward = forward
+    pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=3, guidance_scale=7.5,
+         latents=latents, output_type='latent', hipgraph=False, adapter_states=adapter_states)
+    report(tracer, f'# one regional UNet call (CFG pair, {H}x{W}, 3 regions, fp16, adapter states), preset {args.preset}', args.top,
+           args.out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--preset', default='sd15')
@@ -154,6 +212,7 @@ def main():
     ap.add_argument('--batch', type=int, default=2)
     ap.add_argument('--top', type=int, default=80)
     ap.add_argument('--out', default=None)
+    ap.add_argument('--mode', default='train', choices=['train', 'regional'])
     args = ap.parse_args()
     torch.manual_seed(0)
     import bench
@@ -163,6 +222,8 @@ def main():
 
     tracer = Tracer()
     install_emulation(tracer)
+    if args.mode == 'regional':
+        return trace_regional(args, tracer, bench)
     trainer = bench.build_trainer(args.preset, 'cpu')
     trainer.unet.train()
     trainer.text_encoder.train()
