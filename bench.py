@@ -185,7 +185,9 @@ ATTENTION_PATH_KERNELS = ('attn_', 'region_attn', 'gemm_nt', 'lora_')
 def _tuning_switches():
     """The host-side kernel-dispatch switches in effect (defaults unless overridden in the environment)."""
     from mixofshow.hip import functional as F_hip
-    return dict(conv3x3_min_pixels=F_hip._conv_min_pixels, ring_max_wg=int(os.environ.get('MOS_RING_MAX_WG', -1)))
+    return dict(conv3x3_min_pixels=F_hip._conv_min_pixels, ring_max_wg=int(os.environ.get('MOS_RING_MAX_WG', -1)),
+                fuse_add_layernorm=bool(F_hip._fuse_add_ln), fuse_groupnorm_skip_grad=bool(F_hip._fuse_gn_res),
+                groupnorm_finalize=os.environ.get('MOS_GN_FINALIZE', '1') != '0')
 
 
 def attention_path_aggregate(gflop_per_unit, units, recs, per):

@@ -6,6 +6,8 @@
                   key positions (what cal_attn_reg needs, trainer_edlora.py:289-298).
 Both save only what the backward kernels need (no (B*H, N, 77) probability tensors).
 """
+import os as _os
+
 import torch
 
 from . import ops
@@ -554,11 +556,6 @@ class _GroupNormSiLUTap(torch.autograd.Function):
         return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu) + ds, None, None, None, None, None
 
 
-def _os_env(name, default):
-    import os
-    return os.environ.get(name, default)
-
-
 def _frozen(*params):
     """True when no gradient will be asked for these parameters: they are frozen, or autograd is off (sampling pipelines run
     under no_grad with ordinary requires_grad=True modules)."""
@@ -692,8 +689,9 @@ class _AddLayerNorm(torch.autograd.Function):
         return dx, dr, None, None, None, None
 
 
-_fuse_add_ln = _os_env('MOS_FUSE_ADD_LN', '1') != '0'
-_fuse_gn_res = _os_env('MOS_FUSE_GN_RES', '1') != '0'
+# A/B switches (tests, bench): '0' routes through the separate add + norm kernels of round 2
+_fuse_add_ln = _os.environ.get('MOS_FUSE_ADD_LN', '1') != '0'
+_fuse_gn_res = _os.environ.get('MOS_FUSE_GN_RES', '1') != '0'
 
 
 def add_layer_norm(norm, x, r=None):
@@ -864,8 +862,6 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
     w_fwd, w_bwd, bias32 = cache.get(conv, dt, need_bwd and x.requires_grad)
     return _Conv3x3.apply(x, w_fwd, w_bwd, bias32, tbias, residual, bool(upsample))
 
-
-import os as _os
 
 _conv_enabled = _os.environ.get('MOS_CONV3X3', '1') != '0'
 _conv1x1_enabled = _os.environ.get('MOS_CONV1X1', '1') != '0'
