@@ -89,6 +89,51 @@ def synthetic_batch(B, size, device, seed):
                 prompts=['a <potter1> <potter2> in the park, 4K, high quality'] * B)
 
 
+# ---- the step fed by the data pipeline (JPEG decode -> PIL transform chain -> collate -> pinned H2D) -----------
+JPEG_TRANSFORMS = [dict(type='HumanResizeCropFinalV3', size=512, crop_p=0.5), dict(type='ToTensor'),
+                   dict(type='Normalize', mean=[0.5], std=[0.5]), dict(type='ShuffleCaption', keep_token_num=1),
+                   dict(type='EnhanceText', enhance_type='human')]     # the shipped recipe's instance_transform chain
+
+
+def make_jpeg_concept(root, n_images=8, side=768, seed=0):
+    """A concept folder in the reference's layout (images/, mask/, caption/ + concept list json) with `n_images` synthetic
+    photographs: smooth random fields (so that JPEG decode cost is that of a real photo, not of white noise), a centred
+    elliptical subject mask, one caption per image. Returns the path of the concept list."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    img_dir, mask_dir, cap_dir = (os.path.join(root, d) for d in ('image', 'mask', 'caption'))
+    for d in (img_dir, mask_dir, cap_dir):
+        os.makedirs(d, exist_ok=True)
+    yy, xx = np.mgrid[0:side, 0:side].astype(np.float32) / side
+    for i in range(n_images):
+        low = rng.rand(12, 12, 3).astype(np.float32)
+        img = np.asarray(Image.fromarray((low * 255).astype(np.uint8)).resize((side, side), Image.BICUBIC), dtype=np.float32)
+        img = np.clip(img + rng.randn(side, side, 3) * 6.0, 0, 255).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(img_dir, f'{i:03d}.jpg'), quality=92)
+        cx, cy, rx, ry = 0.5 + 0.1 * rng.randn(), 0.5 + 0.05 * rng.randn(), 0.22, 0.38
+        mask = ((((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2) <= 1.0).astype(np.uint8) * 255
+        Image.fromarray(mask, mode='L').save(os.path.join(mask_dir, f'{i:03d}.png'))
+        with open(os.path.join(cap_dir, f'{i:03d}.txt'), 'w') as f:
+            f.write('<TOK>, standing in the park, looking at the camera, 4K, high quality\n')
+    clist = os.path.join(root, 'concept.json')
+    with open(clist, 'w') as f:
+        json.dump([dict(instance_prompt='<TOK>', instance_data_dir=img_dir, caption_dir=cap_dir, mask_dir=mask_dir)], f)
+    return clist
+
+
+def jpeg_loader(root, batch, size, workers, seed=0, n_images=8):
+    """DataLoader over LoraDataset (mixofshow.data: the reference's dataset + transform chain) on a synthetic JPEG concept."""
+    from mixofshow.data.lora_dataset import LoraDataset
+    tf = [dict(t, size=size) if t['type'] == 'HumanResizeCropFinalV3' else dict(t) for t in JPEG_TRANSFORMS]
+    ds = LoraDataset(dict(name='LoraDataset', concept_list=make_jpeg_concept(root, n_images, seed=seed), use_caption=True,
+                          use_mask=True, replace_mapping={'<TOK>': '<potter1> <potter2>'}, dataset_enlarge_ratio=100000,
+                          instance_transform=tf))
+    kw = dict(num_workers=workers, persistent_workers=True, prefetch_factor=4) if workers > 0 else {}
+    return torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=True, drop_last=True,
+                                       pin_memory=torch.cuda.is_available(), **kw)
+
+
 # ---- roofline helpers ---------------------------------------------------------------------------------------------
 # the translation unit, shared header and build recipe of every kernel profiles/pmc_traffic.json covers (the attention and
 # regional kernels all live in mos_attn.hip): the PMC numbers stay valid exactly as long as these files are unchanged
@@ -325,6 +370,25 @@ def run_train(args, rank, world, device):
     engine = TrainEngine(trainer, dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g'])), total_iter=1e9,
                          mixed_precision=args.precision, channels_last=args.channels_last)
     batches = [synthetic_batch(B, size, device, 1000 * rank + i) for i in range(2)]
+    next_batch, data_info, tmp_dir = (lambda i: batches[i % 2]), None, None
+    if args.data == 'jpeg':
+        # every timed step consumes a batch that was decoded from JPEG, pushed through the reference's
+        # transform chain by DataLoader workers, collated, pinned and copied to the device inside the timed region
+        import tempfile
+        tmp_dir = tempfile.TemporaryDirectory(prefix='mos_jpeg_')
+        loader = jpeg_loader(tmp_dir.name, B, size, args.workers, seed=rank)
+        it = iter(loader)
+        batches = [next(it) for _ in range(2)]                  # also spins the workers up
+        n_probe = 8
+        t_l = time.perf_counter()
+        for _ in range(n_probe):                                # loader-only throughput (no training step consuming)
+            next(it)
+        loader_ips = B * n_probe / (time.perf_counter() - t_l)
+        next_batch = lambda i: next(it)
+        data_info = dict(source='synthetic JPEG concept (8 photos 768x768 q92, masks, captions)', workers=args.workers,
+                         transforms=[t['type'] for t in JPEG_TRANSFORMS], pin_memory=bool(torch.cuda.is_available()),
+                         loader_only_images_per_sec=round(loader_ips, 2))
+        _log(f'data pipeline ready: {args.workers} workers, loader alone {loader_ips:.1f} images/s')
     graphed = False
     if args.graph:
         try:
@@ -336,14 +400,20 @@ def run_train(args, rank, world, device):
             torch.cuda.synchronize()
             import traceback
             _log(f'hipGraph capture failed ({type(e).__name__}); running eager\n' + traceback.format_exc())
+    if data_info is not None:
+        def to_dev(b):
+            return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in b.items()}
+        batches = [to_dev(b) for b in batches]                  # the eager profiled pass below takes device tensors
+        if not graphed:                                         # (a replayed step copies pinned host batches straight into its
+            next_batch = lambda i: to_dev(next(it))             #  static input buffers: one H2D, no staging allocation)
     for i in range(args.warmup):
-        engine.step(batches[i % 2])
+        engine.step(next_batch(i))
         torch.cuda.synchronize()
         _log(f'warmup step {i} done')
     _sync_barrier(world)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        engine.step(batches[i % 2])
+        engine.step(next_batch(i))
     _sync_barrier(world)
     dt = _max_over_ranks(time.perf_counter() - t0, world, device)
     _log(f'timed region: {args.steps} steps in {dt:.3f}s')
@@ -360,7 +430,8 @@ def run_train(args, rank, world, device):
         metric='edlora_train_images_per_sec_512_sd15', value=round(B * world * args.steps / dt, 4), unit='images/s',
         n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
         higher_is_better=True, scaling='weak', vs_baseline=None,
-        dtype={'fp16': 'fp16', 'bf16': 'bf16'}.get(args.precision, 'fp16'), data='synthetic',
+        dtype={'fp16': 'fp16', 'bf16': 'bf16'}.get(args.precision, 'fp16'),
+        data='synthetic' if data_info is None else 'synthetic-jpeg (decode + transforms + H2D inside the timed region)',
         config=dict(workload='BASELINE.json configs[1]: single-concept ED-LoRA tune, SD-1.5 UNet/CLIP/VAE '
                              f'(random init, calibrated), {size}x{size}, LoRA rank 4 on Attention+CLIPAttention, '
                              f'attn_reg on, batch {B}/GPU', global_batch=B * world, per_gpu_batch=B, image_size=size,
@@ -372,6 +443,10 @@ def run_train(args, rank, world, device):
         dominant_kernels_by_name=dominant_by_kernel_name(recs, 2) if recs else None,
         whole_step=whole_step_utilisation(recs, 2, B, dt / args.steps * 1e3) if recs else None,
         kernels=_kernel_table(recs, 2), library_kernel_ms_per_step=round(lib_ms, 3))
+    if data_info is not None:
+        result['data_pipeline'] = data_info
+        del it, loader
+        tmp_dir.cleanup()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_train(trainer, size)
     del engine, trainer
@@ -597,6 +672,10 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--preset', default='sd15')
     ap.add_argument('--precision', default='fp16', choices=['fp16', 'bf16'])
+    ap.add_argument('--data', default='synthetic', choices=['synthetic', 'jpeg'],
+                    help='train: device-resident synthetic batches (the metric) or, SURVEY 8(f).4, batches decoded from JPEG '
+                         'through the dataset / transform chain by DataLoader workers inside the timed region')
+    ap.add_argument('--workers', type=int, default=8, help='--data jpeg: DataLoader worker processes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-regional', action='store_true', help='train mode: skip the regional-sample half of the metric')
     ap.add_argument('--channels-last', type=int, default=1, help='NHWC UNet/VAE (the product default)')

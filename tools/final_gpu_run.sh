@@ -41,6 +41,9 @@ grep -E "attn_bwd_dkdv_kernelIDF16_Li40|conv3x3_nhwc_kernel" "$O/${TAG}_rocprofv
 grep -E "attn_fwd_kernelIDF16_Li40|region_attn_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_regional.csv" | cut -c1-160 | head -6
 cut -c1-200 "$O/${TAG}_bench_train_under_rocprof.json"; cut -c1-200 "$O/${TAG}_bench_regional_under_rocprof.json"
 
+echo "== train step fed by the JPEG data pipeline (SURVEY 8(f).4)"
+timeout 150 python bench.py --steps 20 --warmup 5 --data jpeg --no-cpu-baseline --no-regional > "$O/${TAG}_bench_train_jpeg.json" 2> "$O/${TAG}_bench_train_jpeg.err"
+tail -1 "$O/${TAG}_bench_train_jpeg.err"; cut -c1-200 "$O/${TAG}_bench_train_jpeg.json"
 # last, if the box still has time: the end-to-end tests the validation call did not cover (regional parity, fusion on GPU)
 echo "== remaining end-to-end tests (time-capped)"
 timeout ${TAIL_TESTS_TIMEOUT:-100} python -m pytest tests/test_gpu_end_to_end.py -m gpu -q -x -s \
