@@ -232,7 +232,8 @@ def _tuning_switches():
     from mixofshow.hip import functional as F_hip
     return dict(conv3x3_min_pixels=F_hip._conv_min_pixels, ring_max_wg=int(os.environ.get('MOS_RING_MAX_WG', -1)),
                 fuse_add_layernorm=bool(F_hip._fuse_add_ln), fuse_groupnorm_skip_grad=bool(F_hip._fuse_gn_res),
-                groupnorm_finalize=os.environ.get('MOS_GN_FINALIZE', '1') != '0')
+                groupnorm_finalize=os.environ.get('MOS_GN_FINALIZE', '1') != '0',
+                batched_time_projections=os.environ.get('MOS_BATCH_TEMB', '0') != '0')
 
 
 def attention_path_aggregate(gflop_per_unit, units, recs, per):

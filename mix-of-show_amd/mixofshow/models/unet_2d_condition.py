@@ -13,6 +13,7 @@ PyTorch-ROCm (MIOpen / hipBLASLt); every `Attention` goes through its processor 
 (T2I-Adapter features) are consumed in the diffusers 0.19 order (pipeline_regionally_t2iadapter.py:556-566).
 """
 import math
+import os
 import weakref
 from types import SimpleNamespace
 
@@ -62,6 +63,43 @@ def _act_once(act, temb):
     return out
 
 
+# A/B switch, default off until measured on the device: project the time embedding for ALL ResNet blocks of a UNet call with one
+# `baddbmm` per output width instead of one tiny GEMM per block (M = batch: 22 launches of ~8.5 us in SD-1.5)
+_batch_time_proj = os.environ.get('MOS_BATCH_TEMB', '0') != '0'
+
+
+class _TimeProjections:
+    """Stacked `time_emb_proj` weights of a model's ResNet blocks, grouped by output width: (blocks, C, temb) and (blocks, 1, C).
+    The result of a group is (blocks, B, C), so each block's slice is a contiguous (B, C) tensor -- what the convolution
+    epilogue consumes. Frozen projections only (the stacks are rebuilt when a weight's version or storage changes)."""
+
+    def __init__(self, root):
+        self.blocks = [m for m in root.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+        self.key, self.groups = None, []
+
+    def usable(self):
+        return bool(self.blocks) and all(
+            not (p.weight.requires_grad or p.bias is None or p.bias.requires_grad or p._forward_hooks or p._forward_pre_hooks)
+            and type(p) is nn.Linear for p in (b.time_emb_proj for b in self.blocks))
+
+    def __call__(self, act):
+        key = tuple((b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version,
+                     b.time_emb_proj.weight.dtype) for b in self.blocks)
+        if key != self.key:
+            by_width = {}
+            for b in self.blocks:
+                by_width.setdefault(b.time_emb_proj.out_features, []).append(b)
+            self.groups = [(bs, torch.stack([b.time_emb_proj.weight.detach() for b in bs]).transpose(1, 2).contiguous(),
+                            torch.stack([b.time_emb_proj.bias.detach() for b in bs]).unsqueeze(1)) for bs in by_width.values()]
+            self.key = key
+        out = {}
+        for bs, w, bias in self.groups:       # (dtypes as for nn.Linear: equal, or reconciled by autocast)
+            y = torch.baddbmm(bias, act.unsqueeze(0).expand(len(bs), *act.shape), w)
+            for i, b in enumerate(bs):
+                out[id(b)] = y[i]
+        return out
+
+
 class ResnetBlock2D(nn.Module):
 
     def __init__(self, in_channels, out_channels, temb_channels=1280, groups=32, eps=1e-5):
@@ -80,7 +118,10 @@ class ResnetBlock2D(nn.Module):
         # the residual add in their epilogues (diffusers: conv, + temb[:, :, None, None], ..., x + h as separate kernels)
         tb = None
         if self.time_emb_proj is not None and temb is not None:
-            tb = self.time_emb_proj(_act_once(self.nonlinearity, temb))
+            pre = getattr(temb, '_mos_time_bias', None)          # UNet2DConditionModel.forward projected all blocks at once
+            tb = pre.get(id(self)) if pre is not None else None
+            if tb is None:
+                tb = self.time_emb_proj(_act_once(self.nonlinearity, temb))
         # (x feeds norm1 AND the skip path: taking the skip from the norm's tap adds its gradient inside the norm's backward)
         x, h = group_norm_act(self.norm1, x, True, tap=True)
         h = conv3x3(self.conv1, h, tbias=tb)
@@ -367,6 +408,13 @@ class UNet2DConditionModel(nn.Module):
         timestep = timestep.expand(sample.shape[0])
         t_emb = get_timestep_embedding(timestep, self._time_dim).to(dtype=sample.dtype)
         emb = self.time_embedding(t_emb)
+        if _batch_time_proj:
+            tp = self.__dict__.get('_time_projections')
+            if tp is None:
+                tp = _TimeProjections(self)
+                object.__setattr__(self, '_time_projections', tp)
+            if tp.usable():
+                emb._mos_time_bias = tp(_act_once(self.down_blocks[0].resnets[0].nonlinearity, emb))
 
         if torch.is_tensor(encoder_hidden_states) and encoder_hidden_states.dim() == 4 and sample.is_cuda:
             from mixofshow.models import edlora

@@ -270,3 +270,34 @@ def test_edlora_sampling_on_gpu_branches_fp16_vs_fp32_plain_path(emulated_hip):
     scale = max(1.0, ref.abs().max().item())
     print(f'[parity] tiny EDLoRA sampling, fp16 on GPU branches (emulated) vs fp32 plain path, 4 steps: max|d| = {err:.3e} on scale {scale:.2f}')
     assert err <= 3e-2 * scale
+
+
+def test_batched_time_embedding_projections_equal_per_block_projections(emulated_hip, monkeypatch):
+    """MOS_BATCH_TEMB (off by default): one baddbmm per output width for the time-embedding projections of all ResNet blocks
+    == the per-block nn.Linear calls, in the outputs of the whole UNet; the stacks follow weight updates."""
+    from mixofshow.models import unet_2d_condition as U
+    from mixofshow.utils import pretrained
+    torch.manual_seed(0)
+    unet = pretrained.load_unet('synthetic://tiny?seed=0').eval().requires_grad_(False)
+    x = torch.randn(2, 4, 8, 8)
+    t = torch.tensor([10, 500])
+    ehs = torch.randn(2, 77, unet.config.cross_attention_dim)
+
+    def run():
+        with torch.no_grad():
+            return unet(x, t, ehs).sample
+
+    monkeypatch.setattr(U, '_batch_time_proj', False)
+    ref = run()
+    monkeypatch.setattr(U, '_batch_time_proj', True)
+    got = run()
+    assert unet._time_projections.usable() and len(unet._time_projections.blocks) >= 4
+    assert (got - ref).abs().max() <= 1e-4 * ref.abs().max()          # (the emulated attention rounds its operands to half)
+    with torch.no_grad():                                        # a changed projection is picked up (version-keyed stacks)
+        unet.down_blocks[0].resnets[0].time_emb_proj.bias.add_(1.0)
+    got2 = run()
+    monkeypatch.setattr(U, '_batch_time_proj', False)
+    ref2 = run()
+    assert not torch.allclose(ref2, ref) and (got2 - ref2).abs().max() <= 1e-4 * ref2.abs().max()
+    unet.down_blocks[0].resnets[0].time_emb_proj.weight.requires_grad_(True)      # trainable projection: not batched
+    assert not unet._time_projections.usable()
