@@ -93,6 +93,8 @@ class _DeferredFinals:
     per group, so the record table is identical from step to step: it is uploaded once (in place, fixed-capacity buffer) and
     a captured hipGraph replays the single launch with the table it was captured with."""
 
+    MAX_WORKSPACES = 512     # an unfrozen store forgets its workspaces beyond this (new shapes / new models keep adding keys)
+
     def __init__(self):
         self.ws = {}
         self.pending = []
@@ -100,10 +102,26 @@ class _DeferredFinals:
         self.table = None
         self.table_bytes = None
         self.capacity = 512
+        self.frozen = False      # set once a captured hipGraph holds this store's table address and workspaces
+
+    def freeze(self):
+        """A captured graph replays ONE mos_lora_grad_final_all launch with this table's address and the workspace pointers
+        inside it: from now on any change of the table (another batch shape, another model stepping through this store)
+        raises instead of silently redirecting the replays to stale partial sums."""
+        self.frozen = True
+
+    def begin_scope(self):
+        self.pending = []
+        self.used = set()
+        if not self.frozen and len(self.ws) > self.MAX_WORKSPACES:
+            self.ws.clear()          # (keys hold raw addresses the allocator may recycle: bounded, never while frozen)
 
     def workspace(self, key, n_floats, device):
         t = self.ws.get(key)
         if t is None or t.numel() < n_floats or t.device != device:
+            if self.frozen:
+                raise RuntimeError('LoRA gradient workspaces are held by a captured hipGraph; a step of another shape must '
+                                   'run through its own store (TrainEngine keeps one per graph and one for eager steps)')
             t = torch.empty(n_floats, dtype=torch.float32, device=device)
             self.ws[key] = t
         return t
@@ -125,6 +143,8 @@ class _DeferredFinals:
             self.table = torch.zeros(self.capacity * ctypes.sizeof(_lib.LoraFinalRec), dtype=torch.uint8, device=dev)
             self.table_bytes = None
         if raw != self.table_bytes:
+            if self.frozen:
+                raise RuntimeError('LoRA gradient record table changed while a captured hipGraph replays it')
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError('LoRA gradient record table changed during hipGraph capture (warm-up steps must precede it)')
             self.table[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
@@ -135,25 +155,39 @@ class _DeferredFinals:
 _deferred_finals = None      # a _DeferredFinals while a direct_grad_accumulation(defer_finals=True) scope is open
 
 
+def new_deferred_finals():
+    """A private record table + workspace set for the deferred LoRA gradient sums (one per captured graph, one per engine
+    for its eager steps)."""
+    return _DeferredFinals()
+
+
 class direct_grad_accumulation:
     """with direct_grad_accumulation(): ... — scoped form of set_direct_grad_accumulation(True). `defer_finals` (HIP device
     only): the per-group final sums of the LoRA factor gradients are collected during the backward pass and issued as one
     launch when the scope closes (the caller runs forward AND backward inside the scope)."""
-    _store = None
+    _store = None        # default store of scopes that bring none (never one a graph was captured with)
 
-    def __init__(self, defer_finals=False):
+    def __init__(self, defer_finals=False, store=None):
+        """`store`: the _DeferredFinals to collect into. Whoever captures a scope into a hipGraph must own the store of that
+        scope (new_deferred_finals()), freeze it after capture and run every OTHER scope (eager steps of another batch shape,
+        a second engine) through a different one: the graph bakes the store's table address and workspace pointers in."""
         self.defer = bool(defer_finals)
+        self.store = store
 
     def __enter__(self):
         global _direct_grad, _deferred_finals
         self.prev, _direct_grad = _direct_grad, True
         self.prev_def = _deferred_finals
         if self.defer:
-            if direct_grad_accumulation._store is None:
-                direct_grad_accumulation._store = _DeferredFinals()
-            _deferred_finals = direct_grad_accumulation._store
-            _deferred_finals.pending = []
-            _deferred_finals.used = set()
+            st = self.store
+            if st is None:
+                if direct_grad_accumulation._store is None:
+                    direct_grad_accumulation._store = _DeferredFinals()
+                st = direct_grad_accumulation._store
+            if st.frozen and not torch.cuda.is_current_stream_capturing() and self.store is None:
+                raise RuntimeError('the default LoRA gradient store is frozen')      # (cannot happen: only owned stores freeze)
+            _deferred_finals = st
+            st.begin_scope()
         return self
 
     def __exit__(self, exc_type, *exc):

@@ -53,7 +53,8 @@ _act_memo = [None, None, None]
 
 def _act_once(act, temb):
     """`act(temb)` for the time embedding that all 22 ResNet blocks of one UNet call share: computed by the first block, reused
-    by the others (diffusers: one SiLU launch per block)."""
+    by the others (diffusers: one SiLU launch per block). UNet2DConditionModel.forward clears the memo when it returns, so
+    the activation (and the autograd graph behind it) is not retained beyond its call."""
     ref, ver, out = _act_memo
     if ref is not None and ref() is temb and ver == temb._version and out.requires_grad == (
             temb.requires_grad and torch.is_grad_enabled()):
@@ -61,6 +62,10 @@ def _act_once(act, temb):
     out = act(temb)
     _act_memo[:] = [weakref.ref(temb), temb._version, out]
     return out
+
+
+def _act_forget():
+    _act_memo[:] = [None, None, None]
 
 
 # A/B switch, default off until measured on the device: project the time embedding for ALL ResNet blocks of a UNet call with one
@@ -450,6 +455,7 @@ class UNet2DConditionModel(nn.Module):
             else:
                 sample = blk(sample, take, emb)
         sample = self.conv_out(group_norm_act(self.conv_norm_out, sample, True))
+        _act_forget()
         return UNetOutput(sample=sample) if return_dict else (sample, )
 
     def _run(self, blk, sample, emb, ehs, cak, extra):

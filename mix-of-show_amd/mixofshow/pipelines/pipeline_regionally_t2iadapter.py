@@ -292,16 +292,26 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
         # still runs eagerly: it recomputes the K/V caches into the buffers the graph holds).
         graphed = None
         ent = None
+        procs = [m.processor for m in self.unet.modules() if isinstance(getattr(m, 'processor', None), RegionT2I_AttnProcessor)]
         if hipgraph:
+            # model epoch: the graph also bakes in the addresses of DERIVED buffers (fused / cast weight copies, fp32 affine
+            # copies) that are re-allocated when a weight's version changes (load_state_dict of another fused model, an
+            # in-place LoRA merge, .half()) and the K/V buffers of the processor objects it was captured with: a change of
+            # any of them is a key miss, and the stale entry is dropped
+            epoch = (hipgraph_util.model_epoch(self.unet), tuple(id(p) for p in procs))
             gkey = (tuple(prompt_embeds.shape), prompt_embeds.dtype, height, width, bool(do_cfg),
                     tuple((tuple(r[0].shape), tuple(float(v) for v in r[1])) for r in region_list),
                     None if adapter_states is None else tuple(tuple(a.shape) for a in adapter_states),
-                    tuple(latents.shape), self.unet.conv_in.weight.data_ptr(), self.unet.conv_in.weight.dtype)
+                    tuple(latents.shape))
             cache = self.__dict__.setdefault('_sampling_graphs', {})
             ent = cache.get(gkey)
+            if ent is not None and ent.epoch != epoch:
+                cache.pop(gkey)
+                ent = None
             if ent is None:
                 ent = SimpleNamespace(pe=prompt_embeds.clone(), rl=[(r[0].clone(), r[1]) for r in region_list],
-                                      ad=None if adapter_states is None else [a.clone() for a in adapter_states], graphed=None)
+                                      ad=None if adapter_states is None else [a.clone() for a in adapter_states], graphed=None,
+                                      epoch=epoch)
                 while len(cache) >= 2:                       # at most two shapes resident (graphs pin their memory pools)
                     cache.pop(next(iter(cache)))
                 cache[gkey] = ent
@@ -316,7 +326,6 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
         cak = {'region_list': region_list, 'height': height, 'width': width}
         # the per-layer source K/V caches are keyed on tensor identity (address / version / shape); a new call with new
         # prompts can re-use the very same addresses (caching allocator), so every call starts with stale caches
-        procs = [m.processor for m in self.unet.modules() if isinstance(getattr(m, 'processor', None), RegionT2I_AttnProcessor)]
         for proc in procs:
             proc.reset_cache()
         if graphed is not None:

@@ -99,9 +99,13 @@ class TrainEngine:
 
         from mixofshow.hip import functional as F_hip
 
+        # the captured launch of the deferred LoRA gradient sums bakes in ITS record table and workspaces: a store owned by
+        # this graph alone (warm-up fills it, capture replays it, then it is frozen); eager steps use another one
+        self._finals_graph = F_hip.new_deferred_finals()
+
         def fwd_bwd():
             self.bucket.zero()
-            with F_hip.direct_grad_accumulation(defer_finals=dev.type == 'cuda'):
+            with F_hip.direct_grad_accumulation(defer_finals=dev.type == 'cuda', store=self._finals_graph):
                 with torch.autocast(dev.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                     loss = tr(st.get('images'), None, st.get('masks', st['img_masks']), st['img_masks'],
                               noise=st.get('noise'), timesteps=st.get('timesteps'), latents=st.get('latents'),
@@ -121,6 +125,7 @@ class TrainEngine:
         with torch.cuda.graph(graph):
             self._static_loss = fwd_bwd()
         self._graph = graph
+        self._finals_graph.freeze()
         F_hip.freeze_lora_packs(True)          # the graph holds the descriptor table's address and group count
         return self
 
@@ -129,6 +134,7 @@ class TrainEngine:
         if getattr(self, '_graph', None) is not None:
             from mixofshow.hip import functional as F_hip
             self._graph = None
+            self._finals_graph = None
             F_hip.freeze_lora_packs(False)
 
     def __del__(self):
@@ -189,7 +195,9 @@ class TrainEngine:
         images = batch['images']
         if self.channels_last and images is not None:
             images = images.contiguous(memory_format=torch.channels_last)
-        with F_hip.direct_grad_accumulation(defer_finals=dev_type == 'cuda'):
+        if getattr(self, '_finals_eager', None) is None:
+            self._finals_eager = F_hip.new_deferred_finals()     # never the table a captured graph replays
+        with F_hip.direct_grad_accumulation(defer_finals=dev_type == 'cuda', store=self._finals_eager):
             with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                 loss = tr(images, batch['prompts'], masks, batch['img_masks'], **extra)
             self.scaler.scale(loss / self.grad_accum).backward()

@@ -27,6 +27,17 @@ def has_forward_hooks(module):
     return any(m._forward_hooks or m._forward_pre_hooks for m in module.modules())
 
 
+def model_epoch(module):
+    """A value that changes whenever a captured graph of `module` may have gone stale: parameter / buffer storage (address,
+    dtype) or content (tensor version counters: load_state_dict, in-place merges, optimiser steps). The graph bakes in not
+    only the parameters' addresses but those of derived copies (fused / cast weights, fp32 affine parameters) that the
+    product re-allocates when a version changes."""
+    h = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        h = (h * 1000003 + hash((t.data_ptr(), t._version, t.dtype))) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
 def graphs_usable(device):
     return (torch.device(device).type == 'cuda' and torch.cuda.is_available()
             and os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0')

@@ -112,6 +112,31 @@ def _absmax(t):
     return t.float().abs().max().item()
 
 
+def _record_parity(name, **figures):
+    """Merge the measured parity figures of one test into gpurun_out/parity_latents.json (committed afterwards as
+    profiles/parity_latents.json, which bench.py embeds in its JSON line next to `roofline`: VERDICT r03 1(d))."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, 'parity_latents.json')
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        import bench
+        fp = bench.kernel_source_fingerprint(None)
+        if data.get('kernel_source_sha16_all') != fp:
+            data = {'kernel_source_sha16_all': fp, 'tolerance_north_star': TOL, 'normalisation':
+                    'max|d| / max(1, |.|max) for *_maxabs, rms(d) / max(1, rms) for *_rms; worst of 50 DPM-Solver++ steps, '
+                    'CFG 7.5, synthetic://sd15', 'written_by': 'tests/test_gpu_end_to_end.py', 'cases': {}}
+        data['cases'][name] = {k: float(f'{v:.4e}') for k, v in figures.items()}
+        with open(path, 'w') as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def _per_step(rec_a, rec_b):
     """Worst per-step (max|d eps| / max(1,|eps|), max|d x| / max(1,|x|), rms d eps / rms eps) of a against b."""
     we = wx = wr = 0.0
@@ -238,6 +263,13 @@ def _hot_path_error(name, setup, regional, residuals_fn=None):
     print(f'[parity] {name}, denoised-latent RMS error / max(1, rms latent) (worst step, final step): HIP vs exact {hw:.3e} '
           f'{hl:.3e}; HIP vs reference fp16 attention {dw:.3e} {dl:.3e}; reference fp16 attention vs exact {rw:.3e} {rl:.3e}; '
           f'FREE-RUNNING 50 steps HIP vs exact {fw:.3e} {fl:.3e}')
+    _record_parity(name + ' | fp32 pipeline (attention layers only in half)',
+                   eps_maxabs_hip_vs_exact=he, eps_maxabs_hip_vs_ref_fp16=de, eps_maxabs_ref_fp16_vs_exact=re_,
+                   latent_maxabs_teacher_forced_hip_vs_exact=hx, latent_maxabs_teacher_forced_hip_vs_ref_fp16=dx,
+                   latent_maxabs_teacher_forced_ref_fp16_vs_exact=rx, latent_maxabs_free_running_final_hip_vs_exact=free,
+                   latent_rms_teacher_forced_hip_vs_exact=hw, latent_rms_teacher_forced_hip_vs_ref_fp16=dw,
+                   latent_rms_teacher_forced_ref_fp16_vs_exact=rw, latent_rms_free_running_final_hip_vs_exact=fl,
+                   eps_absmax=emax, latent_absmax=xmax)
     assert xmax <= 8.0, f'{name}: calibrated synthetic latents should stay O(1), got {xmax}'
     # epsilon = what the hot path produces: north_star's 1e-3, every step -- against exact attention AND against the
     # reference's own fp16 attention arithmetic
@@ -296,16 +328,25 @@ def _fp16_pipeline_band_body(name, setup, regional):
           f'{he:.3e} {hx:.3e} {hr:.3e}; reference fp16 path vs exact {re_:.3e} {rx:.3e} {rr:.3e}; HIP vs reference '
           f'{pe:.3e} {px:.3e} {pr:.3e}; reference vs itself (2 runs) {ne:.3e} {nx:.3e} {nr:.3e}; |eps|max {emax:.2f} '
           f'|x|max {xmax:.2f}; free-running 50-step HIP vs reference {free:.3e}')
+    _record_parity(name + ' | fp16 pipeline (every operator in half: the benchmarked dtype)',
+                   eps_maxabs_hip_vs_exact=he, eps_maxabs_ref_path_vs_exact=re_, eps_maxabs_hip_vs_ref_path=pe,
+                   eps_maxabs_ref_path_vs_itself=ne, latent_maxabs_teacher_forced_hip_vs_exact=hx,
+                   latent_maxabs_teacher_forced_ref_path_vs_exact=rx, latent_maxabs_teacher_forced_hip_vs_ref_path=px,
+                   latent_maxabs_teacher_forced_ref_path_vs_itself=nx, latent_maxabs_free_running_final_hip_vs_ref_path=free,
+                   eps_rmsrel_hip_vs_exact=hr, eps_rmsrel_ref_path_vs_exact=rr, eps_rmsrel_hip_vs_ref_path=pr,
+                   eps_absmax=emax, latent_absmax=xmax)
     assert xmax <= 8.0
     ulp = 2.0 ** -8 / max(1.0, emax)         # one fp16 ulp of the top binade, in the normalised units above
     assert hr <= 1.15 * rr + 1e-5, f'{name}: HIP rms error {hr:.3e} vs reference path {rr:.3e} (both against exact)'
     assert he <= 1.5 * re_ + ulp and hx <= 1.5 * rx + 14 * ulp, f'{name}: HIP max error outside the reference band'
     assert he <= 5e-3 and free <= 1e-1
-    if ne == 0.0 and nx == 0.0:
-        # deterministic yardstick: HIP against the reference's fp16 path DIRECTLY, in ulps of epsilon's top binade (both
-        # paths round every operator to half; they differ where the attention arithmetic differs)
-        assert pe <= re_ + he + ulp, f'{name}: HIP vs reference {pe:.3e} exceeds the sum of their distances to exact'
-        assert pr <= 1.5 * max(rr, hr), f'{name}: HIP vs reference rms {pr:.3e}'
+    # HIP against the reference's fp16 path DIRECTLY. The reference path is not bit-reproducible here (hipBLASLt's stream-K
+    # feed-forward GEMMs accumulate atomically: "reference vs itself" measures 2.0e-3 .. 2.6e-3), so the yardstick is the
+    # larger of that run-to-run spread and the reference path's own distance from exact attention -- asserted always (the
+    # round-3 form of this check only fired for a bit-reproducible reference, i.e. never).
+    assert pe <= 1.25 * max(ne, re_) + ulp, f'{name}: HIP vs reference path {pe:.3e} (reference vs itself {ne:.3e}, vs exact {re_:.3e})'
+    assert pr <= 1.25 * max(nr, rr) + 1e-5, f'{name}: HIP vs reference path rms {pr:.3e} (reference vs itself {nr:.3e}, vs exact {rr:.3e})'
+    assert px <= 1.25 * max(nx, rx) + 14 * ulp, f'{name}: latent HIP vs reference path {px:.3e} (itself {nx:.3e}, vs exact {rx:.3e})'
 
 
 def test_edlora_sd15_hot_path_error_teacher_forced():
@@ -617,6 +658,68 @@ def test_hipgraph_step_equals_eager_step():
     assert p_graph <= max(3.0 * p_spread, 1e-3)
 
 
+def test_hipgraph_replay_after_an_eager_step_of_another_batch_size():
+    """the captured graph replays ONE launch of the deferred LoRA gradient sums with a record table and
+    workspaces baked in. An eager step of another batch size (the ragged-last-batch fallback of TrainEngine._graph_step) or a
+    second engine stepping in the same process must not rewrite them: after such a step the replayed gradients still equal
+    an eager engine's on the same batch. Also: a frozen store refuses changes instead of redirecting replays."""
+    from bench import TRAIN_OPT, build_trainer, synthetic_batch
+    from mixofshow.hip import functional as F_hip
+    from mixofshow.pipelines.train_loop import TrainEngine
+
+    def batch(B, seed):
+        g = torch.Generator().manual_seed(seed)
+        b = synthetic_batch(B, 256, 'cpu', seed)
+        b.update(latents=torch.randn(B, 4, 32, 32, generator=g), noise=torch.randn(B, 4, 32, 32, generator=g),
+                 timesteps=torch.randint(0, 1000, (B, ), generator=g))
+        b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+        b['images'] = None
+        return b
+
+    def engine_for(seed=0):
+        tr = build_trainer('small', torch.device(DEV))
+        torch.manual_seed(1)
+        with torch.no_grad():
+            for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+                l.lora_up.weight.normal_(0, 0.02)
+        # lr 0: parameters stay identical, so every step's gradient bucket is comparable across engines
+        opt = dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g']))
+        e = TrainEngine(tr, opt, total_iter=100, mixed_precision='fp16')
+        e.base_lrs = [0.0 for _ in e.base_lrs]
+        for g in e.optimizer.param_groups:
+            g['weight_decay'] = 0.0
+        return e
+
+    def grad_of(e, b):
+        e.step(b)
+        return e.bucket.flat.detach().float().clone() / e.scaler.get_scale()
+
+    b2, b1, b2b = batch(2, 70), batch(1, 71), batch(2, 72)
+    ref = engine_for()
+    g_ref = [grad_of(ref, b2), grad_of(ref, b2b)]
+    eng = engine_for()
+    eng.enable_graph(b2)
+    assert eng._finals_graph.frozen
+    g0 = grad_of(eng, b2)                     # replay
+    g_odd = grad_of(eng, b1)                  # batch of another size: eager fallback, other M -> other workspaces / table
+    assert torch.isfinite(g_odd).all() and g_odd.abs().sum() > 0
+    other = engine_for()                      # a second eager engine in the same process
+    grad_of(other, b1)
+    g1 = grad_of(eng, b2b)                    # replay again: must not sum stale partial buffers
+    g0b = grad_of(eng, b2)
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm()).item()
+    print(f'[parity] graph replay around eager steps: first {rel(g0, g_ref[0]):.3e}, after eager B=1 + second engine '
+          f'{rel(g1, g_ref[1]):.3e}, repeat of batch 0 {rel(g0b, g0):.3e}')
+    assert rel(g0, g_ref[0]) <= 5e-3 and rel(g1, g_ref[1]) <= 5e-3 and rel(g0b, g0) <= 5e-3
+    # the frozen store itself refuses to be rewritten
+    with pytest.raises(RuntimeError):
+        with F_hip.direct_grad_accumulation(defer_finals=True, store=eng._finals_graph):
+            eng._finals_graph.workspace(('no', 'such', 'group'), 16, torch.device(DEV, torch.cuda.current_device()))
+    eng.disable_graph()
+
+
 def test_update_quasi_newton_vs_reference_golden(golden):
     """The Gram-form fp64 L-BFGS (HIP) against the iterates the REAL reference code produced (fp32, direct form)."""
     from mixofshow.utils.lsq import update_quasi_newton
@@ -673,6 +776,62 @@ def test_fusion_feature_collection_and_fused_weights_vs_oracle_gpu(tmp_path, mon
     res = run_product_and_oracle_fusion(cfg, 'small', torch.device(DEV), 40, 10, monkeypatch)
     # fp16 activations: the two paths' features differ by half-precision rounding of the attention outputs upstream
     fusion_parity_report(res, 2e-3, solve_layers=2)
+
+
+def test_fusion_one_sd15_level0_layer_over_14_concepts_vs_oracle(tmp_path, monkeypatch):
+    """configs[3] at ITS scale (reference gradient_fusion.py:627-747): ONE level-0 spatial layer of the SD-1.5
+    UNet (320 -> 320, the output projection of the last self-attention: its input is what the HIP attention kernel wrote)
+    accumulated over 14 synthetic concepts x 20 recorded DPM-Solver steps x 4096 tokens = 1,146,880 rows. The product
+    streams them into fp64 Gram statistics through the feature tap of the fused projection; the oracle runs the reference
+    procedure (forward hook on the nn.Linear, features stored on the host, oracle processors) on the same model and seeds.
+    Compared: n, G = X^T X, P = Y^T X, c = sum Y^2."""
+    import gradient_fusion as gf
+    from bench import synthetic_edlora_checkpoints
+    from oracle import edlora_ref as R
+    from oracle import fusion_ref as FR
+    layer = 'up_blocks.3.attentions.2.transformer_blocks.0.attn1.to_out.0'
+    n_concepts = 14
+    cfg = synthetic_edlora_checkpoints('sd15', n_concepts, str(tmp_path))
+    pipe, _, sched = gf.init_stable_diffusion('synthetic://sd15?seed=0', DEV)
+    for p in list(pipe.text_encoder.parameters()) + list(pipe.unet.parameters()):
+        p.requires_grad = False
+    emb, te, kv, sp, concepts = gf.parse_new_concepts(cfg)
+    _, ncfg = gf.merge_new_concepts_(emb, concepts, pipe.tokenizer, pipe.text_encoder)
+    sp = [{k: v for k, v in d.items() if k.startswith(layer + '.lora_')} for d in sp]
+    assert all(len(d) == 2 for d in sp)
+    captured = {}
+    monkeypatch.setattr(gf, '_solve_layers', lambda accs, sd, iters, tag: captured.setdefault(tag, accs) and {})
+    u0 = {k: v.detach().clone() for k, v in pipe.unet.state_dict().items()}
+    torch.manual_seed(77)                     # decode_to_latents draws from the global CPU generator (reference :601)
+    gf.merge_spatial_attention(concepts, 1, ncfg, pipe.tokenizer, pipe.text_encoder, pipe.unet, sp, sched, DEV)
+    acc = captured['spatial'][layer + '.weight']
+    assert all(torch.equal(v, u0[k]) for k, v in pipe.unet.state_dict().items()), 'original weights not restored'
+    # the reference procedure on the same modules: every projection a real nn.Linear call, features kept on the host
+    for m in pipe.unet.modules():
+        if m.__class__.__name__ == 'Attention':
+            m.set_processor(R.PlainAttnProcessorRef())
+    torch.manual_seed(77)
+    X, Y, _ = FR.merge_spatial_attention_ref(concepts, 1, ncfg, pipe.tokenizer, pipe.text_encoder, pipe.unet, sp, sched, DEV,
+                                             R.bind_concept_prompt_ref, return_features=True)
+    X, Y = X[layer + '.weight'], Y[layer + '.weight']
+    n = n_concepts * 20 * 4096
+    assert acc.n == n == X.shape[0] == 1146880 and X.shape[1] == Y.shape[1] == 320
+    G = torch.zeros(320, 320, dtype=torch.float64, device=DEV)
+    P = torch.zeros(320, 320, dtype=torch.float64, device=DEV)
+    c = torch.zeros((), dtype=torch.float64, device=DEV)
+    for s0 in range(0, n, 131072):
+        x, y = X[s0:s0 + 131072].to(DEV).double(), Y[s0:s0 + 131072].to(DEV).double()
+        G += x.T @ x
+        P += y.T @ x
+        c += (y * y).sum()
+    eg = ((acc.G - G).norm() / G.norm()).item()
+    ep = ((acc.P - P).norm() / P.norm()).item()
+    ec = abs(acc.c.item() - c.item()) / c.item()
+    print(f'[parity] fusion sd15 level-0 layer {layer}, {n_concepts} concepts, n = {n}: Gram statistics of the streamed HIP '
+          f'features vs the reference procedure (stored features, oracle attention): rel err G {eg:.3e} P {ep:.3e} c {ec:.3e}')
+    # both paths sample 20 free-running fp16 steps per concept; they differ by the half-precision rounding of every attention
+    # layer upstream (HIP flash kernel vs baddbmm/softmax/bmm in fp16)
+    assert max(eg, ep, ec) <= 5e-3
 
 
 def test_fusion_reduces_layer_loss_on_real_features():
