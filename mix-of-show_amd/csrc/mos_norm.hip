@@ -621,6 +621,365 @@ int gn_nhwc_check(const void* x, const void* out, const float* gamma, const floa
     return MOS_OK;
 }
 
+
+// ---- channels-last, ONE launch, ONE read: the "column" kernel -------------------------------------------------------------
+// VERDICT r03 item 2. The slice kernels above need three launches (slice partials -> per-image constants -> apply) and read the
+// activation twice, because the pixels of one (image, group) are spread over the workgroups of a grid; at the UNet's map sizes
+// each of the three launches sits on its ~7 us floor (rocprofv3 minimum of every one of them), 20+ us per norm for tensors that
+// move in 1-5 us. Here a workgroup owns a COLUMN of the image instead: all HW pixels x the smallest channel range that is
+// both whole groups and whole 16-byte vectors (lcm(cpg, 8) channels: 40 for C = 320 / 640 / 1280, 80 for 2560, 120 for 960 /
+// 1920 -- runs of 80 .. 240 contiguous bytes per pixel). Its slab (<= 128 KB for every 32x32-and-smaller map of the UNet, and
+// for the 32x48 level of a 512x768 sample) stays in REGISTERS (K <= 16 vectors per thread at 510 threads), so the statistics
+// are the exact two-pass form (mean, then sum (x - mean)^2), and the tensor is read once and written once by one launch.
+// Slabs that do not fit (64x64 maps) can run the same kernel in streaming form (K = 0: one-pass sums, second read from L2).
+// Workgroups are renumbered so that neighbouring columns (which share 128-byte lines) run on the same XCD / L2.
+struct GnColArgs {
+    const void* x; const void* dy; const void* ds; void* out;
+    const float* gamma; const float* beta;
+    float* stats;                                  // [B*G][2] = mean, rstd (written forward, read backward)
+    int B, C, HW, G, cpg;
+    int NV, ng, units, S, RP, npass;               // vectors / groups per unit, units per image, active threads, rows per pass
+    float eps;
+};
+
+constexpr int GN_COL_NG = 4;                       // groups per unit (lcm(cpg, 8) / cpg <= 4 for cpg even)
+constexpr int GN_COL_K = 16;                       // resident vectors per thread
+constexpr int GN_COL_T = 512;                      // threads per workgroup (two waves per SIMD: 256 VGPRs each, no spills)
+
+// block totals of 2 moments x ng groups; (a0, b0) belong to local group gl0, (a1, b1) to gl0 + 1. Result in totd[2 * g + m].
+__device__ __forceinline__ void gn_col_block_sum(float a0, float b0, float a1, float b1, int gl0, float (*red)[2 * GN_COL_NG],
+                                                 double* totd, int nwaves) {
+    float v[2 * GN_COL_NG];
+#pragma unroll
+    for (int g = 0; g < GN_COL_NG; ++g) {
+        v[2 * g] = (g == gl0 ? a0 : 0.f) + (g == gl0 + 1 ? a1 : 0.f);
+        v[2 * g + 1] = (g == gl0 ? b0 : 0.f) + (g == gl0 + 1 ? b1 : 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * GN_COL_NG; ++j)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[j] += __shfl_xor(v[j], off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 2 * GN_COL_NG; ++j) red[wave][j] = v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * GN_COL_NG) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += (double)red[w][threadIdx.x];     // fixed order: deterministic
+        totd[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+template <typename T, int K, bool BWD, bool SILU, bool DS>
+__global__ __launch_bounds__(GN_COL_T) void gn_col_kernel(GnColArgs a) {
+    static_assert(BWD || !DS, "the bypass gradient exists in backward only");
+    typedef typename MT<T>::v8 v8;
+    constexpr bool RES = K > 0;                    // slab resident in registers
+    constexpr int KR = RES ? K : 1;
+    __shared__ float red[GN_COL_T / 64][2 * GN_COL_NG];
+    __shared__ double totd[2 * GN_COL_NG];
+    const int tid = threadIdx.x;
+    const int nwaves = (blockDim.x + 63) >> 6;
+    const int nwg = gridDim.x, wg = blockIdx.x;
+    const int logical = (nwg % 8 == 0) ? (wg % 8) * (nwg / 8) + wg / 8 : wg;     // XCD x runs a contiguous range of columns
+    const int b = logical / a.units, u = logical - b * a.units;
+    const bool active = tid < a.S;
+    const int vec = active ? tid % a.NV : 0, row = active ? tid / a.NV : 0;
+    const int cbase = (u * a.NV + vec) * 8;        // first channel of this thread's vector
+    const int gl0 = (vec * 8) / a.cpg;             // local group of element 0 ; elements [nb, 8) belong to gl0 + 1
+    const int nb = min(8, (gl0 + 1) * a.cpg - vec * 8);
+    const int gidx0 = b * a.G + u * a.ng + gl0;    // row of `stats`
+    const bool two = nb < 8;                        // (then gl0 + 1 < ng: a unit is whole groups)
+    float gam[8], bet[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { gam[i] = a.gamma[cbase + i]; bet[i] = a.beta[cbase + i]; }
+    const int64_t img = (int64_t)b * a.HW * a.C;
+    const T* xb = (const T*)a.x + img + cbase;
+    [[maybe_unused]] const T* db = BWD ? (const T*)a.dy + img + cbase : nullptr;
+    [[maybe_unused]] const T* sb = DS ? (const T*)a.ds + img + cbase : nullptr;
+    T* ob = (T*)a.out + img + cbase;
+    const double ninv = 1.0 / ((double)a.cpg * (double)a.HW);
+
+    u32x4 xr[KR];
+    [[maybe_unused]] u32x4 dr[KR];
+    if constexpr (RES) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int p = row + k * a.RP;
+            const bool ok = active && p < a.HW;
+            xr[k] = ok ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+            if constexpr (BWD) dr[k] = ok ? ld16(db + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+        }
+    }
+
+    float m0 = 0.f, r0 = 0.f, m1 = 0.f, r1 = 0.f;   // mean / rstd of gl0 and gl0 + 1
+    if constexpr (!BWD) {
+        if constexpr (RES) {
+            // exact two-pass statistics from the registers
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const v8 xv = as_v8<T>(xr[k]);     // (rows past HW are zeros: they add nothing)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { const float f = (float)xv[i]; if (i < nb) a0 += f; else a1 += f; }
+            }
+            gn_col_block_sum(a0, 0.f, a1, 0.f, gl0, red, totd, nwaves);
+            m0 = (float)(totd[2 * gl0] * ninv);
+            m1 = two ? (float)(totd[2 * (gl0 + 1)] * ninv) : 0.f;
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (!(active && row + k * a.RP < a.HW)) continue;
+                const v8 xv = as_v8<T>(xr[k]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = (float)xv[i] - (i < nb ? m0 : m1);
+                    if (i < nb) q0 += d * d; else q1 += d * d;
+                }
+            }
+            gn_col_block_sum(q0, 0.f, q1, 0.f, gl0, red, totd, nwaves);
+            r0 = (float)(1.0 / sqrt(totd[2 * gl0] * ninv + (double)a.eps));
+            r1 = two ? (float)(1.0 / sqrt(totd[2 * (gl0 + 1)] * ninv + (double)a.eps)) : 0.f;
+        } else {
+            float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
+            constexpr int U = 4;
+            for (int k0 = 0; k0 < a.npass; k0 += U) {
+                u32x4 t[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int p = row + (k0 + q) * a.RP;
+                    t[q] = (active && p < a.HW) ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const v8 xv = as_v8<T>(t[q]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float f = (float)xv[i];
+                        if (i < nb) { a0 += f; q0 += f * f; } else { a1 += f; q1 += f * f; }
+                    }
+                }
+            }
+            gn_col_block_sum(a0, q0, a1, q1, gl0, red, totd, nwaves);
+            {
+                const double mm = totd[2 * gl0] * ninv;
+                double var = totd[2 * gl0 + 1] * ninv - mm * mm;
+                if (var < 0.0) var = 0.0;
+                m0 = (float)mm; r0 = (float)(1.0 / sqrt(var + (double)a.eps));
+            }
+            if (two) {
+                const double mm = totd[2 * (gl0 + 1)] * ninv;
+                double var = totd[2 * (gl0 + 1) + 1] * ninv - mm * mm;
+                if (var < 0.0) var = 0.0;
+                m1 = (float)mm; r1 = (float)(1.0 / sqrt(var + (double)a.eps));
+            }
+        }
+        if (a.stats != nullptr && active && row == 0) {   // one writer per group: the thread whose vector starts the group
+            if (vec * 8 == gl0 * a.cpg) { a.stats[gidx0 * 2] = m0; a.stats[gidx0 * 2 + 1] = r0; }
+            if (two) { a.stats[(gidx0 + 1) * 2] = m1; a.stats[(gidx0 + 1) * 2 + 1] = r1; }
+        }
+        float c0[8], c1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float mm = i < nb ? m0 : m1, rr = i < nb ? r0 : r1;
+            c0[i] = gam[i] * rr; c1[i] = bet[i] - mm * gam[i] * rr;
+        }
+        auto apply = [&](u32x4 raw, int p) {
+            const v8 xv = as_v8<T>(raw);
+            v8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float z = (float)xv[i] * c0[i] + c1[i];
+                if (SILU) z = silu_f(z);
+                o[i] = (T)z;
+            }
+            st16(ob + (int64_t)p * a.C, from_v8<T>(o));
+        };
+        if constexpr (RES) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int p = row + k * a.RP;
+                if (active && p < a.HW) apply(xr[k], p);
+            }
+        } else {
+            constexpr int U = 4;
+            for (int k0 = 0; k0 < a.npass; k0 += U) {
+                u32x4 t[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int p = row + (k0 + q) * a.RP;
+                    t[q] = (active && p < a.HW) ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int p = row + (k0 + q) * a.RP;
+                    if (active && p < a.HW) apply(t[q], p);
+                }
+            }
+        }
+    } else {
+        m0 = a.stats[gidx0 * 2]; r0 = a.stats[gidx0 * 2 + 1];
+        if (two) { m1 = a.stats[(gidx0 + 1) * 2]; r1 = a.stats[(gidx0 + 1) * 2 + 1]; }
+        // g = dL/dz * gamma (z = xhat * gamma + beta, y = silu(z) or z) and xhat of one vector
+        auto terms = [&](u32x4 xraw, u32x4 draw, float* gg, float* xh) {
+            const v8 xv = as_v8<T>(xraw), dv = as_v8<T>(draw);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xh[i] = ((float)xv[i] - (i < nb ? m0 : m1)) * (i < nb ? r0 : r1);
+                float dz = (float)dv[i];
+                if (SILU) {
+                    const float z = xh[i] * gam[i] + bet[i];
+                    const float sig = 1.f / (1.f + __expf(-z));
+                    dz *= sig * (1.f + z * (1.f - sig));
+                }
+                gg[i] = dz * gam[i];
+            }
+        };
+        float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f;
+        auto accumulate = [&](u32x4 xraw, u32x4 draw) {
+            float gg[8], xh[8];
+            terms(xraw, draw, gg, xh);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < nb) { a0 += gg[i]; b0 += gg[i] * xh[i]; } else { a1 += gg[i]; b1 += gg[i] * xh[i]; }
+            }
+        };
+        if constexpr (RES) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (active && row + k * a.RP < a.HW) accumulate(xr[k], dr[k]);
+        } else {
+            constexpr int U = 2;
+            for (int k0 = 0; k0 < a.npass; k0 += U) {
+                u32x4 tx[U], td[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int p = row + (k0 + q) * a.RP;
+                    const bool ok = active && p < a.HW;
+                    tx[q] = ok ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+                    td[q] = ok ? ld16(db + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q)
+                    if (active && row + (k0 + q) * a.RP < a.HW) accumulate(tx[q], td[q]);
+            }
+        }
+        gn_col_block_sum(a0, b0, a1, b1, gl0, red, totd, nwaves);
+        const float mg0 = (float)(totd[2 * gl0] * ninv), mx0 = (float)(totd[2 * gl0 + 1] * ninv);
+        const float mg1 = two ? (float)(totd[2 * (gl0 + 1)] * ninv) : 0.f, mx1 = two ? (float)(totd[2 * (gl0 + 1) + 1] * ninv) : 0.f;
+        auto apply = [&](u32x4 xraw, u32x4 draw, int p) {
+            float gg[8], xh[8];
+            terms(xraw, draw, gg, xh);
+            v8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o[i] = (T)((i < nb ? r0 : r1) * (gg[i] - (i < nb ? mg0 : mg1) - xh[i] * (i < nb ? mx0 : mx1)));
+            if constexpr (DS) {
+                const v8 sv = as_v8<T>(ld16(sb + (int64_t)p * a.C));
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (T)((float)o[i] + (float)sv[i]);
+            }
+            st16(ob + (int64_t)p * a.C, from_v8<T>(o));
+        };
+        if constexpr (RES) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int p = row + k * a.RP;
+                if (active && p < a.HW) apply(xr[k], dr[k], p);
+            }
+        } else {
+            constexpr int U = 2;
+            for (int k0 = 0; k0 < a.npass; k0 += U) {
+                u32x4 tx[U], td[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int p = row + (k0 + q) * a.RP;
+                    const bool ok = active && p < a.HW;
+                    tx[q] = ok ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+                    td[q] = ok ? ld16(db + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int q = 0; q < U; ++q) {
+                    const int p = row + (k0 + q) * a.RP;
+                    if (active && p < a.HW) apply(tx[q], td[q], p);
+                }
+            }
+        }
+    }
+}
+
+// MOS_GN_FUSED: 0 = slice kernels only (round 3), 1 = column kernel where the slab is register-resident (default),
+// 2 = column kernel (streaming form) also for larger maps. Read per call: tests and A/B runs flip it inside one process.
+int gn_fused_mode() {
+    const char* e = getenv("MOS_GN_FUSED");
+    return e == nullptr ? 1 : atoi(e);
+}
+
+int gn_gcd(int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; }
+
+// true: `c` is filled in and the column kernel takes this call (resident = slab fits K vectors per thread)
+bool gn_col_plan(const GnNhwcArgs& a, GnColArgs& c, bool& resident) {
+    const int mode = gn_fused_mode();
+    if (mode <= 0) return false;
+    const int cpg = a.C / a.G;
+    const int cu = cpg / gn_gcd(cpg, 8) * 8;        // lcm(cpg, 8): whole groups AND whole 16-byte vectors
+    if (cu < 32 || cu > 128 || a.C % cu != 0 || cu / cpg > GN_COL_NG) return false;
+    c.B = a.B; c.C = a.C; c.HW = a.HW; c.G = a.G; c.cpg = cpg; c.eps = a.eps;
+    c.NV = cu / 8; c.ng = cu / cpg; c.units = a.C / cu;
+    const int64_t vectors = (int64_t)a.HW * c.NV;
+    int threads = (int)((vectors + 63) / 64 * 64);
+    if (threads > GN_COL_T) threads = GN_COL_T;
+    if (threads < 64) threads = 64;
+    c.S = threads / c.NV * c.NV;
+    c.RP = c.S / c.NV;
+    c.npass = (a.HW + c.RP - 1) / c.RP;
+    resident = c.npass <= GN_COL_K;
+    if (!resident && mode < 2) return false;
+    c.x = a.x; c.dy = a.dy; c.ds = a.ds; c.out = a.out; c.gamma = a.gamma; c.beta = a.beta; c.stats = a.stats;
+    return true;
+}
+
+template <typename T, bool BWD>
+int gn_col_run(const GnColArgs& c, bool resident, int silu, hipStream_t st) {
+    const int threads = (c.S + 63) / 64 * 64;
+    const dim3 grid(c.units * c.B), block(threads);
+    char key[96];
+    snprintf(key, sizeof(key), "nhwc B%d C%d HW%d%s%s", c.B, c.C, c.HW, silu ? " +silu" : "", resident ? "" : " streaming");
+    const double n = (double)c.B * c.C * c.HW;
+    const bool has_ds = BWD && c.ds != nullptr;
+    MosProfScope prof(st, BWD ? "groupnorm_bwd_fused" : "groupnorm_fused", key, (BWD ? 26.0 : 11.0) * n,
+                      (BWD ? (has_ds ? 8.0 : 6.0) : 4.0) * n);
+#define GN_COL(KK, S_, D_) hipLaunchKernelGGL((gn_col_kernel<T, KK, BWD, S_, D_>), grid, block, 0, st, c)
+    if constexpr (BWD) {
+        if (has_ds) {
+            if (resident) { if (silu) GN_COL(GN_COL_K, true, true); else GN_COL(GN_COL_K, false, true); }
+            else { if (silu) GN_COL(0, true, true); else GN_COL(0, false, true); }
+            return mos_check_launch("gn_col");
+        }
+    }
+    if (resident) { if (silu) GN_COL(GN_COL_K, true, false); else GN_COL(GN_COL_K, false, false); }
+    else { if (silu) GN_COL(0, true, false); else GN_COL(0, false, false); }
+#undef GN_COL
+    return mos_check_launch("gn_col");
+}
+
+template <bool BWD>
+int gn_nhwc_dispatch(GnNhwcArgs& a, int silu, int dtype, hipStream_t st, const char* who) {
+    GnColArgs c = {};
+    bool resident = false;
+    if (gn_col_plan(a, c, resident)) {
+        if (dtype == MOS_F16) return gn_col_run<f16_t, BWD>(c, resident, silu, st);
+        if (dtype == MOS_BF16) return gn_col_run<bf16_t, BWD>(c, resident, silu, st);
+        return mos_set_error(MOS_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
+    }
+    if (dtype == MOS_F16) return gn_nhwc_run<f16_t, BWD>(a, silu, st);
+    if (dtype == MOS_BF16) return gn_nhwc_run<bf16_t, BWD>(a, silu, st);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
+}
+
 }  // namespace
 
 extern "C" {
@@ -667,9 +1026,7 @@ int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* 
     a.B = B; a.C = C; a.HW = HW; a.G = G; a.eps = eps;
     int rc = gn_nhwc_check(x, y, gamma, beta, ws, a, "mos_groupnorm_silu_fwd_nhwc");
     if (rc) return rc;
-    if (dtype == MOS_F16) return gn_nhwc_run<f16_t, false>(a, silu, (hipStream_t)stream);
-    if (dtype == MOS_BF16) return gn_nhwc_run<bf16_t, false>(a, silu, (hipStream_t)stream);
-    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_fwd_nhwc: dtype %d", dtype);
+    return gn_nhwc_dispatch<false>(a, silu, dtype, (hipStream_t)stream, "mos_groupnorm_silu_fwd_nhwc");
 }
 
 int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,
@@ -680,9 +1037,7 @@ int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamm
     int rc = gn_nhwc_check(x, dx, gamma, beta, ws, a, "mos_groupnorm_silu_bwd_nhwc");
     if (rc) return rc;
     MOS_REQUIRE(dy && stats, "mos_groupnorm_silu_bwd_nhwc: NULL dy / stats");
-    if (dtype == MOS_F16) return gn_nhwc_run<f16_t, true>(a, silu, (hipStream_t)stream);
-    if (dtype == MOS_BF16) return gn_nhwc_run<bf16_t, true>(a, silu, (hipStream_t)stream);
-    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_bwd_nhwc: dtype %d", dtype);
+    return gn_nhwc_dispatch<true>(a, silu, dtype, (hipStream_t)stream, "mos_groupnorm_silu_bwd_nhwc");
 }
 
 /* mos_groupnorm_silu_bwd_nhwc plus the gradient `ds` (x's shape, layout and dtype) of a residual connection that bypasses
@@ -697,9 +1052,7 @@ int mos_groupnorm_silu_bwd_nhwc_res(const void* dy, const void* ds, const void* 
     int rc = gn_nhwc_check(x, dx, gamma, beta, ws, a, "mos_groupnorm_silu_bwd_nhwc_res");
     if (rc) return rc;
     MOS_REQUIRE(dy && stats && ds, "mos_groupnorm_silu_bwd_nhwc_res: NULL dy / ds / stats");
-    if (dtype == MOS_F16) return gn_nhwc_run<f16_t, true>(a, silu, (hipStream_t)stream);
-    if (dtype == MOS_BF16) return gn_nhwc_run<bf16_t, true>(a, silu, (hipStream_t)stream);
-    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_bwd_nhwc_res: dtype %d", dtype);
+    return gn_nhwc_dispatch<true>(a, silu, dtype, (hipStream_t)stream, "mos_groupnorm_silu_bwd_nhwc_res");
 }
 
 }  // extern "C"

@@ -395,6 +395,52 @@ def test_groupnorm_silu_channels_last(ops, emu, dtype, silu, B, C, H, W, G):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('silu', [True, False])
+@pytest.mark.parametrize('B,C,H,W', [
+    (4, 640, 32, 32), (2, 640, 32, 48),      # 40-channel columns, two groups each (resident: 1024 / 1536 pixels)
+    (4, 320, 32, 32),                        # four 10-channel groups per column
+    (2, 1280, 16, 24), (4, 1280, 8, 8),      # one group per column
+    (2, 2560, 8, 12), (4, 2560, 16, 16),     # 80-channel columns
+    (2, 1920, 16, 24), (4, 960, 16, 16),     # 120-channel columns: 2 / 4 groups, 15 vectors per pixel
+    (2, 1920, 32, 48), (2, 960, 32, 48),     # 120-channel columns too large for registers: slice kernels in mode 1
+    (4, 320, 64, 64), (2, 320, 64, 96),      # level 0: streaming column form in mode 2 only
+    (1, 640, 5, 8),                          # fewer vectors than one wave
+])
+def test_groupnorm_column_kernel(ops, emu, dtype, silu, B, C, H, W, monkeypatch):
+    """The one-launch column kernel (MOS_GN_FUSED=1: register-resident slabs; =2: also the streaming form) against the
+    slice kernels of round 3 (=0) and the fp32 emulation: forward, statistics, input gradient, gradient + bypass."""
+    g = torch.Generator(device='cpu').manual_seed(8)
+    cl = torch.channels_last
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to('cuda', dtype).contiguous(memory_format=cl)
+    dy = torch.randn(B, C, H, W, generator=g).to('cuda', dtype).contiguous(memory_format=cl)
+    ds = torch.randn(B, C, H, W, generator=g).to('cuda', dtype).contiguous(memory_format=cl)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    y_ref, stats_ref = emu.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, silu)
+    xf = x.float().contiguous().requires_grad_(True)
+    out = torch.nn.functional.group_norm(xf, 32, gamma, beta, 1e-5)
+    out = torch.nn.functional.silu(out) if silu else out
+    (dx_ref, ) = torch.autograd.grad(out, xf, dy.float().contiguous())
+    res = {}
+    for mode in ('0', '1', '2'):
+        monkeypatch.setenv('MOS_GN_FUSED', mode)
+        y, stats = ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, silu)
+        dx = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats_ref, 32, silu)
+        dxs = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats_ref, 32, silu, ds=ds)
+        assert y.stride() == x.stride() and dx.stride() == x.stride()
+        _check(f'groupnorm[mode {mode}].y[{B}x{C}x{H}x{W}]', y, y_ref, dtype, ulps=2.0)
+        _check(f'groupnorm[mode {mode}].stats', stats, stats_ref, torch.float16, ulps=0.05)
+        _check(f'groupnorm[mode {mode}].dx', dx, dx_ref, dtype, ulps=3.0)
+        _check(f'groupnorm[mode {mode}].dx+ds', dxs, dx.float() + ds.float(), dtype, ulps=1.0)
+        res[mode] = (y, stats, dx)
+    for mode in ('1', '2'):
+        same = torch.equal(res[mode][0], res['0'][0]) and torch.equal(res[mode][2], res['0'][2])
+        print(f'[parity] groupnorm column kernel mode {mode} [{B}x{C}x{H}x{W} silu={silu}] bit-identical to the slice kernels: {same}')
+        _check(f'groupnorm mode {mode} vs slice kernels: y', res[mode][0], res['0'][0], dtype, ulps=1.0)
+        _check(f'groupnorm mode {mode} vs slice kernels: dx', res[mode][2], res['0'][2], dtype, ulps=1.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('rows,C', [(16384, 320), (4096, 640), (1024, 1280), (256, 1280), (4928, 768), (77, 768), (6144, 320)])
 def test_layernorm(ops, emu, dtype, rows, C):
     """Fused LayerNorm (half in/out, fp32 statistics) vs torch fp32 layer_norm on the same half inputs, fwd + dx."""
