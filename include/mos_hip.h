@@ -106,6 +106,26 @@ int mos_lora_linear_fused_fwd(const void* x, int64_t ldx, const void* W, int64_t
                               const void* A16, const void* Bp16, const float* bias,
                               void* y, int64_t ldy, void* t_out, int M, int N, int K, int dtype, void* stream);
 
+/* Epilogue variants of the forward GEMM (round 4). The callers are the transformer block's feed-forward and the 1x1
+ * `proj_out` of diffusers' Transformer2DModel, which the reference's processors sit in (edlora.py:49-75,124-141 return into
+ * `hidden_states = attn(...) + hidden_states; hidden_states = ff(norm3(hidden_states)) + hidden_states`):
+ *   residual != NULL : y = round(x.W^T (+ LoRA) + bias) + residual[M, Nout]   -- the rounding points of "GEMM, then an add
+ *                      kernel" (bit-identical to that pair), without the add launch and its 3 passes over the activation
+ *   geglu            : W (and bias) hold the GEGLU projection's rows INTERLEAVED in blocks of 16: rows 32q..32q+15 = value rows
+ *                      16q..16q+15, rows 32q+16..32q+31 = gate rows 16q..16q+15 (packed once by the caller; the weight is
+ *                      frozen). y is [M, N/2] = value * gelu(gate) (exact erf GELU), same arithmetic as the GEMM followed
+ *                      by mos_geglu_fwd: the (M, N) pre-activation never goes to HBM. N % 32 == 0.
+ * A16 / Bp16 NULL: plain GEMM; otherwise the fused LoRA form of mos_lora_linear_fused_fwd (t_out as there). */
+typedef struct {
+    const void* residual;     /* [M, Nout] in `dtype`, or NULL */
+    int64_t ldr;              /* its row stride in elements */
+    int geglu;                /* 0 / 1 */
+} mos_gemm_epilogue;
+int mos_lora_linear_fwd_ex(const void* x, int64_t ldx, const void* W, int64_t ldw,
+                           const void* A16, const void* Bp16, const float* bias,
+                           void* y, int64_t ldy, void* t_out, int M, int N, int K, int dtype,
+                           const mos_gemm_epilogue* epilogue_host, void* stream);
+
 /* Backward of the above w.r.t. x and the packed LoRA factors (W is frozen: no dW).
  *   dt[M,16]  = dy . BpT^T                      (written to dt)
  *   dx[M,K]   = dy[M,N] . Wt[K,N]^T + dt . A16T[K,16]^T   (Wt = W^T, cached by the caller)
@@ -310,9 +330,16 @@ int mos_groupnorm_silu_bwd_nhwc_res(const void* dy, const void* ds, const void* 
  *   residual (B, H, W, Cout) in `dtype` or NULL (added after rounding the convolution, like `x + conv(h)`)
  *   y        (B, H, W, Cout)
  * Cin % 64 == 0, Cout % 8 == 0. No workspace.
+ * `_ws` form (round 4): with a caller-allocated fp32 workspace of mos_conv3x3_nhwc_workspace_bytes() bytes (0 = this shape
+ * does not use one) the low-resolution levels (16x16 / 8x8 maps: a quarter-full chip walking a 9*Cin-deep K loop while the
+ * operator is bound by streaming 30-59 MB of weights) run split over K: per-range fp32 partial tiles + one ordered
+ * (deterministic) reduction that applies the same epilogue. ws NULL: the unsplit kernel, as mos_conv3x3_nhwc.
  * ------------------------------------------------------------------------------------------ */
 int mos_conv3x3_nhwc(const void* x, const void* w, const float* bias, const void* tbias, const void* residual,
                      void* y, int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* stream);
+int64_t mos_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const void* tbias, const void* residual,
+                        void* y, int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise operators of the transformer blocks around the attention layers:

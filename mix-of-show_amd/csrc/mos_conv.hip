@@ -40,6 +40,8 @@ struct ConvArgs {
     int B, H, Wd, Cin, Cout;      // Wd = image width
     int M, mt, nt, cpt;           // M = B*H*W ; cpt = Cin / 64 channel chunks per tap
     int up;                       // 1: the input is read through a nearest 2x upsample (x is (B, H/2, W/2, Cin))
+    int ksplit, kt_per;           // split-K form: K tiles [z * kt_per, (z + 1) * kt_per) per workgroup, z < ksplit
+    float* partial;               // split-K form: fp32 partial sums [ksplit][M][Cout]
 };
 
 template <int N>
@@ -50,7 +52,13 @@ __device__ __forceinline__ void wait_vmcnt_then_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <typename T, int BM, int BN, bool UP, int NS>
+// SPLIT (low-resolution levels: 16x16 / 8x8 maps, M = 192 .. 1024 pixels against K = 9 * Cin = 11.5 k .. 23 k): with 60 - 320
+// output tiles the chip is a quarter full and every workgroup walks a 180 - 360 tile K loop, while what bounds the operator is
+// streaming 30 - 59 MB of weights. The K loop is cut into `ksplit` ranges (tap-major, so a range is a few taps of a channel
+// slab); each workgroup leaves its fp32 partial tile in `partial[z]`, conv_splitk_reduce_kernel sums them in z order
+// (deterministic) and applies the epilogue. All m-tiles of one (n-tile, K range) run on ONE XCD, back to back: its weight
+// slice is fetched into that L2 once.
+template <typename T, int BM, int BN, bool UP, int NS, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     typedef typename MT<T>::v8 v8;
     constexpr int MI = BM / 32, NJ = BN / 32;
@@ -61,10 +69,22 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     T* Ws = Xs + NS * BM * CBK;                    // [NS][BN][64]
 
     const int w = blockIdx.x;                      // XCD-aware map: the 8 m-tiles of a slot share one weight column block
-    const int slot = w >> 3;
-    const int n_tile = slot % a.nt;
-    const int m_tile = (slot / a.nt) * 8 + (w & 7);
-    if (m_tile >= a.mt) return;
+    int n_tile, m_tile, kt0 = 0, kt1 = 9 * a.cpt, zsplit = 0;
+    if constexpr (SPLIT) {
+        const int r = w >> 3;
+        m_tile = r % a.mt;
+        const int u = (r / a.mt) * 8 + (w & 7);    // unit = (n-tile, K range); its mt workgroups share XCD w & 7
+        if (u >= a.nt * a.ksplit) return;
+        n_tile = u % a.nt;
+        zsplit = u / a.nt;
+        kt0 = zsplit * a.kt_per;
+        kt1 = min(kt1, kt0 + a.kt_per);
+    } else {
+        const int slot = w >> 3;
+        n_tile = slot % a.nt;
+        m_tile = (slot / a.nt) * 8 + (w & 7);
+        if (m_tile >= a.mt) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lg = lane >> 4;
     const int n0 = n_tile * BN, m0 = m_tile * BM;
@@ -100,8 +120,8 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = 9 * a.cpt;
-    int tap = 0, cch = 0;                      // tap / channel chunk of the NEXT tile to issue
+    const int nk = kt1;
+    int tap = kt0 / a.cpt, cch = kt0 - tap * a.cpt;   // tap / channel chunk of the NEXT tile to issue
 
     auto issue_tile = [&](int kt, int buf) {   // tile kt -> LDS buffer buf; wave w's i-th piece = slots (4 i + w) * 64 ..
         const bool live = kt < nk;             // ring only: tiles past the end are issued out of range (zeros, no traffic)
@@ -145,11 +165,11 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     };
 
     if constexpr (NS == 2) {
-        issue_tile(0, 0);
+        issue_tile(kt0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
+        for (int kt = kt0; kt < nk; ++kt) {
+            const int cur = (kt - kt0) & 1;
             if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
             compute_tile(cur);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -158,9 +178,9 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     } else {
         constexpr int L = XCH + WCH;           // DMAs per wave per tile
 #pragma unroll
-        for (int s = 0; s < NS - 1; ++s) issue_tile(s, s);
+        for (int s = 0; s < NS - 1; ++s) issue_tile(kt0 + s, s);
         int cur = 0, nxt = NS - 1;
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kt0; kt < nk; ++kt) {
             // tile kt has landed for this wave once at most the NS-2 younger tiles are outstanding; past the barrier it has
             // landed for all waves, and all of them have finished reading tile kt-1, whose buffer the next issue overwrites
             wait_vmcnt_then_barrier<(NS - 2) * L>();
@@ -173,6 +193,19 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
+    if constexpr (SPLIT) {                     // raw fp32 partial tile; the reduce kernel owns the epilogue
+        float* P = a.partial + (int64_t)zsplit * M * N;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + lg * 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+                if (m < M && n < N) *reinterpret_cast<f32x4*>(P + (int64_t)m * N + n) = acc[j][i];   // N % 8 == 0
+            }
+        }
+        return;
+    }
     // epilogue: + bias[n] + tbias[b(m)][n], round, stage in LDS, then coalesced rows (+ residual)
     T* Cs = reinterpret_cast<T*>(smem_raw);
     const T* tb = reinterpret_cast<const T*>(a.tbias);
@@ -217,6 +250,75 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     }
 }
 
+// y = round(sum_z partial[z] + tbias + bias) (+ residual): the epilogue of the unsplit kernel on the summed partials
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs a) {
+    typedef typename MT<T>::v8 v8;
+    const int N = a.Cout, nc = N / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)a.M * nc) return;
+    const int m = (int)(idx / nc), n = (int)(idx - (int64_t)m * nc) * 8;
+    const float* p = a.partial + (int64_t)m * N + n;
+    const int64_t zs = (int64_t)a.M * N;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int z = 0; z < a.ksplit; ++z) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p + z * zs), hi = *reinterpret_cast<const f32x4*>(p + z * zs + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[4 + e] += hi[e]; }
+    }
+    if (a.tbias != nullptr) {
+        const v8 t = as_v8<T>(ld16(reinterpret_cast<const T*>(a.tbias) + (int64_t)(m / (a.H * a.Wd)) * N + n));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+    }
+    v8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (T)(v[e] + (a.bias != nullptr ? a.bias[n + e] : 0.f));
+    const int64_t off = (int64_t)m * N + n;
+    if (a.R != nullptr) {
+        const v8 r = as_v8<T>(ld16(reinterpret_cast<const T*>(a.R) + off));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (T)((float)o[e] + (float)r[e]);
+    }
+    st16(reinterpret_cast<T*>(a.Y) + off, from_v8<T>(o));
+}
+
+// split-K plan: only where the 64x64 tiling leaves the chip underfilled and K is deep; aims at ~640 workgroups
+inline bool conv_splitk_enabled() {          // read per call: tests and same-box A/Bs flip it inside one process
+    const char* e = getenv("MOS_CONV_SPLITK");
+    return e == nullptr || atoi(e) != 0;
+}
+inline int conv_ksplit(int M, int Cout, int Cin, int* kt_per) {
+    const int64_t tiles = (int64_t)((M + 63) / 64) * ((Cout + 63) / 64);
+    const int nk = 9 * (Cin / 64);
+    if (!conv_splitk_enabled() || tiles > 320 || nk < 36) return 1;
+    int ks = (int)((640 + tiles - 1) / tiles);
+    if (ks > nk / 6) ks = nk / 6;               // at least 6 K tiles per workgroup
+    if (ks < 2) return 1;
+    const int per = (nk + ks - 1) / ks;
+    *kt_per = per;
+    return (nk + per - 1) / per;
+}
+
+template <typename T, bool UP>
+int launch_conv_split(ConvArgs a, hipStream_t st) {
+    constexpr int BM = 64, BN = 64, NS = 3;
+    const size_t lds = (size_t)NS * (BM + BN) * CBK * sizeof(T);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN, UP, NS, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    a.mt = (a.M + BM - 1) / BM;
+    a.nt = (a.Cout + BN - 1) / BN;
+    const int units8 = (a.nt * a.ksplit + 7) / 8;
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, BM, BN, UP, NS, true>), dim3(8 * units8 * a.mt), dim3(256), lds, st, a);
+    int rc = mos_check_launch("conv3x3_nhwc(split-K)");
+    if (rc) return rc;
+    const int64_t chunks = (int64_t)a.M * (a.Cout / 8);
+    hipLaunchKernelGGL((conv_splitk_reduce_kernel<T>), dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, a);
+    return mos_check_launch("conv_splitk_reduce");
+}
+
 template <typename T, int BM, int BN, bool UP, int NS>
 int launch_conv_cfg2(ConvArgs a, hipStream_t st) {
     size_t lds = (size_t)NS * (BM + BN) * CBK * sizeof(T);
@@ -245,11 +347,17 @@ inline int ring_max_wg() {
 
 template <typename T>
 int launch_conv(ConvArgs a, hipStream_t st) {
-    char key[96];
-    snprintf(key, sizeof(key), "%s B%d %dx%d Cin%d Cout%d%s%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", a.B, a.H, a.Wd,
-             a.Cin, a.Cout, a.up ? " up2x" : "", a.tbias ? " +tbias" : "", a.R ? " +res" : "");
+    char key[112];
+    int kt_per = 0;
+    const int ks = a.partial != nullptr ? conv_ksplit(a.M, a.Cout, a.Cin, &kt_per) : 1;
+    snprintf(key, sizeof(key), "%s B%d %dx%d Cin%d Cout%d%s%s%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", a.B, a.H, a.Wd,
+             a.Cin, a.Cout, a.up ? " up2x" : "", a.tbias ? " +tbias" : "", a.R ? " +res" : "", ks > 1 ? " splitK" : "");
     MosProfScope prof(st, "conv3x3", key, 2.0 * a.M * (double)a.Cout * 9.0 * a.Cin,
                       2.0 * ((double)a.M * a.Cin / (a.up ? 4 : 1) + 9.0 * a.Cin * a.Cout + (double)a.M * a.Cout * (a.R ? 2 : 1)));
+    if (ks > 1) {
+        a.ksplit = ks; a.kt_per = kt_per;
+        return a.up ? launch_conv_split<T, true>(a, st) : launch_conv_split<T, false>(a, st);
+    }
     int bn = (a.Cout % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
     if (tiles(bm, bn) < 384) bm = 64;
@@ -265,8 +373,22 @@ int launch_conv(ConvArgs a, hipStream_t st) {
 
 extern "C" {
 
+int64_t mos_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 8) return 0;
+    int kt_per = 0;
+    const int64_t M = (int64_t)B * H * W;
+    if (M > (1 << 20)) return 0;
+    const int ks = conv_ksplit((int)M, Cout, Cin, &kt_per);
+    return ks > 1 ? (int64_t)ks * M * Cout * (int64_t)sizeof(float) : 0;
+}
+
 int mos_conv3x3_nhwc(const void* x, const void* w, const float* bias, const void* tbias, const void* residual, void* y,
                      int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* stream) {
+    return mos_conv3x3_nhwc_ws(x, w, bias, tbias, residual, y, B, H, W, Cin, Cout, upsample2x, dtype, nullptr, stream);
+}
+
+int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const void* tbias, const void* residual, void* y,
+                        int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws, void* stream) {
     MOS_REQUIRE(x && w && y, "mos_conv3x3_nhwc: NULL argument");
     MOS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 8 == 0,
                 "mos_conv3x3_nhwc: B=%d H=%d W=%d Cin=%d Cout=%d (need Cin %% 64 == 0, Cout %% 8 == 0)", B, H, W, Cin, Cout);
@@ -277,6 +399,7 @@ int mos_conv3x3_nhwc(const void* x, const void* w, const float* bias, const void
     a.X = x; a.W = w; a.bias = bias; a.tbias = tbias; a.R = residual; a.Y = y;
     a.B = B; a.H = H; a.Wd = W; a.Cin = Cin; a.Cout = Cout; a.M = B * H * W; a.cpt = Cin / 64; a.up = upsample2x ? 1 : 0;
     a.mt = a.nt = 0;
+    a.ksplit = 1; a.kt_per = 0; a.partial = (float*)ws;
     if (dtype == MOS_F16) return launch_conv<f16_t>(a, (hipStream_t)stream);
     if (dtype == MOS_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_conv3x3_nhwc: dtype %d", dtype);

@@ -926,7 +926,7 @@ bool gn_col_plan(const GnNhwcArgs& a, GnColArgs& c, bool& resident) {
     if (mode <= 0) return false;
     const int cpg = a.C / a.G;
     const int cu = cpg / gn_gcd(cpg, 8) * 8;        // lcm(cpg, 8): whole groups AND whole 16-byte vectors
-    if (cu < 32 || cu > 128 || a.C % cu != 0 || cu / cpg > GN_COL_NG) return false;
+    if (cpg < 8 || cu < 32 || cu > 128 || a.C % cu != 0 || cu / cpg > GN_COL_NG) return false;   // (cpg >= 8: a vector spans <= 2 groups)
     c.B = a.B; c.C = a.C; c.HW = a.HW; c.G = a.G; c.cpg = cpg; c.eps = a.eps;
     c.NV = cu / 8; c.ng = cu / cpg; c.units = a.C / cu;
     const int64_t vectors = (int64_t)a.HW * c.NV;

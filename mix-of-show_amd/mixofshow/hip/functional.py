@@ -359,7 +359,7 @@ def _lora_operands(downs, ups, alphas, K, dtype, device):
 class _LoRALinear(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, W16, Wt16, bias32, alphas, *params):
+    def forward(ctx, x, W16, Wt16, bias32, alphas, residual, *params):
         cd = W16.dtype
         K = W16.shape[1]
         N = W16.shape[0]
@@ -368,22 +368,36 @@ class _LoRALinear(torch.autograd.Function):
             x2 = x2.to(cd)
         if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
             x2 = x2.contiguous()
+        r2 = None
+        if residual is not None:         # y = round(GEMM) + residual in the GEMM's epilogue (== the GEMM followed by a half add)
+            r2 = residual.reshape(-1, N)
+            if r2.dtype != cd:
+                r2 = r2.to(cd)
+            if r2.stride(1) != 1 or r2.stride(0) % 8 != 0:
+                r2 = r2.contiguous()
         n_sites = len(params) // 2
         need_grad = any(ctx.needs_input_grad)
         if n_sites:
             downs, ups = params[0::2], params[1::2]
             A16, A16T, Bp16, BpT = _lora_operands(downs, ups, alphas, K, cd, x2.device)
-            y, t = ops.linear_fused_fwd(x2, W16, A16, Bp16, bias32, need_t=need_grad)
+            if r2 is None:
+                y, t = ops.linear_fused_fwd(x2, W16, A16, Bp16, bias32, need_t=need_grad)
+            else:
+                y, t = ops.linear_fwd_ex(x2, W16, A16, Bp16, bias32, residual=r2, need_t=need_grad)
             ctx.save_for_backward(x2, t, A16T, BpT, Wt16)
             ctx.params = params if need_grad else None
         else:
-            y = ops.linear_fwd(x2, W16, None, None, bias32)
+            if r2 is None:
+                y = ops.linear_fwd(x2, W16, None, None, bias32)
+            else:
+                y = ops.linear_fwd_ex(x2, W16, None, None, bias32, residual=r2)[0]
             ctx.save_for_backward(x2, None, None, None, Wt16)
             ctx.params = None
         ctx.alphas = alphas
         ctx.n_sites = n_sites
         ctx.rank = params[0].shape[0] if n_sites else 0
         ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
+        ctx.r_shape, ctx.r_dtype = (None, None) if residual is None else (residual.shape, residual.dtype)
         return y.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -398,18 +412,23 @@ class _LoRALinear(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         if need_dx and Wt16 is None:
             raise RuntimeError('mixofshow.hip: backward to the input needs the transposed weight (Wt16)')
+        dres = None
+        if ctx.r_shape is not None and ctx.needs_input_grad[5]:      # the residual's gradient IS dy (no kernel)
+            dres = dy.reshape(ctx.r_shape)
+            if dres.dtype != ctx.r_dtype:
+                dres = dres.to(ctx.r_dtype)
         grads = [None] * (2 * ctx.n_sites)
         if ctx.n_sites == 0:
             dx = ops.linear_bwd(dy2, x2, Wt16, None, None, None, need_dx=need_dx, need_lora=False)[0]
         else:
             targets = None
-            if any(ctx.needs_input_grad[5:]):
+            if any(ctx.needs_input_grad[6:]):
                 targets = []
                 for g in range(ctx.n_sites):
                     pair, accs = [], []
                     for q in (2 * g, 2 * g + 1):
                         p = ctx.params[q]
-                        if not ctx.needs_input_grad[5 + q]:
+                        if not ctx.needs_input_grad[6 + q]:
                             pair.append(None)
                             accs.append(False)
                         elif (_direct_grad and p.grad is not None and p.grad.dtype == torch.float32
@@ -438,16 +457,80 @@ class _LoRALinear(torch.autograd.Function):
             dx = dx.view(ctx.x_shape)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
-        return (dx, None, None, None, None, *grads)
+        return (dx, None, None, None, None, dres, *grads)
 
 
-def lora_linear(x, W16, Wt16, bias32, sites):
-    """sites: list of (lora_down.weight (r,K[,1,1]), lora_up.weight (n,r[,1,1]), alpha float)."""
+def lora_linear(x, W16, Wt16, bias32, sites, residual=None):
+    """sites: list of (lora_down.weight (r,K[,1,1]), lora_up.weight (n,r[,1,1]), alpha float).
+    residual (shape of the result): added in the GEMM's epilogue (same rounding points as GEMM + add kernel)."""
     params, alphas = [], []
     for down, up, alpha in sites:
         params += [down, up]
         alphas.append(float(alpha))
-    return _LoRALinear.apply(x, W16, Wt16, bias32, tuple(alphas), *params)
+    return _LoRALinear.apply(x, W16, Wt16, bias32, tuple(alphas), residual, *params)
+
+
+# ---- feed-forward of the transformer block (diffusers FeedForward: GEGLU projection, Linear) on the library's GEMM ---------
+# A/B switches: MOS_FF_GEGLU=0 keeps FF1 on torch's GEMM + the geglu kernel also when sampling; MOS_FF2_OWN=0 keeps FF2 on
+# torch's GEMM (hipBLASLt) + a separate add; MOS_GEMM_RESIDUAL=0 keeps the 1x1 proj_out's residual a separate add.
+_ff_geglu = _os.environ.get('MOS_FF_GEGLU', '1') != '0'
+_ff2_own = _os.environ.get('MOS_FF2_OWN', '1') != '0'
+_gemm_residual = _os.environ.get('MOS_GEMM_RESIDUAL', '1') != '0'
+
+
+def _plain_linear(linear):
+    """An untouched, frozen nn.Linear: no LoRA branch (its forward is replaced), no hooks (gradient fusion records through
+    nn.Module.__call__), nothing trainable."""
+    return (type(linear) is torch.nn.Linear and getattr(linear, '_mos_lora', None) is None
+            and linear.forward.__func__ is torch.nn.Linear.forward and not linear._forward_hooks
+            and not linear._forward_pre_hooks and _frozen(linear.weight, linear.bias))
+
+
+def _half_path(x):
+    half = x.dtype in (torch.float16, torch.bfloat16)
+    ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
+    if not (x.is_cuda and (half or ac)):
+        return None
+    return x.dtype if half else torch.get_autocast_dtype('cuda')
+
+
+def linear_residual(linear, x, residual):
+    """`linear(x) + residual` (transformer block: ff.net[2](h) + hidden_states) as ONE GEMM with the add in its epilogue, on the
+    HIP path (frozen plain Linear, half activations, K and N multiples of 8); anything else: the two plain ops."""
+    dt = _half_path(x) if (_ff2_own and _plain_linear(linear)) else None
+    if dt is None or linear.in_features % 8 or linear.out_features % 8 or residual.shape[:-1] != x.shape[:-1]:
+        return linear(x) + residual
+    cache = linear.__dict__.get('_mos_cache')
+    if cache is None:
+        cache = WeightCache()
+        object.__setattr__(linear, '_mos_cache', cache)
+    need_bwd = torch.is_grad_enabled() and x.requires_grad
+    W16, Wt16 = cache.weight('w', [linear.weight], dt, transposed=need_bwd)
+    b32 = cache.bias('w', [linear.bias])
+    return lora_linear(x if x.dtype == dt else x.to(dt), W16, Wt16, b32, [], residual=residual)
+
+
+def linear_geglu(proj, x):
+    """`geglu(proj(x))` (diffusers GEGLU). Sampling (no gradient wanted) on the HIP path: ONE GEMM whose epilogue forms
+    value * gelu(gate) from the interleaved weight rows -- the (rows, 8C) pre-activation is never written. Training keeps the
+    pre-activation (the backward of GEGLU needs it): torch's GEMM + the geglu kernel."""
+    dt = _half_path(x) if (_ff_geglu and _plain_linear(proj)) else None
+    if (dt is None or (torch.is_grad_enabled() and x.requires_grad) or proj.in_features % 8 or proj.out_features % 32):
+        return geglu(proj(x))
+    ent = proj.__dict__.get('_mos_geglu')
+    w, b = proj.weight, proj.bias
+    key = (w.data_ptr(), w._version, w.dtype, dt, None if b is None else (b.data_ptr(), b._version))
+    if ent is None or ent[0] != key:
+        Wi, bi = ops.geglu_interleave(w.detach().to(dt), None if b is None else b.detach().float())
+        ent = (key, Wi, bi)
+        object.__setattr__(proj, '_mos_geglu', ent)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype != dt:
+        x2 = x2.to(dt)
+    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
+        x2 = x2.contiguous()
+    y = ops.linear_fwd_ex(x2, ent[1], None, None, ent[2], geglu=True)[0]
+    return y.view(*x.shape[:-1], y.shape[-1])
 
 
 class _Attention(torch.autograd.Function):
@@ -908,8 +991,8 @@ def set_conv3x3_enabled(flag):
     _conv_enabled = bool(flag)
 
 
-def conv1x1(conv, x):
-    """`conv(x)` for a frozen 1x1 nn.Conv2d (Transformer2DModel.proj_in / proj_out, ResnetBlock2D.conv_shortcut) as a plain
+def conv1x1(conv, x, residual=None):
+    """`conv(x)` (+ residual, in the GEMM's epilogue) for a frozen 1x1 nn.Conv2d (Transformer2DModel.proj_in / proj_out, ResnetBlock2D.conv_shortcut) as a plain
     GEMM of the library on the token-major view of a channels_last tensor (free view in, free view out). A LoRA-wrapped
     conv never gets here (its forward is LoRALinearLayer.forward); CPU / fp32 / trainable / NCHW inputs take torch."""
     half = x.dtype in (torch.float16, torch.bfloat16)
@@ -921,7 +1004,8 @@ def conv1x1(conv, x):
           and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and _conv_enabled and _conv1x1_enabled
           and not conv._forward_hooks and not conv._forward_pre_hooks)      # hooks (gradient fusion) need conv.__call__
     if not ok:
-        return conv(x)
+        y = conv(x)
+        return y if residual is None else y + residual
     dt = x.dtype if half else torch.get_autocast_dtype('cuda')
     cache = conv.__dict__.get('_mos_cache')
     if cache is None:
@@ -931,5 +1015,12 @@ def conv1x1(conv, x):
     W16, Wt16 = cache.weight('w', [conv.weight], dt, transposed=torch.is_grad_enabled() and x.requires_grad)
     b32 = cache.bias('w', [conv.bias])
     tokens = x.permute(0, 2, 3, 1).reshape(b * h * w, c)
-    y = lora_linear(tokens if tokens.dtype == dt else tokens.to(dt), W16, Wt16, b32, [])
-    return y.view(b, h, w, -1).permute(0, 3, 1, 2)
+    res2 = None
+    if residual is not None:
+        fuse = (_gemm_residual and residual.dim() == 4 and residual.shape == (b, conv.out_channels, h, w)
+                and residual.dtype == dt and residual.is_contiguous(memory_format=torch.channels_last))
+        if fuse:
+            res2 = residual.permute(0, 2, 3, 1).reshape(b * h * w, conv.out_channels)     # free view of a channels_last tensor
+    y = lora_linear(tokens if tokens.dtype == dt else tokens.to(dt), W16, Wt16, b32, [], residual=res2)
+    y = y.view(b, h, w, -1).permute(0, 3, 1, 2)
+    return y if (residual is None or res2 is not None) else y + residual

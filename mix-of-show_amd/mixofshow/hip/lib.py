@@ -69,6 +69,10 @@ class LoraFinalRec(ctypes.Structure):          # mos_lora_final_rec
     ]
 
 
+class GemmEpilogue(ctypes.Structure):          # mos_gemm_epilogue
+    _fields_ = [('residual', ctypes.c_void_p), ('ldr', ctypes.c_int64), ('geglu', ctypes.c_int)]
+
+
 class AttnShape(ctypes.Structure):
     _fields_ = [
         ('B', ctypes.c_int), ('H', ctypes.c_int), ('Nq', ctypes.c_int), ('Nkv', ctypes.c_int), ('d', ctypes.c_int),
@@ -113,6 +117,8 @@ SIGNATURES = {
     'mos_lora_pack': (_i, [ctypes.POINTER(LoraSites), _i, _vp, _vp, _vp, _vp, _vp]),
     'mos_lora_pack_all': (_i, [_vp, _i, _i, _i, _vp]),
     'mos_lora_linear_fused_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
+    'mos_lora_linear_fwd_ex': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _i,
+                                    ctypes.POINTER(GemmEpilogue), _vp]),
     'mos_lora_linear_fused_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
                                        ctypes.POINTER(LoraGradOut), _vp, _i, _i, _i, _i, _i, _vp]),
     'mos_lora_linear_fused_bwd_deferred': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
@@ -142,6 +148,8 @@ SIGNATURES = {
     'mos_groupnorm_silu_bwd_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_groupnorm_silu_bwd_nhwc_res': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_conv3x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'mos_conv3x3_nhwc_workspace_bytes': (_i64, [_i, _i, _i, _i, _i]),
+    'mos_conv3x3_nhwc_ws': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mos_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     'mos_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'mos_add_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp]),

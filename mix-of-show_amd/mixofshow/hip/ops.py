@@ -218,6 +218,41 @@ def linear_fwd(x, W, t=None, Bp16=None, bias=None, out=None):
     return y
 
 
+def geglu_interleave(W, bias=None):
+    """The GEGLU projection's rows (and bias) in the order the GEGLU epilogue of linear_fwd_ex consumes: blocks of 16 value
+    rows followed by the 16 gate rows of the same output features (include/mos_hip.h mos_gemm_epilogue). W (2F, K)."""
+    F2 = W.shape[0]
+    assert F2 % 32 == 0
+    F = F2 // 2
+    idx = torch.arange(F, device=W.device).view(F // 16, 1, 16)
+    perm = torch.cat([idx, idx + F], dim=1).reshape(-1)           # [16 value | 16 gate] per block
+    return W[perm].contiguous(), (None if bias is None else bias[perm].contiguous())
+
+
+def linear_fwd_ex(x, W, A16=None, Bp16=None, bias=None, residual=None, geglu=False, need_t=False):
+    """mos_lora_linear_fwd_ex: y = x . W^T (+ (x . A16^T) . Bp16^T) (+ bias) with an epilogue variant:
+    residual (M, Nout): added to the rounded result (== GEMM followed by a half add, one launch);
+    geglu: W / bias interleaved by geglu_interleave, y (M, N/2) = value * gelu(gate). Returns (y, t | None)."""
+    _dev(x, W, A16, Bp16, bias, residual)
+    M, K = x.shape
+    N = W.shape[0]
+    nout = N // 2 if geglu else N
+    assert W.shape[1] == K and W.dtype == x.dtype and (A16 is None) == (Bp16 is None)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+    epi = _lib.GemmEpilogue()
+    epi.residual, epi.ldr, epi.geglu = None, 0, int(bool(geglu))
+    if residual is not None:
+        assert residual.shape == (M, nout) and residual.dtype == x.dtype
+        epi.residual, epi.ldr = residual.data_ptr(), _rows(residual)
+    y = torch.empty((M, nout), dtype=x.dtype, device=x.device)
+    t = torch.empty((M, MOS_LORA_PAD), dtype=x.dtype, device=x.device) if (need_t and A16 is not None) else None
+    L = _lib.load()
+    _lib.check(L.mos_lora_linear_fwd_ex(_p(x), _rows(x), _p(W), _rows(W), _p(A16), _p(Bp16), _p(bias), _p(y), _rows(y), _p(t),
+                                        M, N, K, _dt(x), ctypes.byref(epi), _stream()), 'mos_lora_linear_fwd_ex')
+    return y, t
+
+
 def linear_bwd(dy, x, Wt, t, A16T, BpT, need_dx=True, need_lora=True, lora_cols=16):
     """Backward of linear_fwd. Returns (dx | None, dA16 (16,K) fp32 | None, dBpT (16,N) fp32 | None)."""
     _dev(dy, x, Wt, t, A16T, BpT)
@@ -571,6 +606,8 @@ def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=Fal
     if residual is not None:
         assert residual.shape == y.shape and residual.dtype == x.dtype and residual.stride() == y.stride()
     L = _lib.load()
-    _lib.check(L.mos_conv3x3_nhwc(_p(x), _p(w_ohwi), _p(bias), _p(tbias), _p(residual), _p(y), B, H, W, Cin, Cout,
-                                  int(bool(upsample2x)), _dt(x), _stream()), 'mos_conv3x3_nhwc')
+    nbytes = L.mos_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout)      # > 0: the split-K form of the low-resolution levels
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device) if nbytes > 0 else None
+    _lib.check(L.mos_conv3x3_nhwc_ws(_p(x), _p(w_ohwi), _p(bias), _p(tbias), _p(residual), _p(y), B, H, W, Cin, Cout,
+                                     int(bool(upsample2x)), _dt(x), _p(ws), _stream()), 'mos_conv3x3_nhwc_ws')
     return y

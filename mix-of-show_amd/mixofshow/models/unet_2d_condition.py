@@ -21,7 +21,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mixofshow.hip.functional import add_layer_norm, conv1x1, conv3x3, geglu, group_norm_act
+from mixofshow.hip.functional import (add_layer_norm, conv1x1, conv3x3, geglu, group_norm_act, linear_geglu,  # noqa: F401
+                                       linear_residual)
 from mixofshow.models.attention import Attention
 
 
@@ -165,7 +166,9 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        return geglu(self.proj(x))          # value * gelu(gate): one fused kernel each way on the HIP device
+        # value * gelu(gate). Sampling: formed in the epilogue of the projection GEMM (the (rows, 8C) pre-activation never
+        # reaches HBM); training: GEMM + one fused kernel each way (the backward needs the pre-activation)
+        return linear_geglu(self.proj, x)
 
 
 class FeedForward(nn.Module):
@@ -174,10 +177,12 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
 
-    def forward(self, x):
-        for m in self.net:
-            x = m(x)
-        return x
+    def forward(self, x, residual=None):
+        """`net(x)` (+ residual: the transformer block's `ff(norm3(h)) + h`, added in the epilogue of the last GEMM)."""
+        x = self.net[1](self.net[0](x))
+        if residual is None:
+            return self.net[2](x)
+        return linear_residual(self.net[2], x, residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -200,7 +205,7 @@ class BasicTransformerBlock(nn.Module):
         x, n = add_layer_norm(self.norm2, x, a)
         a = self.attn2(n, encoder_hidden_states=encoder_hidden_states, **cak)
         x, n = add_layer_norm(self.norm3, x, a)
-        return self.ff(n) + x
+        return self.ff(n, residual=x)
 
 
 class Transformer2DModel(nn.Module):
@@ -223,7 +228,7 @@ class Transformer2DModel(nn.Module):
         # (b, hw, c) -> NCHW view with channels-last strides: free when the UNet runs in channels_last memory format
         # (the token-major layout of the attention path IS NHWC); the 1x1 conv accepts either layout
         x = x.reshape(b, h, w, -1).permute(0, 3, 1, 2)
-        return conv1x1(self.proj_out, x) + residual
+        return conv1x1(self.proj_out, x, residual=residual)
 
 
 class CrossAttnDownBlock2D(nn.Module):

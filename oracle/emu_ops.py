@@ -7,7 +7,7 @@ Emulations compute in fp32 from the (possibly half) inputs and round the result 
 """
 import torch
 
-EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
+EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_fwd_ex', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
             'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
             'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
 PAD = 16
@@ -50,6 +50,22 @@ def linear_fused_fwd(x, W, A16, Bp16, bias=None, need_t=True):
     """mos_lora_linear_fused_fwd: t = x A16^T accumulated in fp32, ROUNDED to the half type, then y as linear_fwd."""
     t = (x.float() @ A16.float().t()).to(x.dtype)
     return linear_fwd(x, W, t, Bp16, bias), (t if need_t else None)
+
+
+def linear_fwd_ex(x, W, A16=None, Bp16=None, bias=None, residual=None, geglu=False, need_t=False):
+    """mos_lora_linear_fwd_ex: the GEMM rounded to the half type, then the epilogue on the rounded values (geglu on the
+    interleaved [16 value | 16 gate] column blocks; residual added last, rounded again)."""
+    t = None
+    if A16 is not None:
+        t = (x.float() @ A16.float().t()).to(x.dtype)
+    y = linear_fwd(x, W, t, Bp16, bias)
+    if geglu:
+        M, N = y.shape
+        blk = y.view(M, N // 32, 2, 16).float()
+        y = (blk[:, :, 0] * torch.nn.functional.gelu(blk[:, :, 1])).reshape(M, N // 2).to(x.dtype)
+    if residual is not None:
+        y = (y.float() + residual.float()).to(x.dtype)
+    return y, (t if need_t else None)
 
 
 def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True):

@@ -301,3 +301,97 @@ def test_batched_time_embedding_projections_equal_per_block_projections(emulated
     assert not torch.allclose(ref2, ref) and (got2 - ref2).abs().max() <= 1e-4 * ref2.abs().max()
     unet.down_blocks[0].resnets[0].time_emb_proj.weight.requires_grad_(True)      # trainable projection: not batched
     assert not unet._time_projections.usable()
+
+
+# ---- round 4: GEMM epilogues (residual add, GEGLU) on the feed-forward and the 1x1 proj_out -------------------------------
+def test_geglu_interleave_and_epilogue_emulation_equal_projection_then_geglu():
+    """ops.geglu_interleave puts the projection's rows in the order the GEGLU epilogue pairs them; the emulated
+    linear_fwd_ex(geglu=True) on the interleaved weight == GEMM (rounded) followed by value * gelu(gate)."""
+    from mixofshow.hip import ops
+    from oracle import emu_ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(24, 64, generator=g).half()
+    W = (torch.randn(256, 64, generator=g) * 0.1).half()
+    b = torch.randn(256, generator=g) * 0.1
+    Wi, bi = ops.geglu_interleave(W, b)
+    assert Wi.shape == W.shape and torch.equal(Wi[:16], W[:16]) and torch.equal(Wi[16:32], W[128:144])
+    assert torch.equal(Wi[32:48], W[16:32]) and torch.equal(bi[16:32], b[128:144])
+    h = emu_ops.linear_fwd(x, W, bias=b)
+    want = emu_ops.geglu_fwd(h)
+    got, _ = emu_ops.linear_fwd_ex(x, Wi, None, None, bi, geglu=True)
+    # (the CPU BLAS blocks the permuted weight differently: last-place differences of the fp32 GEMM before the rounding)
+    assert (got.float() - want.float()).abs().max() <= 2 ** -9 * want.float().abs().max()
+    r = torch.randn(24, 128, generator=g).half()
+    got_r, _ = emu_ops.linear_fwd_ex(x, Wi, None, None, bi, residual=r, geglu=True)
+    assert torch.equal(got_r, (got.float() + r.float()).half())
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+def test_feed_forward_with_fused_residual_and_geglu_epilogue(gpu_branches, dtype):
+    """FeedForward(n, residual=x): training branch (GEMM + geglu kernel, FF2 with the add in its epilogue) is bit-identical
+    to `ff(n) + x` with the separate add, gradients included; the sampling branch (no_grad: GEGLU epilogue) gives the same
+    forward values."""
+    from mixofshow.models.unet_2d_condition import FeedForward
+    torch.manual_seed(5)
+    ff = FeedForward(64).requires_grad_(False)
+    for p in ff.parameters():
+        p.data = p.data.to(dtype)
+    g = torch.Generator().manual_seed(6)
+    n0 = torch.randn(2, 24, 64, generator=g).to(dtype)
+    x0 = torch.randn(2, 24, 64, generator=g).to(dtype)
+    wy = torch.randn(2, 24, 64, generator=g).to(dtype)
+
+    def run(fused):
+        F_hip._ff2_own = fused
+        n = n0.clone().requires_grad_(True)
+        x = x0.clone().requires_grad_(True)
+        y = ff(n, residual=x) if fused else ff(n) + x
+        (y * wy).float().sum().backward()
+        return y.detach(), n.grad, x.grad
+
+    try:
+        fused, plain = run(True), run(False)
+    finally:
+        F_hip._ff2_own = True
+    assert torch.equal(fused[2], plain[2]) and torch.equal(fused[2], wy)      # the residual's gradient IS dy
+    # forward: own GEMM (fp32 accumulate, one rounding, then the half add) vs torch's CPU half linear + add
+    assert (fused[0].float() - plain[0].float()).abs().max() <= 2 ** -6 * plain[0].float().abs().max()
+    assert ((fused[1].float() - plain[1].float()).norm() / plain[1].float().norm()).item() <= 2e-2
+    with torch.no_grad():
+        y_s = ff(n0, residual=x0)                     # sampling: FF1 = GEMM with the GEGLU epilogue
+        F_hip._ff_geglu = False
+        try:
+            y_p = ff(n0, residual=x0)
+        finally:
+            F_hip._ff_geglu = True
+    assert getattr(ff.net[0].proj, '_mos_geglu', None) is not None
+    assert (y_s.float() - y_p.float()).abs().max() <= 2 ** -6 * y_p.float().abs().max()
+    assert (y_s.float() - fused[0].float()).abs().max() <= 2 ** -6 * fused[0].float().abs().max()
+
+
+def test_conv1x1_residual_epilogue_matches_conv_plus_residual(gpu_branches):
+    """Transformer2DModel.proj_out(x) + residual with the add in the GEMM's epilogue: same values as the separate add,
+    gradient of the residual = dy, layout kept."""
+    torch.manual_seed(7)
+    conv = torch.nn.Conv2d(64, 32, 1).requires_grad_(False).half()
+    g = torch.Generator().manual_seed(8)
+    cl = torch.channels_last
+    x0 = torch.randn(2, 64, 6, 8, generator=g).half().contiguous(memory_format=cl)
+    r0 = torch.randn(2, 32, 6, 8, generator=g).half().contiguous(memory_format=cl)
+    wy = torch.randn(2, 32, 6, 8, generator=g).half().contiguous(memory_format=cl)
+
+    def run(fused):
+        F_hip._gemm_residual = fused
+        x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        r = r0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        y = F_hip.conv1x1(conv, x, residual=r)
+        (y * wy).float().sum().backward()
+        return y.detach(), x.grad, r.grad
+
+    try:
+        fused, plain = run(True), run(False)
+    finally:
+        F_hip._gemm_residual = True
+    for a, b in zip(fused, plain):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert fused[0].is_contiguous(memory_format=cl)

@@ -395,6 +395,62 @@ def test_groupnorm_silu_channels_last(ops, emu, dtype, silu, B, C, H, W, G):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,N,K,lora', [
+    (16384, 320, 1280, False),    # FF2 level 0, training batch (N = 320: 64-wide tiles)
+    (12288, 320, 1280, False),    # FF2 level 0, 512x768 CFG pair
+    (3072, 640, 2560, False), (768, 1280, 5120, False), (192, 1280, 5120, False), (1024, 1280, 5120, False),
+    (12288, 320, 320, False),     # proj_out 1x1 + residual
+    (4096, 640, 640, True),       # a LoRA site with a residual (where: Transformer2DModel)
+    (300, 320, 328, False),       # ragged M, K % 64 != 0
+])
+def test_gemm_residual_epilogue(ops, emu, dtype, M, N, K, lora):
+    """mos_lora_linear_fwd_ex(residual): bit-identical to the GEMM followed by torch's half add (same rounding points), and
+    within tolerance of the fp32 emulation."""
+    g = torch.Generator(device='cpu').manual_seed(12)
+    x = torch.randn(M, K, generator=g).to('cuda', dtype)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to('cuda', dtype)
+    b = (torch.randn(N, generator=g) * 0.1).cuda()
+    r = torch.randn(M, N, generator=g).to('cuda', dtype)
+    A16 = Bp16 = None
+    if lora:
+        downs, ups = _lora_factors([N], 4, K, 'cuda', 3)
+        A16, _, Bp16, _ = ops.lora_pack(downs, ups, [1.0], K, dtype, x.device)
+    y, t = ops.linear_fwd_ex(x, W, A16, Bp16, b, residual=r, need_t=lora)
+    if lora:
+        y0, t0 = ops.linear_fused_fwd(x, W, A16, Bp16, b)
+        assert torch.equal(t, t0)
+    else:
+        y0 = ops.linear_fwd(x, W, None, None, b)
+    exact = torch.equal(y, y0 + r)
+    print(f'[parity] gemm+residual[{M}x{N}x{K} lora={lora}] bit-identical to GEMM + add: {exact}')
+    assert exact
+    _check('gemm+residual vs emulation', y, emu.linear_fwd_ex(x, W, A16, Bp16, b, residual=r)[0], dtype, ulps=2.0)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('M,C', [(12288, 320), (8192, 320), (3072, 640), (768, 1280), (192, 1280), (100, 64)])
+def test_gemm_geglu_epilogue(ops, emu, dtype, M, C):
+    """mos_lora_linear_fwd_ex(geglu) on the interleaved GEGLU projection (C -> 8C): bit-identical to the GEMM on the original
+    weight followed by mos_geglu_fwd (same arithmetic: rounded pre-activations, fp32 product, one rounding)."""
+    g = torch.Generator(device='cpu').manual_seed(13)
+    x = torch.randn(M, C, generator=g).to('cuda', dtype)
+    W = (torch.randn(8 * C, C, generator=g) * C ** -0.5).to('cuda', dtype)
+    b = (torch.randn(8 * C, generator=g) * 0.1).cuda()
+    Wi, bi = ops.geglu_interleave(W, b)
+    y, _ = ops.linear_fwd_ex(x, Wi, None, None, bi, geglu=True)
+    assert y.shape == (M, 4 * C)
+    want = ops.geglu_fwd(ops.linear_fwd(x, W, None, None, b))
+    exact = torch.equal(y, want)
+    print(f'[parity] gemm+geglu[{M}x{8 * C}x{C}] bit-identical to GEMM + geglu kernel: {exact}')
+    if not exact:          # (the two GEMMs tile N differently only if their grids differ: same kernel, same K order -> expected exact)
+        _check('gemm+geglu vs GEMM + geglu kernel', y, want, dtype, ulps=1.0)
+    _check('gemm+geglu vs emulation', y, emu.linear_fwd_ex(x, Wi, None, None, bi, geglu=True)[0], dtype, ulps=2.0)
+    r = torch.randn(M, 4 * C, generator=g).to('cuda', dtype)
+    yr, _ = ops.linear_fwd_ex(x, Wi, None, None, bi, residual=r, geglu=True)
+    assert torch.equal(yr, y + r)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('silu', [True, False])
 @pytest.mark.parametrize('B,C,H,W', [
     (4, 640, 32, 32), (2, 640, 32, 48),      # 40-channel columns, two groups each (resident: 1024 / 1536 pixels)
@@ -694,6 +750,10 @@ def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
     (1, 128, 256, 250, 203, 'r'),     # VAE stage, 128 x 128 tiles, ragged last tile
     (1, 128, 128, 512, 500, ''),      # VAE 512-px stage (largest tile variant when enabled)
     (1, 64, 8, 5, 7, 'tr'),           # tiny / odd sizes
+    (2, 1280, 1280, 16, 24, 'tr'),    # 512x768 sample, level 2: split-K form (240 tiles, 4 K ranges)
+    (2, 2560, 1280, 8, 12, 't'),      # level 3 up block: split-K, 360 K tiles
+    (2, 1280, 1280, 8, 12, 'u'),      # Upsample2D into the 16x24 level: split-K with the upsampling gather
+    (2, 1280, 640, 16, 24, ''),       # Cout = 640
 ])
 def test_conv3x3_nhwc(ops, emu, dtype, B, Cin, Cout, H, W, extras):
     """Implicit-GEMM 3x3 convolution (channels_last) vs fp32 torch conv2d on the same half operands: forward with the
@@ -721,3 +781,15 @@ def test_conv3x3_nhwc(ops, emu, dtype, B, Cin, Cout, H, W, extras):
     xf = torch.zeros(B, Cin, Ho, Wo, device='cuda', requires_grad=True)
     (dx_ref, ) = torch.autograd.grad(torch.nn.functional.conv2d(xf, w.float(), None, padding=1), xf, dy.float())
     _check('conv3x3 backward-data', dx, dx_ref, dtype)
+    from mixofshow.hip import lib as _lib
+    if _lib.load().mos_conv3x3_nhwc_workspace_bytes(B, Ho, Wo, Cin, Cout) > 0:
+        # this shape took the split-K form: the unsplit kernel must agree to the rounding of the fp32 summation order
+        import os
+        os.environ['MOS_CONV_SPLITK'] = '0'
+        try:
+            assert _lib.load().mos_conv3x3_nhwc_workspace_bytes(B, Ho, Wo, Cin, Cout) == 0
+            y1 = ops.conv3x3_nhwc(x, w_fwd, bias, tb, res, up)
+        finally:
+            os.environ.pop('MOS_CONV_SPLITK')
+        _check(f'conv3x3 split-K vs unsplit [{B}x{Cin}->{Cout}x{H}x{W} {extras}]', y, y1, dtype, ulps=1.0)
+        print(f'[parity] conv3x3 split-K [{B}x{Cin}->{Cout}x{Ho}x{Wo}] bit-identical to the unsplit kernel: {torch.equal(y, y1)}')

@@ -121,6 +121,67 @@ def conv_reference(shapes, dtype, iters, ref=True):
         print(f"{f'B{B} {Cin}->{Cout} {H}x{W}':34s} {t_mf:9.1f} {t_rf:11.1f} {t_mb:9.1f} {t_rb:11.1f} {fl / t_mf / 1e6:9.1f}")
 
 
+def _timed(fn, iters):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def ff_reference(levels, dtype, iters):
+    """Feed-forward of the transformer block (rows x C -> 8C -GEGLU-> 4C -> C, + residual) per UNet level: torch's GEMMs
+    (hipBLASLt) + geglu kernel + add, against the library's GEMM with the GEGLU / residual epilogues."""
+    print(f"{'FF rows C':18s} {'FF1 blas':>9s} {'+geglu':>8s} {'FF1 mos+geglu epi':>18s} {'FF2 blas':>9s} {'+add':>7s} {'FF2 mos+res epi':>16s} {'FF2 mos':>8s}")
+    with torch.no_grad():
+        for rows, C in levels:
+            x = torch.randn(rows, C, device='cuda', dtype=dtype)
+            W1 = torch.randn(8 * C, C, device='cuda', dtype=dtype) / math.sqrt(C)
+            b1 = torch.randn(8 * C, device='cuda', dtype=dtype) * 0.1
+            W2 = torch.randn(C, 4 * C, device='cuda', dtype=dtype) / math.sqrt(4 * C)
+            b2 = torch.randn(C, device='cuda', dtype=dtype) * 0.1
+            res = torch.randn(rows, C, device='cuda', dtype=dtype)
+            W1i, b1i = ops.geglu_interleave(W1, b1.float())
+            b2f = b2.float()
+            h = torch.nn.functional.linear(x, W1, b1)
+            a = ops.geglu_fwd(h)
+            t_f1 = _timed(lambda: torch.nn.functional.linear(x, W1, b1), iters)
+            t_g = _timed(lambda: ops.geglu_fwd(h), iters)
+            t_f1m = _timed(lambda: ops.linear_fwd_ex(x, W1i, None, None, b1i, geglu=True), iters)
+            t_f2 = _timed(lambda: torch.nn.functional.linear(a, W2, b2), iters)
+            y = torch.nn.functional.linear(a, W2, b2)
+            t_add = _timed(lambda: y + res, iters)
+            t_f2m = _timed(lambda: ops.linear_fwd_ex(a, W2, None, None, b2f, residual=res), iters)
+            t_f2p = _timed(lambda: ops.linear_fwd(a, W2, None, None, b2f), iters)
+            print(f"{f'{rows} {C}':18s} {t_f1:9.1f} {t_g:8.1f} {t_f1m:18.1f} {t_f2:9.1f} {t_add:7.1f} {t_f2m:16.1f} {t_f2p:8.1f}")
+
+
+def gn_reference(shapes, dtype, iters):
+    """GroupNorm(+SiLU) on channels_last maps: slice kernels (MOS_GN_FUSED=0: 3 launches) vs the one-launch column kernel
+    (=1 register-resident only, =2 also streaming), forward and backward, us per call."""
+    print(f"{'GroupNorm B C HxW':24s} {'fwd m0':>8s} {'fwd m1':>8s} {'fwd m2':>8s} {'bwd m0':>8s} {'bwd m1':>8s} {'bwd m2':>8s} {'MB':>7s}")
+    for B, C, H, W in shapes:
+        x = torch.randn(B, C, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(B, C, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
+        gamma, beta = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+        _, stats = ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, True)
+        row = []
+        for kind in ('fwd', 'bwd'):
+            for mode in ('0', '1', '2'):
+                os.environ['MOS_GN_FUSED'] = mode
+                if kind == 'fwd':
+                    row.append(_timed(lambda: ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, True), iters))
+                else:
+                    row.append(_timed(lambda: ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, True), iters))
+        os.environ.pop('MOS_GN_FUSED', None)
+        print(f"{f'B{B} C{C} {H}x{W}':24s} " + ' '.join(f'{v:8.1f}' for v in row) + f' {x.numel() * 2 / 1e6:7.2f}')
+
+
 def region_case(fh, fw, d, dtype, iters):
     B, H = 2, 8
     C = H * d
@@ -182,8 +243,18 @@ def main():
         conv_reference([(4, 320, 320, 64, 64), (4, 640, 320, 64, 64), (4, 960, 320, 64, 64), (4, 640, 640, 32, 32),
                         (4, 1280, 640, 32, 32), (4, 1920, 640, 32, 32), (4, 1280, 1280, 16, 16), (4, 2560, 1280, 16, 16),
                         (4, 1280, 1280, 8, 8), (4, 2560, 1280, 8, 8), (4, 128, 128, 512, 512), (4, 256, 256, 256, 256),
-                        (4, 512, 512, 128, 128), (4, 512, 512, 64, 64), (2, 320, 320, 64, 96), (2, 1280, 1280, 16, 24)],
+                        (4, 512, 512, 128, 128), (4, 512, 512, 64, 64), (2, 320, 320, 64, 96), (2, 1280, 1280, 16, 24),
+                        (2, 640, 640, 32, 48), (2, 1920, 640, 32, 48), (2, 2560, 1280, 16, 24), (2, 1280, 1280, 8, 12),
+                        (2, 2560, 1280, 8, 12)],
                        dt, args.iters, ref=bool(args.ref))
+    if 'ff' in only:
+        ff_reference([(12288, 320), (3072, 640), (768, 1280), (192, 1280), (16384, 320), (4096, 640), (1024, 1280), (256, 1280)],
+                     dt, args.iters)
+    if 'gn' in only:
+        gn_reference([(2, 320, 64, 96), (2, 640, 64, 96), (2, 960, 64, 96), (2, 640, 32, 48), (2, 1280, 32, 48), (2, 1920, 32, 48),
+                      (2, 960, 32, 48), (2, 1280, 16, 24), (2, 2560, 16, 24), (2, 1920, 16, 24), (2, 1280, 8, 12),
+                      (2, 2560, 8, 12), (4, 320, 64, 64), (4, 960, 64, 64), (4, 640, 32, 32), (4, 1920, 32, 32),
+                      (4, 1280, 16, 16), (4, 2560, 8, 8)], dt, args.iters)
     if (want('gemm') or want('blas')) and args.ref:
         blas_reference([(16384, 320, 320), (16384, 960, 320), (4096, 640, 640), (4096, 1920, 640), (1024, 1280, 1280),
                         (1024, 3840, 1280), (256, 1280, 1280), (4928, 768, 768), (4928, 2304, 768), (12288, 320, 320),
