@@ -114,6 +114,17 @@ class TrainEngine:
                 self.scaler.scale(loss).backward()
             return loss.detach()
 
+        self._graph, self._static_loss = self._capture(fwd_bwd, warmup)
+        self._finals_graph.freeze()
+        F_hip.freeze_lora_packs(True)          # the graph holds the descriptor table's address and group count
+        return self
+
+    @staticmethod
+    def _capture(fwd_bwd, warmup):
+        """Warm up on a side stream, then capture `fwd_bwd()` into a hipGraph. Returns (graph with .replay(), the static
+        tensor the captured call returned). Kept apart from enable_graph so that the host logic around a replay (static input
+        copies, eager all-reduce, GradScaler bookkeeping across ranks) can be exercised on the CPU with a stand-in."""
+        from mixofshow.hip import functional as F_hip
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -123,11 +134,8 @@ class TrainEngine:
         F_hip.invalidate_lora_packs()          # the one-launch repack of all LoRA operands must be part of the graph
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self._static_loss = fwd_bwd()
-        self._graph = graph
-        self._finals_graph.freeze()
-        F_hip.freeze_lora_packs(True)          # the graph holds the descriptor table's address and group count
-        return self
+            static_loss = fwd_bwd()
+        return graph, static_loss
 
     def disable_graph(self):
         """Back to the eager step (also releases the LoRA descriptor table)."""

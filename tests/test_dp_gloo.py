@@ -156,3 +156,77 @@ def test_two_rank_train_cli(tmp_path):
     torch.testing.assert_close(r0['params'], r1['params'], rtol=0, atol=0)
     models = tmp_path / 'experiments' / 'cli_cpu' / 'models'
     assert sorted(os.listdir(models)) == ['edlora_model-latest.pth']
+
+
+# ---- graph replay + eager all-reduce + GradScaler found_inf agreement across ranks ----------------------
+class _FakeGraph:
+    """Stand-in for torch.cuda.CUDAGraph on the CPU: replay() re-runs the captured closure and refreshes the static output
+    in place, which is what a replay does to the captured kernels' output buffers."""
+
+    def __init__(self, fn, out):
+        self.fn, self.out, self.replays = fn, out, 0
+
+    def replay(self):
+        self.out.copy_(self.fn())
+        self.replays += 1
+
+
+def _graph_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DEBUG_CLR_GRAPH_PACKET_CAPTURE='0')
+    torch.set_num_threads(2)
+    _setup_emulation()
+    from mixofshow.parallel import dp
+    from mixofshow.pipelines.train_loop import TrainEngine
+    dp.init_distributed(backend='gloo')
+    from tests.test_host_cpu import _trainer
+    tr = _trainer()
+    opt = dict(optim_g=dict(type='AdamW', lr=1e-3, weight_decay=0.0, betas=[0.9, 0.999]), emb_norm_threshold=1e9)
+    engine = TrainEngine(tr, opt, total_iter=100, mixed_precision='no')
+    engine.base_lrs = [1e-3 for _ in engine.base_lrs]
+    engine.scaler = torch.amp.GradScaler('cpu', init_scale=1024.0, enabled=True)     # fp16 training's loss scaling, on the CPU
+
+    def fake_capture(fwd_bwd, warmup):
+        for _ in range(warmup):
+            fwd_bwd()
+        out = fwd_bwd().clone()
+        return _FakeGraph(fwd_bwd, out), out
+
+    engine._capture = fake_capture
+    engine.enable_graph(_rank_batch(rank), warmup=1)
+    assert isinstance(engine._graph, _FakeGraph) and engine._finals_graph is not None
+    p0 = torch.cat([p.detach().reshape(-1) for p in tr.trainable_parameters()]).clone()
+    rec = dict(scales=[], params=[], losses=[], found=[])
+    for step in range(4):
+        b = _rank_batch(rank)
+        if step == 1 and rank == 1:
+            b['latents'] = b['latents'].clone()
+            b['latents'][0, 0, 0, 0] = float('inf')          # ONE rank overflows in this step
+        out = engine.step(b)
+        rec['losses'].append(float(out['loss']))
+        rec['scales'].append(float(engine.scaler.get_scale()))
+        rec['params'].append(torch.cat([p.detach().reshape(-1) for p in tr.trainable_parameters()]).clone())
+    torch.save(dict(p0=p0, replays=engine._graph.replays, steps=engine.global_step, **rec), os.path.join(out_dir, f'g_rank{rank}.pt'))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_graph_replay_allreduce_and_found_inf_agree_across_ranks(tmp_path, emulated_hip):
+    """TrainEngine._graph_step on two gloo ranks (the replay itself emulated: the captured closure re-run): static-input copies,
+    replay, EAGER all-reduce of the bucket, GradScaler unscale / found_inf / update, AdamW. An overflow on ONE rank must make
+    BOTH ranks skip that update (the bucket is reduced before the scaler looks at it), halve BOTH loss scales, and leave the
+    ranks in lock-step afterwards (reference: accelerate's GradScaler under DDP, train_edlora.py:34,70,128)."""
+    world, port = 2, 35500 + (os.getpid() % 2000)
+    mp.spawn(_graph_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / 'g_rank0.pt'), torch.load(tmp_path / 'g_rank1.pt')
+    assert r0['replays'] == r1['replays'] == 4 and r0['steps'] == r1['steps'] == 4
+    assert r0['scales'] == r1['scales'] == [1024.0, 512.0, 512.0, 512.0]      # the overflow of rank 1 halves BOTH scales
+    for k in range(4):
+        torch.testing.assert_close(r0['params'][k], r1['params'][k], rtol=0, atol=0)     # lock-step, every step
+    assert not torch.equal(r0['params'][0], r0['p0'])                          # step 0 updated
+    assert torch.equal(r0['params'][1], r0['params'][0])                       # step 1 skipped on both ranks
+    assert not torch.equal(r0['params'][2], r0['params'][1])                   # and training goes on
+    assert all(torch.isfinite(p).all() for p in r0['params'])
+    assert r1['losses'][1] != r1['losses'][1] or abs(r1['losses'][1]) == float('inf')   # rank 1 saw the overflow
+    assert abs(r0['losses'][1]) < float('inf')

@@ -61,3 +61,61 @@ def test_two_rank_rccl_allreduce_of_the_gradient_bucket(tmp_path):
     torch.testing.assert_close(r0['reduced'], r1['reduced'], rtol=0, atol=0)
     torch.testing.assert_close(r0['reduced'], (r0['local'] + r1['local']) / 2, rtol=1e-6, atol=1e-9)
     torch.testing.assert_close(r0['params'], r1['params'], rtol=0, atol=0)        # lock-step after fused AdamW
+
+
+def _graph_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, ROOT)
+    import mos_path  # noqa: F401
+    from bench import TRAIN_OPT, build_trainer, synthetic_batch
+    from mixofshow.parallel import dp
+    from mixofshow.pipelines.train_loop import TrainEngine
+    r, w, local = dp.init_distributed()
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    tr = build_trainer('small', dev)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+            l.lora_up.weight.normal_(0, 0.02)
+    opt = dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g']), emb_norm_threshold=1e9)
+    engine = TrainEngine(tr, opt, total_iter=100, mixed_precision='fp16')
+
+    def batch(step):
+        g = torch.Generator().manual_seed(10 + rank + 7 * step)
+        b = synthetic_batch(2, 256, dev, 100 + rank + 7 * step)
+        b.update(latents=torch.randn(2, 4, 32, 32, generator=g).to(dev), noise=torch.randn(2, 4, 32, 32, generator=g).to(dev),
+                 timesteps=torch.randint(0, 1000, (2, ), generator=g).to(dev))
+        b['images'] = None
+        return b
+
+    engine.enable_graph(batch(0))                           # hipGraph replay, then the EAGER RCCL all-reduce after it
+    rec = dict(scales=[], params=[])
+    for step in range(4):
+        b = batch(step)
+        if step == 1 and rank == 1:
+            b['latents'][0, 0, 0, 0] = float('inf')        # one rank overflows
+        engine.step(b)
+        torch.cuda.synchronize()
+        rec['scales'].append(float(engine.scaler.get_scale()))
+        rec['params'].append(torch.cat([p.detach().reshape(-1) for p in tr.trainable_parameters()]).cpu())
+    torch.save(rec, os.path.join(out_dir, f'g_rank{rank}.pt'))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_rccl_graph_replay_then_allreduce_and_found_inf(tmp_path):
+    """The interaction most likely to break the first time RCCL runs: a hipGraph replay followed by an
+    eager RCCL all-reduce on the same stream, GradScaler's found_inf agreeing across ranks when ONE rank overflows. Same
+    assertions as tests/test_dp_gloo.py::test_graph_replay_allreduce_and_found_inf_agree_across_ranks."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (RCCL over xGMI); the host logic is covered with gloo on CPU in tests/test_dp_gloo.py')
+    world, port = 2, 31700 + (os.getpid() % 2000)
+    mp.spawn(_graph_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / 'g_rank0.pt'), torch.load(tmp_path / 'g_rank1.pt')
+    assert r0['scales'] == r1['scales'] and r0['scales'][1] == r0['scales'][0] / 2
+    for k in range(4):
+        torch.testing.assert_close(r0['params'][k], r1['params'][k], rtol=0, atol=0)
+    assert torch.equal(r0['params'][1], r0['params'][0]) and not torch.equal(r0['params'][2], r0['params'][1])
