@@ -467,6 +467,10 @@ def lora_linear(x, W16, Wt16, bias32, sites, residual=None):
     for down, up, alpha in sites:
         params += [down, up]
         alphas.append(float(alpha))
+    ranks = sum(down.shape[0] for down, _, _ in sites)
+    if ranks > MAX_PACKED_RANK:
+        raise ValueError(f'LoRA rank {ranks} (summed over {len(sites)} fused site(s)) is not supported by the fused HIP path: the '
+                         f'rank dimension is one {MAX_PACKED_RANK}-wide MFMA operand (rank <= {MAX_PACKED_RANK}); see INTEGRATION.md')
     return _LoRALinear.apply(x, W16, Wt16, bias32, tuple(alphas), residual, *params)
 
 

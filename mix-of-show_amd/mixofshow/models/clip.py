@@ -51,9 +51,12 @@ class CLIPAttention(nn.Module):
 
     def forward(self, x):
         b, s, c = x.shape
-        if all(getattr(m, '_mos_lora', None) is not None for m in (self.q_proj, self.k_proj, self.v_proj)):
+        from mixofshow.models.attention import _sites
+        if all(getattr(m, '_mos_lora', None) is not None for m in (self.q_proj, self.k_proj, self.v_proj)) and \
+                _sites(self.q_proj, self.k_proj, self.v_proj) is not None:
             # all three projections carry ED-LoRA branches (where: CLIPAttention): one fused [Wq;Wk;Wv] GEMM with
-            # the three rank-r updates appended to the contraction instead of 3 x (GEMM + down + up) launches
+            # the three rank-r updates appended to the contraction instead of 3 x (GEMM + down + up) launches. (Ranks
+            # whose sum exceeds the packed rank-16 operand, e.g. 3 x 8: one GEMM per projection below.)
             from mixofshow.hip import functional as F_hip
             from mixofshow.models.attention import project
             if getattr(self, '_mos_cache', None) is None:

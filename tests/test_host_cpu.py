@@ -765,3 +765,65 @@ def test_sampling_hipgraph_default_and_hook_guard(monkeypatch):
     h.remove()
     assert not hg.has_forward_hooks(net)
     assert not hg.graphs_usable('cpu')
+
+
+# ---- the other LoRA placements of the reference (trainer_edlora.py:97-136) ------------------------------
+def _trainer_where(te_where, unet_where, rank=4):
+    from mixofshow.pipelines.trainer_edlora import EDLoRATrainer
+    cfg = dict(text_embedding=dict(enable_tuning=True, lr=1e-3),
+               text_encoder=dict(enable_tuning=True, lora_cfg=dict(rank=rank, alpha=1.0, where=te_where), lr=1e-5),
+               unet=dict(enable_tuning=True, lora_cfg=dict(rank=rank, alpha=0.8, where=unet_where), lr=1e-4))
+    torch.manual_seed(0)
+    tr = EDLoRATrainer('synthetic://tiny', '<potter1>+<potter2>', '<rand-0.013>+man', True, finetune_cfg=cfg,
+                       noise_offset=0.01, attn_reg_weight=0.01, reg_full_identity=False, use_mask_loss=True)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+            l.lora_up.weight.normal_(0, 0.02)
+    return tr
+
+
+@pytest.mark.parametrize('rank', [4, 8])
+def test_lora_on_transformer2dmodel_and_clip_encoder_layer_vs_reference_path(emulated_hip, rank):
+    """`where: Transformer2DModel` puts LoRA on the 1x1 proj_in / proj_out convolutions and on both feed-forward Linears besides
+    the eight attention projections; `where: CLIPEncoderLayer` adds the CLIP MLP. Rank 8 makes the fused q/k/v group
+    (3 x 8 = 24 columns) exceed the packed rank-16 operand: the product falls back to one GEMM per projection. Loss and
+    every gradient against the oracle twin (LoRALinearLayerRef on the same sites)."""
+    tr = _trainer_where('CLIPEncoderLayer', 'Transformer2DModel', rank)
+    names = [l.name for l in tr.unet_lora]
+    assert len(tr.unet_lora) == 4 * 12 and len(tr.text_encoder_lora) == 6
+    assert sum(n.endswith('proj_in') or n.endswith('proj_out') for n in names) == 8
+    assert sum('ff.net.0.proj' in n for n in names) == 4 and sum(n.endswith('ff.net.2') for n in names) == 4
+    assert sum(l.is_conv for l in tr.unet_lora) == 8
+    assert sum('mlp.fc' in l.name for l in tr.text_encoder_lora) == 2
+    b = _batch()
+    loss = tr(**b)
+    loss.backward()
+    twin = trainer_ref.make_reference_twin(tr)
+    loss_ref = trainer_ref.reference_forward(twin, **b)
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 2e-2 * abs(loss_ref.item())
+    got, ref = tr.trainable_parameters(), trainer_ref.twin_parameters(twin)
+    assert len(got) == len(ref) == 1 + 2 * (48 + 6)
+    num = den = 0.0
+    for a, r in zip(got, ref):
+        assert a.grad is not None and a.grad.shape == r.grad.shape, 'every trainable tensor must receive a gradient'
+        num += (a.grad.float() - r.grad).pow(2).sum().item()
+        den += r.grad.pow(2).sum().item()
+    assert (num / den)**0.5 < 5e-2, f'relative grad error {(num / den) ** 0.5}'
+    # the checkpoint carries every site under the reference's key names (App. C)
+    sd = tr.delta_state_dict()
+    assert any(k.endswith('proj_in.lora_down.weight') for k in sd['unet']) and any('ff.net.2.lora_up.weight' in k for k in sd['unet'])
+    assert sd['unet'][next(k for k in sd['unet'] if k.endswith('proj_in.lora_down.weight'))].dim() == 4     # 1x1 conv factors
+
+
+def test_lora_rank_limits_of_the_packed_operand(emulated_hip):
+    """A single site up to rank 16 runs fused; above it the product raises (INTEGRATION.md 'Limits'), it never silently
+    truncates."""
+    tr = _trainer_where('CLIPAttention', 'Transformer2DModel', 16)
+    loss = tr(**_batch())
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in tr.trainable_parameters())
+    tr17 = _trainer_where('CLIPAttention', 'Attention', 17)
+    with pytest.raises(ValueError, match='rank'):
+        tr17(**_batch())
