@@ -248,7 +248,9 @@ def _tuning_switches():
     return dict(conv3x3_min_pixels=F_hip._conv_min_pixels, ring_max_wg=int(os.environ.get('MOS_RING_MAX_WG', -1)),
                 fuse_add_layernorm=bool(F_hip._fuse_add_ln), fuse_groupnorm_skip_grad=bool(F_hip._fuse_gn_res),
                 groupnorm_finalize=os.environ.get('MOS_GN_FINALIZE', '1') != '0',
-                batched_time_projections=os.environ.get('MOS_BATCH_TEMB', '0') != '0')
+                batched_time_projections=os.environ.get('MOS_BATCH_TEMB', '1') != '0',
+                groupnorm_column_kernel=int(os.environ.get('MOS_GN_FUSED', 1)), conv_splitk=os.environ.get('MOS_CONV_SPLITK', '1') != '0',
+                ff_geglu_epilogue=bool(F_hip._ff_geglu), ff2_residual_epilogue=bool(F_hip._ff2_own))
 
 
 def attention_path_aggregate(gflop_per_unit, units, recs, per):

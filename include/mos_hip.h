@@ -114,7 +114,7 @@ int mos_lora_linear_fused_fwd(const void* x, int64_t ldx, const void* W, int64_t
  *   geglu            : W (and bias) hold the GEGLU projection's rows INTERLEAVED in blocks of 16: rows 32q..32q+15 = value rows
  *                      16q..16q+15, rows 32q+16..32q+31 = gate rows 16q..16q+15 (packed once by the caller; the weight is
  *                      frozen). y is [M, N/2] = value * gelu(gate) (exact erf GELU), same arithmetic as the GEMM followed
- *                      by mos_geglu_fwd: the (M, N) pre-activation never goes to HBM. N % 32 == 0.
+ *                      by mos_geglu_fwd: the (M, N) pre-activation never goes to HBM. N % 32 == 0; not combined with residual.
  * A16 / Bp16 NULL: plain GEMM; otherwise the fused LoRA form of mos_lora_linear_fused_fwd (t_out as there). */
 typedef struct {
     const void* residual;     /* [M, Nout] in `dtype`, or NULL */

@@ -52,9 +52,8 @@ __device__ __forceinline__ void wait_vmcnt_then_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// SPLIT (low-resolution levels: 16x16 / 8x8 maps, M = 192 .. 1024 pixels against K = 9 * Cin = 11.5 k .. 23 k): with 60 - 320
-// output tiles the chip is a quarter full and every workgroup walks a 180 - 360 tile K loop, while what bounds the operator is
-// streaming 30 - 59 MB of weights. The K loop is cut into `ksplit` ranges (tap-major, so a range is a few taps of a channel
+// SPLIT (low-resolution levels: 32x32 .. 8x8 maps, M = 192 .. 4096 pixels against K = 9 * Cin = 5.8 k .. 23 k): few output
+// tiles, each walking a 90 - 360 tile K loop, while the operator streams up to 59 MB of weights (see conv_ksplit). The K loop is cut into `ksplit` ranges (tap-major, so a range is a few taps of a channel
 // slab); each workgroup leaves its fp32 partial tile in `partial[z]`, conv_splitk_reduce_kernel sums them in z order
 // (deterministic) and applies the epilogue. All m-tiles of one (n-tile, K range) run on ONE XCD, back to back: its weight
 // slice is fetched into that L2 once.
@@ -285,26 +284,35 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
     st16(reinterpret_cast<T*>(a.Y) + off, from_v8<T>(o));
 }
 
-// split-K plan: only where the 64x64 tiling leaves the chip underfilled and K is deep; aims at ~640 workgroups
+// split-K plan. Measured in round 4 (profiles/r04_kernel_bench_ff_gn_conv.txt): every convolution that the tile heuristic
+// below sends to 64 x 64 tiles runs at 450-490 TFLOP/s whatever its shape -- the L2 -> LDS operand traffic of a 64 x 64 x 64
+// step (16 KB for 0.5 MFLOP: 32 flop/B, x ~14 TB/s of L2) bounds it, not HBM and not the MFMAs. 128 x 128 tiles halve that
+// traffic; the K split restores the workgroup count that the larger tiles give up. Rules: split only where 128 x 128 tiles
+// alone underfill the chip (< 384), aim at ~640 workgroups, keep >= 6 K tiles per workgroup, and keep the fp32 partials
+// (ksplit * M * Cout * 4 B, written and read once) below the weight bytes: ksplit <= 9 * Cin / (2 M).
 inline bool conv_splitk_enabled() {          // read per call: tests and same-box A/Bs flip it inside one process
     const char* e = getenv("MOS_CONV_SPLITK");
     return e == nullptr || atoi(e) != 0;
 }
-inline int conv_ksplit(int M, int Cout, int Cin, int* kt_per) {
-    const int64_t tiles = (int64_t)((M + 63) / 64) * ((Cout + 63) / 64);
+inline int conv_ksplit(int M, int Cout, int Cin, int* kt_per, int* bm) {
     const int nk = 9 * (Cin / 64);
-    if (!conv_splitk_enabled() || tiles > 320 || nk < 36) return 1;
-    int ks = (int)((640 + tiles - 1) / tiles);
+    const int64_t t128 = (int64_t)((M + 127) / 128) * ((Cout + 127) / 128);
+    if (!conv_splitk_enabled() || t128 >= 384 || nk < 36) return 1;
+    *bm = M > 256 ? 128 : 64;
+    const int64_t tiles = (int64_t)((M + *bm - 1) / *bm) * ((Cout + 127) / 128);
+    int64_t ks = (640 + tiles - 1) / tiles;
     if (ks > nk / 6) ks = nk / 6;               // at least 6 K tiles per workgroup
+    if (ks > (int64_t)9 * Cin / (2 * (int64_t)M)) ks = (int64_t)9 * Cin / (2 * (int64_t)M);   // partial bytes <= weight bytes
+    if (ks > 16) ks = 16;
     if (ks < 2) return 1;
-    const int per = (nk + ks - 1) / ks;
+    const int per = (nk + (int)ks - 1) / (int)ks;
     *kt_per = per;
     return (nk + per - 1) / per;
 }
 
-template <typename T, bool UP>
+template <typename T, int BM, bool UP>
 int launch_conv_split(ConvArgs a, hipStream_t st) {
-    constexpr int BM = 64, BN = 64, NS = 3;
+    constexpr int BN = 128, NS = 3;
     const size_t lds = (size_t)NS * (BM + BN) * CBK * sizeof(T);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN, UP, NS, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -348,15 +356,16 @@ inline int ring_max_wg() {
 template <typename T>
 int launch_conv(ConvArgs a, hipStream_t st) {
     char key[112];
-    int kt_per = 0;
-    const int ks = a.partial != nullptr ? conv_ksplit(a.M, a.Cout, a.Cin, &kt_per) : 1;
+    int kt_per = 0, sbm = 128;
+    const int ks = a.partial != nullptr ? conv_ksplit(a.M, a.Cout, a.Cin, &kt_per, &sbm) : 1;
     snprintf(key, sizeof(key), "%s B%d %dx%d Cin%d Cout%d%s%s%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", a.B, a.H, a.Wd,
              a.Cin, a.Cout, a.up ? " up2x" : "", a.tbias ? " +tbias" : "", a.R ? " +res" : "", ks > 1 ? " splitK" : "");
     MosProfScope prof(st, "conv3x3", key, 2.0 * a.M * (double)a.Cout * 9.0 * a.Cin,
                       2.0 * ((double)a.M * a.Cin / (a.up ? 4 : 1) + 9.0 * a.Cin * a.Cout + (double)a.M * a.Cout * (a.R ? 2 : 1)));
     if (ks > 1) {
         a.ksplit = ks; a.kt_per = kt_per;
-        return a.up ? launch_conv_split<T, true>(a, st) : launch_conv_split<T, false>(a, st);
+        if (sbm == 128) return a.up ? launch_conv_split<T, 128, true>(a, st) : launch_conv_split<T, 128, false>(a, st);
+        return a.up ? launch_conv_split<T, 64, true>(a, st) : launch_conv_split<T, 64, false>(a, st);
     }
     int bn = (a.Cout % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
@@ -375,10 +384,10 @@ extern "C" {
 
 int64_t mos_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 8) return 0;
-    int kt_per = 0;
+    int kt_per = 0, bm = 0;
     const int64_t M = (int64_t)B * H * W;
     if (M > (1 << 20)) return 0;
-    const int ks = conv_ksplit((int)M, Cout, Cin, &kt_per);
+    const int ks = conv_ksplit((int)M, Cout, Cin, &kt_per, &bm);
     return ks > 1 ? (int64_t)ks * M * Cout * (int64_t)sizeof(float) : 0;
 }
 

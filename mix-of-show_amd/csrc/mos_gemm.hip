@@ -319,7 +319,6 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
         // chunk (row, oc) of the BM x BN/2 result pairs the value chunk at 32 * (oc / 16) + oc % 16 with the gate chunk 16
         // columns further (same arithmetic as the GEMM followed by geglu_fwd_kernel: half operands, fp32 product, one rounding)
         constexpr int GCH = (BM * (BN / 16) + 255) / 256;
-        const T* Rg = reinterpret_cast<const T*>(a.R);
 #pragma unroll
         for (int i = 0; i < GCH; ++i) {
             const int c = tid + 256 * i;
@@ -330,13 +329,7 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
                 v8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (T)((float)vv[e] * gemm_gelu_f((float)gv[e]));
-                const int64_t off = (int64_t)(m0 + row) * a.ldy + (n0 >> 1) + oc;
-                if (Rg != nullptr) {
-                    const v8 rv = as_v8<T>(ld16(Rg + (int64_t)(m0 + row) * a.ldr + (n0 >> 1) + oc));
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (T)((float)o[e] + (float)rv[e]);
-                }
-                st16(Y + off, from_v8<T>(o));
+                st16(Y + (int64_t)(m0 + row) * a.ldy + (n0 >> 1) + oc, from_v8<T>(o));
             }
         }
         return;
@@ -1022,6 +1015,7 @@ int mos_lora_linear_fwd_ex(const void* x, int64_t ldx, const void* W, int64_t ld
     if (rc) return rc;
     MOS_REQUIRE(!geglu || (N % 32 == 0 && ldy % 8 == 0 && ldy >= nout),
                 "mos_lora_linear_fwd_ex: geglu needs N %% 32 == 0 and ldy %% 8 == 0 (N=%d ldy=%lld)", N, (long long)ldy);
+    MOS_REQUIRE(!(geglu && epi->residual), "mos_lora_linear_fwd_ex: the GEGLU epilogue takes no residual");
     MOS_REQUIRE(epi->residual == nullptr || (epi->ldr % 8 == 0 && epi->ldr >= nout),
                 "mos_lora_linear_fwd_ex: residual row stride %lld (need %% 8 == 0, >= %d)", (long long)epi->ldr, nout);
     hipStream_t st = (hipStream_t)stream;

@@ -475,9 +475,16 @@ def lora_linear(x, W16, Wt16, bias32, sites, residual=None):
 
 
 # ---- feed-forward of the transformer block (diffusers FeedForward: GEGLU projection, Linear) on the library's GEMM ---------
-# A/B switches: MOS_FF_GEGLU=0 keeps FF1 on torch's GEMM + the geglu kernel also when sampling; MOS_FF2_OWN=0 keeps FF2 on
-# torch's GEMM (hipBLASLt) + a separate add; MOS_GEMM_RESIDUAL=0 keeps the 1x1 proj_out's residual a separate add.
-_ff_geglu = _os.environ.get('MOS_FF_GEGLU', '1') != '0'
+# Switches, defaults from the same-box measurements of round 4 (profiles/r04_kernel_bench_ff_gn_conv.txt,
+# profiles/r04_ab_same_box_{train,regional}_switches.txt):
+#   MOS_FF_GEGLU (default 0): FF1 as the library's GEMM with the GEGLU epilogue when sampling. Measured: equal to hipBLASLt +
+#     geglu kernel at level 0 (51.5 vs 50.6 us), slower at the wide levels (N = 5120 / 10240: 38 vs 33, 52 vs 34 us; regional
+#     sample 508.8 vs 504.8 ms) -- kept as an option, off.
+#   MOS_FF2_OWN (default 1): FF2 as the library's GEMM with the residual add in its epilogue where it wins: K = 4C <= 1280
+#     (level 0: 19.4 vs 24.4 us sampling, 24.8 vs 25.7 training) and K <= 2560 up to 3072 rows (22.9 vs 25.7 us); the wide
+#     levels stay on hipBLASLt + add (33.5 vs 27.3 us at 768 x 5120 -> 1280).
+#   MOS_GEMM_RESIDUAL (default 1): the 1x1 proj_out's residual in the GEMM epilogue (bit-identical to GEMM + add).
+_ff_geglu = _os.environ.get('MOS_FF_GEGLU', '0') != '0'
 _ff2_own = _os.environ.get('MOS_FF2_OWN', '1') != '0'
 _gemm_residual = _os.environ.get('MOS_GEMM_RESIDUAL', '1') != '0'
 
@@ -502,7 +509,9 @@ def linear_residual(linear, x, residual):
     """`linear(x) + residual` (transformer block: ff.net[2](h) + hidden_states) as ONE GEMM with the add in its epilogue, on the
     HIP path (frozen plain Linear, half activations, K and N multiples of 8); anything else: the two plain ops."""
     dt = _half_path(x) if (_ff2_own and _plain_linear(linear)) else None
-    if dt is None or linear.in_features % 8 or linear.out_features % 8 or residual.shape[:-1] != x.shape[:-1]:
+    K, rows = linear.in_features, x.numel() // max(1, x.shape[-1])
+    wins = K <= 1280 or (K <= 2560 and rows <= 3072)         # measured crossover against hipBLASLt + add, see above
+    if dt is None or not wins or K % 8 or linear.out_features % 8 or residual.shape[:-1] != x.shape[:-1]:
         return linear(x) + residual
     cache = linear.__dict__.get('_mos_cache')
     if cache is None:
@@ -960,10 +969,11 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
     need_bwd = torch.is_grad_enabled() and (x.requires_grad or (tbias is not None and tbias.requires_grad)
                                             or (residual is not None and residual.requires_grad))
     if ok:
-        # measured against MIOpen on MI355X (profiles/r02_kernel_bench_conv_vs_miopen.txt for MIOpen,
-        # profiles/r02_dma_ring_ab.txt for this kernel): the implicit-GEMM kernel wins from 4 k output pixels up (64x64 maps
-        # at batch 4: 49 vs 112 us; 32x32: 63 vs 79 us; the VAE's 128..512 px stages: 0.37-0.46 vs 0.67-0.81 ms) and still
-        # loses below (16x16: 89 vs 80 us, 8x8: 73 vs 40 us); whole-step A/B: 4096 -> 44.85, 1024 -> 45.0, 256 -> 46.0 ms
+        # measured against MIOpen on MI355X (profiles/r04_kernel_bench_ff_gn_conv.txt): with the split-K form of the
+        # low-resolution levels the implicit-GEMM kernel wins at every UNet level (batch 4: 64x64 48 vs 112 us, 32x32 62 vs 77,
+        # 16x16 68 vs 77, 8x8 26 vs 38; 512x768 sample: 32x48 50 vs 60, 16x24 50 vs 58, 8x12 23 vs 34 us) and takes the
+        # time-embedding / residual adds with it; whole-step A/B of the dispatch threshold (MOS_CONV3X3_MIN_PIXELS, pixels below
+        # which MIOpen is used): train 4096 -> 38.69, 0 -> 38.13 ms; regional sample 4096 -> 508.8, 3072 -> 500.2, 0 -> 475.0 ms
         pixels = x.shape[0] * x.shape[2] * x.shape[3] * (4 if upsample else 1)
         ok = pixels >= _conv_min_pixels and (not need_bwd or conv.out_channels % 64 == 0)
     if not ok:
@@ -986,7 +996,7 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
 
 _conv_enabled = _os.environ.get('MOS_CONV3X3', '1') != '0'
 _conv1x1_enabled = _os.environ.get('MOS_CONV1X1', '1') != '0'
-_conv_min_pixels = int(_os.environ.get('MOS_CONV3X3_MIN_PIXELS', 4096))
+_conv_min_pixels = int(_os.environ.get('MOS_CONV3X3_MIN_PIXELS', 0))
 
 
 def set_conv3x3_enabled(flag):

@@ -69,9 +69,10 @@ def _act_forget():
     _act_memo[:] = [None, None, None]
 
 
-# A/B switch, default off until measured on the device: project the time embedding for ALL ResNet blocks of a UNet call with one
-# `baddbmm` per output width instead of one tiny GEMM per block (M = batch: 22 launches of ~8.5 us in SD-1.5)
-_batch_time_proj = os.environ.get('MOS_BATCH_TEMB', '0') != '0'
+# Project the time embedding for ALL ResNet blocks of a UNet call with one `baddbmm` per output width instead of one tiny GEMM
+# per block (M = batch: 22 launches of ~8.5 us in SD-1.5). Same-box A/B (profiles/r04_ab_same_box_*_switches.txt): training step
+# 38.69 -> 38.41 ms, 512x768 regional sample 508.8 -> 501.9 ms. MOS_BATCH_TEMB=0: the per-block projections.
+_batch_time_proj = os.environ.get('MOS_BATCH_TEMB', '1') != '0'
 
 
 class _TimeProjections:

@@ -60,6 +60,7 @@ def linear_fwd_ex(x, W, A16=None, Bp16=None, bias=None, residual=None, geglu=Fal
         t = (x.float() @ A16.float().t()).to(x.dtype)
     y = linear_fwd(x, W, t, Bp16, bias)
     if geglu:
+        assert residual is None, 'the GEGLU epilogue takes no residual'
         M, N = y.shape
         blk = y.view(M, N // 32, 2, 16).float()
         y = (blk[:, :, 0] * torch.nn.functional.gelu(blk[:, :, 1])).reshape(M, N // 2).to(x.dtype)

@@ -321,9 +321,9 @@ def test_geglu_interleave_and_epilogue_emulation_equal_projection_then_geglu():
     got, _ = emu_ops.linear_fwd_ex(x, Wi, None, None, bi, geglu=True)
     # (the CPU BLAS blocks the permuted weight differently: last-place differences of the fp32 GEMM before the rounding)
     assert (got.float() - want.float()).abs().max() <= 2 ** -9 * want.float().abs().max()
-    r = torch.randn(24, 128, generator=g).half()
-    got_r, _ = emu_ops.linear_fwd_ex(x, Wi, None, None, bi, residual=r, geglu=True)
-    assert torch.equal(got_r, (got.float() + r.float()).half())
+    r = torch.randn(24, 256, generator=g).half()
+    got_r, _ = emu_ops.linear_fwd_ex(x, W, None, None, b, residual=r)
+    assert torch.equal(got_r, (h.float() + r.float()).half())
 
 
 @pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
