@@ -22,6 +22,7 @@
 //   * grid: blockIdx.x = head + H*(q_block + n_q_blocks*batch): blocks land on XCD (id % 8) = head,
 //     so all query blocks that re-read one head's K/V share one XCD's L2.
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include "mos_common.h"
 
@@ -469,6 +470,207 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
                 }
         }
     }
+}
+
+// ---- forward, software-pipelined (round 4) -------------------------------------------------------------------------------
+// Why (profiles/r03_attention_ablation.txt, r03_microbench_mfma_*.txt): at d = 40 the softmax VALU work of a 64-key tile
+// (32 fma + 32 v_exp + 16 cvt + 16 max3 per lane per 32 queries: ~700 SIMD cycles) costs more than its 14 MFMAs (448 cycles),
+// and in attn_fwd_kernel the two run strictly one after the other -- the matrix pipe idles through the softmax, the VALU through
+// the MFMAs; a second wave on the SIMD does not fill either gap (measured: MFMA and VALU of DIFFERENT waves serialise). Only
+// independent VALU issued by the SAME wave behind an MFMA runs in its shadow. So this kernel
+//   * computes S(j+1) = K(j+1).Q^T while it exponentiates S(j): the two are independent, one basic block;
+//   * keeps that block free of branches: the running maximum is a REFERENCE m_ref that only moves when a tile's maximum
+//     exceeds it by more than 2^LAZY_T (in the exp2 domain); p = exp2(c s - c m_ref) <= 2^LAZY_T fits the half P operand and
+//     the fp32 accumulators; the (rare) move rescales O^T in a cold block at the END of a step, using the maximum of S(j+1)
+//     that this step computed anyway -- no per-tile alpha, no per-tile vote in the hot block;
+//   * row sums from the ones row of the V^T padding (as attn_fwd_kernel), K two tiles ahead in 2 buffers, V^T in 3 buffers:
+//     one barrier per tile;
+//   * tells the scheduler the interleave it should build (sched_group_barrier: 1 MFMA, then a few VALU / TRANS, repeated).
+// 32 queries per wave, 128 per workgroup; Nkv % 64 == 0, no probability columns, no causal mask (the UNet's self-attention:
+// 4096 / 1024 / 6144 / 1536 keys); everything else takes attn_fwd_kernel. MOS_ATTN_PIPE=0 disables it.
+constexpr float LAZY_T = 8.0f;
+
+template <typename T, int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
+    typedef typename MT<T>::v8 v8;
+    constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
+    constexpr int KT = HD<D>::ROW_TILE_ELEMS, VT = HD<D>::TR_TILE_ELEMS;
+    static_assert(HD<D>::DV > D, "needs a spare V^T row for the row sums");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Ks_ = reinterpret_cast<T*>(smem_raw);        // [2] K tiles
+    T* Vt_ = Ks_ + 2 * KT;                          // [3] V^T tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H;
+    const int rest = blockIdx.x / a.H;
+    const int qb = rest % a.nqb, b = rest / a.nqb;
+    const int q0 = qb * 128 + wave * 32;
+
+    zero_row_pads<T, D>(Ks_, tid); zero_row_pads<T, D>(Ks_ + KT, tid);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) zero_tr_pads<T, D>(Vt_ + i * VT, tid);
+    __syncthreads();
+    if (tid < KV_TILE) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) Vt_[i * VT + D * TS + tid] = (T)1.0f;       // ones row: O^T row D = running row sum
+    }
+    const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
+    const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * D;
+    const T* vp = (const T*)a.v + (int64_t)b * a.v_bs + h * D;
+    T* op = (T*)a.o + (int64_t)b * a.o_bs + h * D;
+    const int qi = q0 + l31;
+    v8 qf[KS];
+    load_row_frags<T, D>(qf, qp + (int64_t)min(qi, a.Nq - 1) * a.q_rs, qi < a.Nq, hh);
+    const float c = a.scale * LOG2E;
+
+    RowStage<T, D> kst;
+    TrStage<T, D> vst;
+    kst.init(a.k_rs, tid);
+    vst.init(a.v_rs, tid);
+    const rsrc_t ksrc = make_rsrc(kp, slice_bytes<T, D>(a.Nkv, a.k_rs));
+    const rsrc_t vsrc = make_rsrc(vp, slice_bytes<T, D>(a.Nkv, a.v_rs));
+    const int ktb = KV_TILE * (int)a.k_rs * (int)sizeof(T), vtb = KV_TILE * (int)a.v_rs * (int)sizeof(T);
+    const int nt = a.Nkv / KV_TILE;
+    constexpr int OOB = 0x7FFFFF00;               // past every descriptor: the loads return zeros, no traffic
+
+    // prologue: tiles 0 and 1 resident, S(0) and its maximum
+    kst.load(ksrc, 0);
+    vst.load(vsrc, 0);
+    __syncthreads();                               // (the ones rows / pads above)
+    kst.store(Ks_, tid);
+    vst.store(Vt_, tid);
+    kst.load(ksrc, nt > 1 ? ktb : OOB);
+    vst.load(vsrc, nt > 1 ? vtb : OOB);
+    kst.store(Ks_ + KT, tid);
+    vst.store(Vt_ + VT, tid);
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    auto scores = [&](const T* Ks, f32x16 (&s)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v8 af = as_v8<T>(ld16(Ks + (32 * t + l31) * RS + ks * 16 + hh * 8));
+                s[t] = MT<T>::mfma32(af, qf[ks], s[t]);
+            }
+        }
+    };
+    auto tile_max = [&](const f32x16 (&s)[2]) __attribute__((always_inline)) {
+        float mx = s[0][0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+        return fmaxf(mx, __shfl_xor(mx, 32));
+    };
+
+    f32x16 s_cur[2], s_nxt[2], o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    scores(Ks_, s_cur);
+    float m_ref = tile_max(s_cur);                 // raw score units; every p of tile 0 is <= 1
+    __syncthreads();                               // every wave has read K(0): step 0 stores K(2) over it
+    const float lazy = LAZY_T / c;                 // the reference moves when a tile maximum exceeds it by this much
+
+    int kbuf = 1, vcur = 0, vfree = 2;             // K(j+1) buffer ; V(j) buffer ; V buffer that takes tile j+2
+    for (int j = 0; j < nt; ++j) {
+        const T* Kn = Ks_ + kbuf * KT;
+        const T* Vc = Vt_ + vcur * VT;
+        const bool more2 = j + 2 < nt;
+        kst.load(ksrc, more2 ? (j + 2) * ktb : OOB);
+        vst.load(vsrc, more2 ? (j + 2) * vtb : OOB);
+        // The step as 2 KS + 4 DT slots, one MFMA each: 2 KS slots of S(j+1) = K(j+1) Q^T, then 4 DT slots of O^T += V^T(j) P(j).
+        // Behind every MFMA run the independent VALU / transcendental ops of ~2.3 elements of P(j) = exp2(c S(j) - c m_ref) (an
+        // MFMA shadows about that much: profiles/r03_microbench_mfma_filler.txt), then the maximum of S(j+1) and the LDS stores
+        // of tile j+2. Slots are fenced by empty volatile asms that every value crossing them passes through: the accumulators
+        // (so an MFMA cannot leave its slot), S(j) (so no exponential is hoisted) and the slot's own p values (none is sunk).
+        const float mc = m_ref * c;
+        v8 pf[2][2];
+        float pe[32];
+        float mx_n = 0.f;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto slot = [&](auto slot_c, auto e0_c, auto e1_c) __attribute__((always_inline)) {
+            constexpr int SL = decltype(slot_c)::value, E0 = decltype(e0_c)::value, E1 = decltype(e1_c)::value;
+            if constexpr (SL < 2 * KS) {
+                constexpr int t = SL / KS, ks = SL % KS;     // (the first MFMA of a half starts from the constant 0: no zero fill)
+                s_nxt[t] = MT<T>::mfma32(as_v8<T>(ld16(Kn + (32 * t + l31) * RS + ks * 16 + hh * 8)), qf[ks],
+                                         ks == 0 ? zero16 : s_nxt[t]);
+            } else {
+                constexpr int q = SL - 2 * KS, t = q / (2 * DT), s2 = (q / DT) % 2, dt = q % DT;
+                o[dt] = MT<T>::mfma32(tr_afrag<T>(Vc + (32 * dt + l31) * TS, t, s2, hh), pf[t][s2], o[dt]);
+            }
+#pragma unroll
+            for (int i = E0; i < E1; ++i) pe[i] = __builtin_amdgcn_exp2f(s_cur[i / 16][i % 16] * c - mc);
+            if constexpr (E1 > E0 && E1 % 8 == 0) {       // a chunk of 8 is complete: round it to the MFMA operand
+                constexpr int ch = E1 / 8 - 1;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[ch / 2][ch % 2][e] = (T)pe[ch * 8 + e];
+            }
+            if constexpr (SL == 2 * KS + 4 * DT - 2) {    // S(j+1) is complete since slot 2 KS - 1: its maximum, first half
+                mx_n = s_nxt[0][0];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx_n = fmaxf(mx_n, s_nxt[0][r]);
+                kst.store(Ks_ + (kbuf ^ 1) * KT, tid);    // K(j) was consumed one step ago
+            }
+            if constexpr (SL == 2 * KS + 4 * DT - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx_n = fmaxf(mx_n, s_nxt[1][r]);
+                vst.store(Vt_ + vfree * VT, tid);         // the V buffer of tile j-1
+            }
+            // the fence (no instructions): everything the following slots need passes through it. S(j+1)'s second half joins
+            // once it exists (slot KS on); the running maximum once it exists (the last two slots).
+#define MOS_PIN_COMMON "+v"(s_nxt[0]), "+v"(o[0]), "+v"(o[DT - 1]), "+v"(s_cur[0]), "+v"(s_cur[1])
+            if constexpr (SL < KS) {
+                if constexpr (E1 - E0 == 3) asm volatile("" : MOS_PIN_COMMON, "+v"(pe[E0]), "+v"(pe[E0 + 1]), "+v"(pe[E0 + 2]));
+                else asm volatile("" : MOS_PIN_COMMON, "+v"(pe[E0]), "+v"(pe[E0 + 1]));
+            } else if constexpr (E1 - E0 == 4) {
+                asm volatile("" : MOS_PIN_COMMON, "+v"(s_nxt[1]), "+v"(pe[E0]), "+v"(pe[E0 + 1]), "+v"(pe[E0 + 2]), "+v"(pe[E0 + 3]));
+            } else if constexpr (E1 - E0 == 3) {
+                asm volatile("" : MOS_PIN_COMMON, "+v"(s_nxt[1]), "+v"(pe[E0]), "+v"(pe[E0 + 1]), "+v"(pe[E0 + 2]));
+            } else if constexpr (E1 - E0 == 2) {
+                asm volatile("" : MOS_PIN_COMMON, "+v"(s_nxt[1]), "+v"(pe[E0]), "+v"(pe[E0 + 1]));
+            } else {
+                asm volatile("" : MOS_PIN_COMMON, "+v"(s_nxt[1]), "+v"(mx_n));
+            }
+#undef MOS_PIN_COMMON
+        };
+#define MOS_SLOT(SL, E0, E1) slot(std::integral_constant<int, SL>{}, std::integral_constant<int, E0>{}, std::integral_constant<int, E1>{})
+        static_assert(KS == 3 && DT == 2, "the slot table below is written for d = 40");
+        MOS_SLOT(0, 0, 3);   MOS_SLOT(1, 3, 6);    MOS_SLOT(2, 6, 8);      // S rows 0-31   || P keys 0-7 of the first 32-key half
+        MOS_SLOT(3, 8, 11);  MOS_SLOT(4, 11, 14);  MOS_SLOT(5, 14, 16);    // S rows 32-63  || P keys 8-15
+        MOS_SLOT(6, 16, 18); MOS_SLOT(7, 18, 20);                           // V^T P(0-7)    || P of the second half ...
+        MOS_SLOT(8, 20, 22); MOS_SLOT(9, 22, 24);                           // V^T P(8-15)
+        MOS_SLOT(10, 24, 28); MOS_SLOT(11, 28, 32);                         // V^T P(16-23)
+        MOS_SLOT(12, 32, 32); MOS_SLOT(13, 32, 32);                         // V^T P(24-31)  || max of S(j+1), LDS stores of tile j+2
+#undef MOS_SLOT
+        mx_n = fmaxf(mx_n, __shfl_xor(mx_n, 32));
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) s_cur[t] = s_nxt[t];
+        { const int tmp = vcur; vcur = (vcur + 1 == 3) ? 0 : vcur + 1; vfree = tmp; }
+        kbuf ^= 1;
+        if (j + 1 < nt && __any(mx_n > m_ref + lazy)) {   // cold: the reference moves, O^T (with its row sums) follows (the
+                                                           // phantom tile behind the last one, all zeros, must not move it)
+            const float m_new = fmaxf(m_ref, mx_n);
+            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * c);
+            m_ref = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+    }
+    constexpr int RL = (D % 32) / 8 * 4;
+    static_assert((D % 32) % 8 == 0 && D % 32 != 0, "row D must sit in a register of the hh = 0 lanes");
+    const float lt = __shfl(o[D / 32][RL], l31);
+    const float inv = 1.0f / lt;
+    store_out_rows<T, D>(op + (int64_t)qi * a.o_rs, qi < a.Nq, o, inv, hh);
+    if (a.lse != nullptr && hh == 0 && qi < a.Nq)
+        a.lse[((int64_t)b * a.H + h) * a.Nq + qi] = m_ref * a.scale + __logf(lt);
 }
 
 // ---- regional cross-attention: sum over covering sources of attention / count ---------------------
@@ -1292,6 +1494,17 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     // sequences) they leave CUs idle / unbalanced: fall back to 32 queries per wave when the 256-query grid would
     // not give every CU at least two workgroups.
     const int64_t wg_big = (int64_t)s->H * s->B * ((s->Nq + 4 * QW - 1) / (4 * QW));
+    if constexpr (D == 40) {
+        const char* pe_ = getenv("MOS_ATTN_PIPE");            // read per call: tests and same-box A/Bs flip it in one process
+        const bool pipe = pe_ == nullptr || atoi(pe_) != 0;
+        if (pipe && np == 0 && !s->causal && s->Nkv % KV_TILE == 0 && s->Nkv >= 2 * KV_TILE) {
+            const AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 128);
+            const size_t plds = (2 * HD<D>::ROW_TILE_ELEMS + 3 * HD<D>::TR_TILE_ELEMS) * sizeof(T);
+            set_lds(&attn_fwd_pipe_kernel<T, D>, plds);
+            hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, D>), dim3((unsigned)(a.H * a.nqb * a.B)), dim3(256), plds, st, a);
+            return mos_check_launch("attn_fwd_pipe");
+        }
+    }
     if (QW == 64 && wg_big < 512) {
         launch_fwd_qw<T, D, 32>(make_args(q, k, v, o, lse, tok, np, pcols, s, 128), np, lds, st);
     } else {

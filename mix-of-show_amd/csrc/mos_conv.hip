@@ -284,35 +284,49 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
     st16(reinterpret_cast<T*>(a.Y) + off, from_v8<T>(o));
 }
 
-// split-K plan. Measured in round 4 (profiles/r04_kernel_bench_ff_gn_conv.txt): every convolution that the tile heuristic
-// below sends to 64 x 64 tiles runs at 450-490 TFLOP/s whatever its shape -- the L2 -> LDS operand traffic of a 64 x 64 x 64
-// step (16 KB for 0.5 MFLOP: 32 flop/B, x ~14 TB/s of L2) bounds it, not HBM and not the MFMAs. 128 x 128 tiles halve that
-// traffic; the K split restores the workgroup count that the larger tiles give up. Rules: split only where 128 x 128 tiles
-// alone underfill the chip (< 384), aim at ~640 workgroups, keep >= 6 K tiles per workgroup, and keep the fp32 partials
-// (ksplit * M * Cout * 4 B, written and read once) below the weight bytes: ksplit <= 9 * Cin / (2 M).
+// split-K plan. Two tilings were measured on the low-resolution levels (profiles/r04_kernel_bench_ff_gn_conv.txt against
+// profiles/r04_kernel_bench_conv_splitk_128wide_tiles.txt, MIOpen in the same tables):
+//   * 64 x 64 tiles (3 workgroups per CU), split where that tiling alone gives <= 320 tiles, ~640 workgroups, >= 6 K tiles each:
+//     batch-4 16x16 67.7 us, 8x8 25.7 us; 512x768 sample 16x24 49.8 us, 8x12 23.1 us (MIOpen: 77.1 / 38.1 / 57.9 / 34.0);
+//   * 128-row x 128-wide tiles (half the L2 -> LDS operand traffic per flop, one workgroup per CU): 76.8 / 30.0 / 60.7 / 22.9 us,
+//     and 224 vs 150 us where it replaced the unsplit kernel at 32x48 -- occupancy beats operand reuse here.
+// The first is the default; MOS_CONV_SPLIT_TILE=128 selects the second (kept for the A/B).
 inline bool conv_splitk_enabled() {          // read per call: tests and same-box A/Bs flip it inside one process
     const char* e = getenv("MOS_CONV_SPLITK");
     return e == nullptr || atoi(e) != 0;
 }
+inline bool conv_split_wide() {
+    const char* e = getenv("MOS_CONV_SPLIT_TILE");
+    return e != nullptr && atoi(e) == 128;
+}
 inline int conv_ksplit(int M, int Cout, int Cin, int* kt_per, int* bm) {
     const int nk = 9 * (Cin / 64);
-    const int64_t t128 = (int64_t)((M + 127) / 128) * ((Cout + 127) / 128);
-    if (!conv_splitk_enabled() || t128 >= 384 || nk < 36) return 1;
-    *bm = M > 256 ? 128 : 64;
-    const int64_t tiles = (int64_t)((M + *bm - 1) / *bm) * ((Cout + 127) / 128);
-    int64_t ks = (640 + tiles - 1) / tiles;
+    if (!conv_splitk_enabled() || nk < 36) return 1;
+    int64_t ks;
+    if (conv_split_wide()) {
+        const int64_t t128 = (int64_t)((M + 127) / 128) * ((Cout + 127) / 128);
+        if (t128 >= 384) return 1;
+        *bm = M > 256 ? 128 : 64;
+        const int64_t tiles = (int64_t)((M + *bm - 1) / *bm) * ((Cout + 127) / 128);
+        ks = (640 + tiles - 1) / tiles;
+        if (ks > (int64_t)9 * Cin / (2 * (int64_t)M)) ks = (int64_t)9 * Cin / (2 * (int64_t)M);   // partial bytes <= weight bytes
+        if (ks > 16) ks = 16;
+    } else {
+        *bm = 0;                                  // 64 x 64 tiles
+        const int64_t tiles = (int64_t)((M + 63) / 64) * ((Cout + 63) / 64);
+        if (tiles > 320) return 1;
+        ks = (640 + tiles - 1) / tiles;
+    }
     if (ks > nk / 6) ks = nk / 6;               // at least 6 K tiles per workgroup
-    if (ks > (int64_t)9 * Cin / (2 * (int64_t)M)) ks = (int64_t)9 * Cin / (2 * (int64_t)M);   // partial bytes <= weight bytes
-    if (ks > 16) ks = 16;
     if (ks < 2) return 1;
     const int per = (nk + (int)ks - 1) / (int)ks;
     *kt_per = per;
     return (nk + per - 1) / per;
 }
 
-template <typename T, int BM, bool UP>
+template <typename T, int BM, int BN, bool UP>
 int launch_conv_split(ConvArgs a, hipStream_t st) {
-    constexpr int BN = 128, NS = 3;
+    constexpr int NS = 3;
     const size_t lds = (size_t)NS * (BM + BN) * CBK * sizeof(T);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN, UP, NS, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -364,8 +378,9 @@ int launch_conv(ConvArgs a, hipStream_t st) {
                       2.0 * ((double)a.M * a.Cin / (a.up ? 4 : 1) + 9.0 * a.Cin * a.Cout + (double)a.M * a.Cout * (a.R ? 2 : 1)));
     if (ks > 1) {
         a.ksplit = ks; a.kt_per = kt_per;
-        if (sbm == 128) return a.up ? launch_conv_split<T, 128, true>(a, st) : launch_conv_split<T, 128, false>(a, st);
-        return a.up ? launch_conv_split<T, 64, true>(a, st) : launch_conv_split<T, 64, false>(a, st);
+        if (sbm == 128) return a.up ? launch_conv_split<T, 128, 128, true>(a, st) : launch_conv_split<T, 128, 128, false>(a, st);
+        if (sbm == 64) return a.up ? launch_conv_split<T, 64, 128, true>(a, st) : launch_conv_split<T, 64, 128, false>(a, st);
+        return a.up ? launch_conv_split<T, 64, 64, true>(a, st) : launch_conv_split<T, 64, 64, false>(a, st);
     }
     int bn = (a.Cout % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };

@@ -211,17 +211,32 @@ __global__ __launch_bounds__(256) void lsq_grad_mfma_kernel(const double* __rest
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < Cin; k0 += 16) {
-        __syncthreads();
-        for (int e = tid; e < 16 * 64; e += 256) {
+    // the next 16-deep slab is fetched into registers while the MFMAs of the current one run (first version: load -> LDS ->
+    // sync -> MFMA in sequence paid a memory round trip per slab: 160 us at 768 x 768, profiles/r04_lsq_fp64_mfma_vs_valu_first.txt)
+    double wreg[4], greg[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
             const int kk = e & 15, ii = e >> 4;  // W tile: rows i (64) x k (16), k contiguous in memory
             const int gi = i0 + ii, gk = k0 + kk;
-            Ws[kk][ii] = (gi < Cout && gk < Cin) ? W[(int64_t)gi * Cin + gk] : 0.0;
+            wreg[q] = (gi < Cout && gk < Cin) ? W[(int64_t)gi * Cin + gk] : 0.0;
             const int jj = e & 63, k2 = e >> 6;  // G tile: rows k (16) x cols j (64), j contiguous
             const int gj = j0 + jj, gk2 = k0 + k2;
-            Gs[k2][jj] = (gj < Cin && gk2 < Cin) ? G[(int64_t)gk2 * Cin + gj] : 0.0;
+            greg[q] = (gj < Cin && gk2 < Cin) ? G[(int64_t)gk2 * Cin + gj] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < Cin; k0 += 16) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q;
+            Ws[e & 15][e >> 4] = wreg[q];
+            Gs[e >> 6][e & 63] = greg[q];
         }
         __syncthreads();
+        if (k0 + 16 < Cin) fetch(k0 + 16);
 #pragma unroll
         for (int k4 = 0; k4 < 4; ++k4) {
             double af[2], bf[2];

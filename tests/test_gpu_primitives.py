@@ -249,6 +249,35 @@ def test_attention_fwd_bwd(ops, emu, dtype, B, H, Nq, Nkv, d):
     _check('attn_bwd.dv', dv, dv_r, dtype, ulps=6.0)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,Nq,Nkv', [(2, 6144, 6144), (4, 4096, 4096), (1, 200, 256), (1, 128, 128), (2, 1000, 1536)])
+def test_attention_fwd_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch):
+    """attn_fwd_pipe_kernel (d = 40, keys % 64 == 0: software-pipelined, lazily moved softmax reference) against
+    attn_fwd_kernel (MOS_ATTN_PIPE=0) and the fp32 emulation; plus a drifting-score case in which every tile's maximum is
+    far above the previous one (the reference moves at every step) and one in which it falls (it never moves)."""
+    H, d = 8, 40
+    C = H * d
+    g = torch.Generator(device='cpu').manual_seed(31)
+    q = torch.randn(B, Nq, C, generator=g)
+    k = torch.randn(B, Nkv, C, generator=g)
+    v = torch.randn(B, Nkv, C, generator=g)
+    for name, ramp in (('plain', None), ('rising', 1.0), ('falling', -1.0)):
+        kk = k.clone()
+        if ramp is not None:          # q.k grows / falls by ~30 raw units per 64-key tile for the first queries
+            kk += ramp * 0.75 * (torch.arange(Nkv).float() / 64.0).floor()[None, :, None] * q[:, :1, :] / (q[:, :1, :].pow(2).mean(-1, keepdim=True).sqrt())
+        qd, kd, vd = (t.to('cuda', dtype) for t in (q, kk, v))
+        monkeypatch.setenv('MOS_ATTN_PIPE', '1')
+        o1, lse1, _ = ops.attn_fwd(qd, kd, vd, H, d**-0.5)
+        monkeypatch.setenv('MOS_ATTN_PIPE', '0')
+        o0, lse0, _ = ops.attn_fwd(qd, kd, vd, H, d**-0.5)
+        monkeypatch.delenv('MOS_ATTN_PIPE')
+        o_r, lse_r, _ = emu.attn_fwd(qd, kd, vd, H, d**-0.5)
+        _check(f'attn_fwd pipelined[{name} {B}x{Nq}x{Nkv}].o vs emulation', o1, o_r, dtype)
+        _check(f'attn_fwd pipelined[{name}].lse vs emulation', lse1, lse_r, torch.float16, ulps=2.0)
+        _check(f'attn_fwd pipelined[{name}].o vs attn_fwd_kernel', o1, o0, dtype, ulps=2.0)
+        _check(f'attn_fwd pipelined[{name}].lse vs attn_fwd_kernel', lse1, lse0, torch.float16, ulps=1.0)
+
+
 def test_attention_softmax_rescale_branch(ops, emu):
     """Force the online-softmax rescale: one key far above the rest in a LATE kv tile (cdna guide 5.4 rule 26)."""
     B, H, N, d = 1, 8, 512, 40
