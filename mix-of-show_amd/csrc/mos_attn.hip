@@ -583,70 +583,106 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
         const bool more2 = j + 2 < nt;
         kst.load(ksrc, more2 ? (j + 2) * ktb : OOB);
         vst.load(vsrc, more2 ? (j + 2) * vtb : OOB);
-        // The step as 2 KS + 4 DT slots, one MFMA each: 2 KS slots of S(j+1) = K(j+1) Q^T, then 4 DT slots of O^T += V^T(j) P(j).
-        // Behind every MFMA run the independent VALU / transcendental ops of ~2.3 elements of P(j) = exp2(c S(j) - c m_ref) (an
-        // MFMA shadows about that much: profiles/r03_microbench_mfma_filler.txt), then the maximum of S(j+1) and the LDS stores
-        // of tile j+2. Slots are fenced by empty volatile asms that every value crossing them passes through: the accumulators
-        // (so an MFMA cannot leave its slot), S(j) (so no exponential is hoisted) and the slot's own p values (none is sunk).
+        // The step as 14 slots, one MFMA each: 6 of S(j+1) = K(j+1) Q^T (the two 32-row halves alternating: independent chains),
+        // then 8 of O^T += V^T(j) P(j). Behind every MFMA run the independent VALU / transcendental ops of ~2.3 elements of
+        // P(j) = exp2(c S(j) - c m_ref) (an MFMA shadows about that much: profiles/r03_microbench_mfma_filler.txt), then the maximum
+        // of S(j+1) and the LDS stores of tile j+2. Slots are fenced by empty volatile asms that every value crossing them passes
+        // through: the accumulators (an MFMA cannot leave its slot), S(j) (no exponential is hoisted), the slot's own p values (none
+        // is sunk). The A-operand fragments are read a whole stage ahead and ride through the fences too: the first version of
+        // this kernel read each one inside its slot and waited on LDS in front of every MFMA (187 vs 161 us at B4 H8 N4096,
+        // profiles/r04_kernel_bench_attn_pipelined_fwd_on.txt).
         const float mc = m_ref * c;
         v8 pf[2][2];
         float pe[32];
         float mx_n = 0.f;
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        auto slot = [&](auto slot_c, auto e0_c, auto e1_c) __attribute__((always_inline)) {
-            constexpr int SL = decltype(slot_c)::value, E0 = decltype(e0_c)::value, E1 = decltype(e1_c)::value;
-            if constexpr (SL < 2 * KS) {
-                constexpr int t = SL / KS, ks = SL % KS;     // (the first MFMA of a half starts from the constant 0: no zero fill)
-                s_nxt[t] = MT<T>::mfma32(as_v8<T>(ld16(Kn + (32 * t + l31) * RS + ks * 16 + hh * 8)), qf[ks],
-                                         ks == 0 ? zero16 : s_nxt[t]);
-            } else {
-                constexpr int q = SL - 2 * KS, t = q / (2 * DT), s2 = (q / DT) % 2, dt = q % DT;
-                o[dt] = MT<T>::mfma32(tr_afrag<T>(Vc + (32 * dt + l31) * TS, t, s2, hh), pf[t][s2], o[dt]);
-            }
-#pragma unroll
-            for (int i = E0; i < E1; ++i) pe[i] = __builtin_amdgcn_exp2f(s_cur[i / 16][i % 16] * c - mc);
-            if constexpr (E1 > E0 && E1 % 8 == 0) {       // a chunk of 8 is complete: round it to the MFMA operand
-                constexpr int ch = E1 / 8 - 1;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[ch / 2][ch % 2][e] = (T)pe[ch * 8 + e];
-            }
-            if constexpr (SL == 2 * KS + 4 * DT - 2) {    // S(j+1) is complete since slot 2 KS - 1: its maximum, first half
-                mx_n = s_nxt[0][0];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx_n = fmaxf(mx_n, s_nxt[0][r]);
-                kst.store(Ks_ + (kbuf ^ 1) * KT, tid);    // K(j) was consumed one step ago
-            }
-            if constexpr (SL == 2 * KS + 4 * DT - 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx_n = fmaxf(mx_n, s_nxt[1][r]);
-                vst.store(Vt_ + vfree * VT, tid);         // the V buffer of tile j-1
-            }
-            // the fence (no instructions): everything the following slots need passes through it. S(j+1)'s second half joins
-            // once it exists (slot KS on); the running maximum once it exists (the last two slots).
-#define MOS_PIN_COMMON "+v"(s_nxt[0]), "+v"(o[0]), "+v"(o[DT - 1]), "+v"(s_cur[0]), "+v"(s_cur[1])
-            if constexpr (SL < KS) {
-                if constexpr (E1 - E0 == 3) asm volatile("" : MOS_PIN_COMMON, "+v"(pe[E0]), "+v"(pe[E0 + 1]), "+v"(pe[E0 + 2]));
-                else asm volatile("" : MOS_PIN_COMMON, "+v"(pe[E0]), "+v"(pe[E0 + 1]));
-            } else if constexpr (E1 - E0 == 4) {
-                asm volatile("" : MOS_PIN_COMMON, "+v"(s_nxt[1]), "+v"(pe[E0]), "+v"(pe[E0 + 1]), "+v"(pe[E0 + 2]), "+v"(pe[E0 + 3]));
-            } else if constexpr (E1 - E0 == 3) {
-                asm volatile("" : MOS_PIN_COMMON, "+v"(s_nxt[1]), "+v"(pe[E0]), "+v"(pe[E0 + 1]), "+v"(pe[E0 + 2]));
-            } else if constexpr (E1 - E0 == 2) {
-                asm volatile("" : MOS_PIN_COMMON, "+v"(s_nxt[1]), "+v"(pe[E0]), "+v"(pe[E0 + 1]));
-            } else {
-                asm volatile("" : MOS_PIN_COMMON, "+v"(s_nxt[1]), "+v"(mx_n));
-            }
-#undef MOS_PIN_COMMON
-        };
-#define MOS_SLOT(SL, E0, E1) slot(std::integral_constant<int, SL>{}, std::integral_constant<int, E0>{}, std::integral_constant<int, E1>{})
-        static_assert(KS == 3 && DT == 2, "the slot table below is written for d = 40");
-        MOS_SLOT(0, 0, 3);   MOS_SLOT(1, 3, 6);    MOS_SLOT(2, 6, 8);      // S rows 0-31   || P keys 0-7 of the first 32-key half
-        MOS_SLOT(3, 8, 11);  MOS_SLOT(4, 11, 14);  MOS_SLOT(5, 14, 16);    // S rows 32-63  || P keys 8-15
-        MOS_SLOT(6, 16, 18); MOS_SLOT(7, 18, 20);                           // V^T P(0-7)    || P of the second half ...
-        MOS_SLOT(8, 20, 22); MOS_SLOT(9, 22, 24);                           // V^T P(8-15)
-        MOS_SLOT(10, 24, 28); MOS_SLOT(11, 28, 32);                         // V^T P(16-23)
-        MOS_SLOT(12, 32, 32); MOS_SLOT(13, 32, 32);                         // V^T P(24-31)  || max of S(j+1), LDS stores of tile j+2
-#undef MOS_SLOT
+        v8 kfr[2][KS], vfr[2][2][DT];
+        #pragma unroll
+        for (int t = 0; t < 2; ++t)
+        #pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kfr[t][ks] = as_v8<T>(ld16(Kn + (32 * t + l31) * RS + ks * 16 + hh * 8));
+        asm volatile("" : "+v"(kfr[0][0]), "+v"(kfr[0][1]), "+v"(kfr[0][2]), "+v"(kfr[1][0]), "+v"(kfr[1][1]), "+v"(kfr[1][2]));      // all six K fragments are in flight together; this is the one LDS wait of the step
+        s_nxt[0] = MT<T>::mfma32(kfr[0][0], qf[0], zero16);
+        pe[0] = __builtin_amdgcn_exp2f(s_cur[0][0] * c - mc);
+        pe[1] = __builtin_amdgcn_exp2f(s_cur[0][1] * c - mc);
+        pe[2] = __builtin_amdgcn_exp2f(s_cur[0][2] * c - mc);
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[0]), "+v"(pe[1]), "+v"(pe[2]));
+        s_nxt[1] = MT<T>::mfma32(kfr[1][0], qf[0], zero16);
+        // the V^T fragments of the first 32 keys: consumed four slots from here
+        #pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+        #pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vfr[0][s2][dt] = tr_afrag<T>(Vc + (32 * dt + l31) * TS, 0, s2, hh);
+        pe[3] = __builtin_amdgcn_exp2f(s_cur[0][3] * c - mc);
+        pe[4] = __builtin_amdgcn_exp2f(s_cur[0][4] * c - mc);
+        pe[5] = __builtin_amdgcn_exp2f(s_cur[0][5] * c - mc);
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[3]), "+v"(pe[4]), "+v"(pe[5]));
+        s_nxt[0] = MT<T>::mfma32(kfr[0][1], qf[1], s_nxt[0]);
+        pe[6] = __builtin_amdgcn_exp2f(s_cur[0][6] * c - mc);
+        pe[7] = __builtin_amdgcn_exp2f(s_cur[0][7] * c - mc);
+        pf[0][0] = v8{(T)pe[0], (T)pe[1], (T)pe[2], (T)pe[3], (T)pe[4], (T)pe[5], (T)pe[6], (T)pe[7]};
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[6]), "+v"(pe[7]));
+        s_nxt[1] = MT<T>::mfma32(kfr[1][1], qf[1], s_nxt[1]);
+        pe[8] = __builtin_amdgcn_exp2f(s_cur[0][8] * c - mc);
+        pe[9] = __builtin_amdgcn_exp2f(s_cur[0][9] * c - mc);
+        pe[10] = __builtin_amdgcn_exp2f(s_cur[0][10] * c - mc);
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[8]), "+v"(pe[9]), "+v"(pe[10]));
+        s_nxt[0] = MT<T>::mfma32(kfr[0][2], qf[2], s_nxt[0]);
+        pe[11] = __builtin_amdgcn_exp2f(s_cur[0][11] * c - mc);
+        pe[12] = __builtin_amdgcn_exp2f(s_cur[0][12] * c - mc);
+        pe[13] = __builtin_amdgcn_exp2f(s_cur[0][13] * c - mc);
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[11]), "+v"(pe[12]), "+v"(pe[13]));
+        s_nxt[1] = MT<T>::mfma32(kfr[1][2], qf[2], s_nxt[1]);
+        pe[14] = __builtin_amdgcn_exp2f(s_cur[0][14] * c - mc);
+        pe[15] = __builtin_amdgcn_exp2f(s_cur[0][15] * c - mc);
+        pf[0][1] = v8{(T)pe[8], (T)pe[9], (T)pe[10], (T)pe[11], (T)pe[12], (T)pe[13], (T)pe[14], (T)pe[15]};
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[14]), "+v"(pe[15]), "+v"(vfr[0][0][0]), "+v"(vfr[0][0][1]), "+v"(vfr[0][1][0]), "+v"(vfr[0][1][1]), "+v"(pf[0][0]), "+v"(pf[0][1]));
+        o[0] = MT<T>::mfma32(vfr[0][0][0], pf[0][0], o[0]);
+        // the V^T fragments of keys 32-63
+        #pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+        #pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vfr[1][s2][dt] = tr_afrag<T>(Vc + (32 * dt + l31) * TS, 1, s2, hh);
+        pe[16] = __builtin_amdgcn_exp2f(s_cur[1][0] * c - mc);
+        pe[17] = __builtin_amdgcn_exp2f(s_cur[1][1] * c - mc);
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[16]), "+v"(pe[17]));
+        o[1] = MT<T>::mfma32(vfr[0][0][1], pf[0][0], o[1]);
+        pe[18] = __builtin_amdgcn_exp2f(s_cur[1][2] * c - mc);
+        pe[19] = __builtin_amdgcn_exp2f(s_cur[1][3] * c - mc);
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[18]), "+v"(pe[19]));
+        o[0] = MT<T>::mfma32(vfr[0][1][0], pf[0][1], o[0]);
+        pe[20] = __builtin_amdgcn_exp2f(s_cur[1][4] * c - mc);
+        pe[21] = __builtin_amdgcn_exp2f(s_cur[1][5] * c - mc);
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[20]), "+v"(pe[21]));
+        o[1] = MT<T>::mfma32(vfr[0][1][1], pf[0][1], o[1]);
+        pe[22] = __builtin_amdgcn_exp2f(s_cur[1][6] * c - mc);
+        pe[23] = __builtin_amdgcn_exp2f(s_cur[1][7] * c - mc);
+        pf[1][0] = v8{(T)pe[16], (T)pe[17], (T)pe[18], (T)pe[19], (T)pe[20], (T)pe[21], (T)pe[22], (T)pe[23]};
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[22]), "+v"(pe[23]), "+v"(vfr[1][0][0]), "+v"(vfr[1][0][1]), "+v"(vfr[1][1][0]), "+v"(vfr[1][1][1]), "+v"(pf[1][0]));
+        o[0] = MT<T>::mfma32(vfr[1][0][0], pf[1][0], o[0]);
+        pe[24] = __builtin_amdgcn_exp2f(s_cur[1][8] * c - mc);
+        pe[25] = __builtin_amdgcn_exp2f(s_cur[1][9] * c - mc);
+        pe[26] = __builtin_amdgcn_exp2f(s_cur[1][10] * c - mc);
+        pe[27] = __builtin_amdgcn_exp2f(s_cur[1][11] * c - mc);
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[24]), "+v"(pe[25]), "+v"(pe[26]), "+v"(pe[27]));
+        o[1] = MT<T>::mfma32(vfr[1][0][1], pf[1][0], o[1]);
+        pe[28] = __builtin_amdgcn_exp2f(s_cur[1][12] * c - mc);
+        pe[29] = __builtin_amdgcn_exp2f(s_cur[1][13] * c - mc);
+        pe[30] = __builtin_amdgcn_exp2f(s_cur[1][14] * c - mc);
+        pe[31] = __builtin_amdgcn_exp2f(s_cur[1][15] * c - mc);
+        pf[1][1] = v8{(T)pe[24], (T)pe[25], (T)pe[26], (T)pe[27], (T)pe[28], (T)pe[29], (T)pe[30], (T)pe[31]};
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[28]), "+v"(pe[29]), "+v"(pe[30]), "+v"(pe[31]), "+v"(pf[1][1]));
+        o[0] = MT<T>::mfma32(vfr[1][1][0], pf[1][1], o[0]);
+        mx_n = s_nxt[0][0];
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) mx_n = fmaxf(mx_n, s_nxt[0][r]);
+        kst.store(Ks_ + (kbuf ^ 1) * KT, tid);    // K(j) was consumed one step ago
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(mx_n));
+        o[1] = MT<T>::mfma32(vfr[1][1][1], pf[1][1], o[1]);
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) mx_n = fmaxf(mx_n, s_nxt[1][r]);
+        vst.store(Vt_ + vfree * VT, tid);         // the V buffer of tile j-1
+        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(mx_n));
         mx_n = fmaxf(mx_n, __shfl_xor(mx_n, 32));
         __syncthreads();
 #pragma unroll
@@ -1407,6 +1443,259 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part, int nspli
     st8(dv + (int64_t)b * dv_bs + (int64_t)kv * dv_rs + h * D + d, pack4<T>(sv[0], sv[1], sv[2], sv[3]));
 }
 
+// ---- dK/dV, slot-interleaved (round 4) ---------------------------------------------------------------------------------------
+// The ablation of attn_bwd_dkdv_kernel (profiles/r03_attention_ablation.txt: 185 us of MFMA + LDS reads, 62 us of softmax VALU,
+// 55 us of staging, 17 us of barriers that ADD UP) names the fault: per 32-query half the kernel runs 6 MFMAs, then ~300 cycles
+// of VALU (exp2, p * (dP - D), two roundings), then 8 MFMAs, each phase waiting for the previous one. Only VALU issued by the
+// SAME wave behind an MFMA overlaps with it, so the tile is laid out as 28 MFMA slots in program order
+//     A0 (6)            S, dP of queries 0-31
+//     A1 (6)  || P, dS of queries 0-31, accumulator rows 0-7           (needs A0)
+//     C0a (4) || P, dS of queries 0-31, rows 8-15                      (needs the first eight)
+//     C0b (4) || P, dS of queries 32-63, rows 0-7                      (needs A1)
+//     C1a (4) || P, dS of queries 32-63, rows 8-15
+//     C1b (4) || the transposing LDS stores of the next tile
+// with 1-2 elements of softmax work behind every MFMA and an empty volatile asm after each slot that the accumulators and the
+// in-place S / dP vectors pass through (the compiler can neither bunch the MFMAs nor move the exponentials out of their slot).
+// d = 40, no probability columns, no causal mask, whole 64-query tiles: the level-0 self-attention of the UNet; everything else
+// takes attn_bwd_dkdv_kernel. MOS_ATTN_PIPE=0 disables it.
+template <typename T, int D>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_pipe_kernel(AttnBwdArgs a) {
+    constexpr int NT = 256, NW = 4;
+    typedef typename MT<T>::v8 v8;
+    constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
+    static_assert(KS == 3 && DT == 2, "the slot table is written for d = 40");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int RT = HD<D>::ROW_TILE_ELEMS, TT = HD<D>::TR_TILE_ELEMS;
+    constexpr int ST = KV_TILE * (2 + MOS_MAX_PCOLS);   // (same LDS layout as attn_bwd_dkdv_kernel: dkdv_lds<D>)
+    T* Qs_ = reinterpret_cast<T*>(smem_raw);
+    T* dOs_ = Qs_ + 2 * RT;
+    T* Qt_ = dOs_ + 2 * RT;
+    T* dOt_ = Qt_ + 2 * TT;
+    float* stat_ = reinterpret_cast<float*>(dOt_ + 2 * TT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.x % a.H;
+    const int rest = blockIdx.x / a.H;
+    const int kb = rest % a.nkb, b = rest / a.nkb;
+    const int split = blockIdx.y;
+    const int kvi = kb * (32 * NW) + wave * 32 + l31;
+    const bool kvalid = kvi < a.Nkv;
+    const int kc = min(kvi, a.Nkv - 1);
+#pragma unroll
+    for (int bf = 0; bf < 2; ++bf) {
+        zero_row_pads<T, D, NT>(Qs_ + bf * RT, tid);
+        zero_row_pads<T, D, NT>(dOs_ + bf * RT, tid);
+        zero_tr_pads<T, D, NT>(Qt_ + bf * TT, tid);
+        zero_tr_pads<T, D, NT>(dOt_ + bf * TT, tid);
+    }
+    v8 kf[KS], vf[KS];
+    load_row_frags<T, D>(kf, (const T*)a.k + (int64_t)b * a.k_bs + (int64_t)kc * a.k_rs + h * D, kvalid, hh);
+    load_row_frags<T, D>(vf, (const T*)a.v + (int64_t)b * a.v_bs + (int64_t)kc * a.v_rs + h * D, kvalid, hh);
+    const float c = a.scale * LOG2E;
+    f32x16 dkT[DT], dvT[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkT[dt][r] = 0.f; dvT[dt][r] = 0.f; }
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
+    const T* dop = (const T*)a.dO + (int64_t)b * a.do_bs + h * D;
+    const int64_t rowbase = ((int64_t)b * a.H + h) * a.Nq;
+    const int qbeg = split * a.q_per_split;
+    const int qend = min(qbeg + a.q_per_split, a.Nq);
+    TrStage<T, D, NT> qtst, dotst;
+    qtst.init(a.q_rs, tid);
+    dotst.init(a.do_rs, tid);
+    float st_lse = 0.f, st_D = 0.f;
+    int st_nv = 0;
+    const rsrc_t qsrc = make_rsrc(qp, slice_bytes<T, D>(a.Nq, a.q_rs));
+    const rsrc_t dosrc = make_rsrc(dop, slice_bytes<T, D>(a.Nq, a.do_rs));
+    const int q_row_bytes = (int)a.q_rs * (int)sizeof(T), do_row_bytes = (int)a.do_rs * (int)sizeof(T);
+    auto load_tile = [&](int q0) {
+        const int nv = qend - q0;
+        qtst.load(qsrc, q0 * q_row_bytes);
+        dotst.load(dosrc, q0 * do_row_bytes);
+        st_nv = nv;
+        const int64_t rr = rowbase + q0 + min(tid & (KV_TILE - 1), nv - 1);
+        st_lse = a.lse[rr];
+        st_D = a.Dvec[rr];
+    };
+    auto store_tile = [&](int bf) {
+        qtst.store_rows(Qs_ + bf * RT, tid);
+        dotst.store_rows(dOs_ + bf * RT, tid);
+        qtst.store(Qt_ + bf * TT, tid);
+        dotst.store(dOt_ + bf * TT, tid);
+        if (tid < KV_TILE) {
+            float* sb = stat_ + bf * ST;
+            const bool ok = tid < st_nv;
+            sb[tid] = ok ? st_lse * LOG2E : 0.f;
+            sb[KV_TILE + tid] = ok ? -st_D : 0.f;     // negated: the initial value of the dP accumulator
+        }
+    };
+    __syncthreads();
+    if (qbeg < qend) {
+        load_tile(qbeg);
+        store_tile(0);
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), see attn_bwd_dkdv_kernel
+    int cur = 0;
+    for (int q0 = qbeg; q0 < qend; q0 += KV_TILE) {
+        const T* Qs = Qs_ + cur * RT;
+        const T* dOs = dOs_ + cur * RT;
+        const T* Qt = Qt_ + cur * TT;
+        const T* dOt = dOt_ + cur * TT;
+        const float* lse_s = stat_ + cur * ST;
+        const float* D_s = lse_s + KV_TILE;
+        const bool more = q0 + KV_TILE < qend;
+        if (more) load_tile(q0 + KV_TILE);
+        f32x4 l0[4], l1[4];
+        f32x16 nd0, nd1;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int ql = 8 * r4 + 4 * hh;
+            l0[r4] = *reinterpret_cast<const f32x4*>(lse_s + ql);
+            l1[r4] = *reinterpret_cast<const f32x4*>(lse_s + 32 + ql);
+            const f32x4 d0 = *reinterpret_cast<const f32x4*>(D_s + ql), d1 = *reinterpret_cast<const f32x4*>(D_s + 32 + ql);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) { nd0[4 * r4 + rr] = d0[rr]; nd1[4 * r4 + rr] = d1[rr]; }
+        }
+        f32x16 s0, dp0, s1, dp1;
+        v8 pf0[2], dsf0[2], pf1[2], dsf1[2];
+        // A-operand fragments are read a whole stage ahead of the MFMAs that consume them and ride through the fences (read inside
+        // their slot, every MFMA would wait on LDS): the row fragments of both halves now, the transposed ones stage by stage.
+        v8 aq0[KS], ado0[KS], aq1[KS], ado1[KS], fdo00[DT], fq00[DT], fdo01[DT], fq01[DT], fdo10[DT], fq10[DT], fdo11[DT], fq11[DT];
+        #pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { aq0[ks] = as_v8<T>(ld16(Qs + (32 * 0 + l31) * RS + ks * 16 + hh * 8)); ado0[ks] = as_v8<T>(ld16(dOs + (32 * 0 + l31) * RS + ks * 16 + hh * 8)); }
+        #pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { aq1[ks] = as_v8<T>(ld16(Qs + (32 * 1 + l31) * RS + ks * 16 + hh * 8)); ado1[ks] = as_v8<T>(ld16(dOs + (32 * 1 + l31) * RS + ks * 16 + hh * 8)); }
+        asm volatile("" : "+v"(aq0[0]), "+v"(ado0[0]), "+v"(aq0[1]), "+v"(ado0[1]), "+v"(aq0[2]), "+v"(ado0[2]));
+        // A0: S and dP of queries 0-31 (nothing to hide behind them yet)
+        s0 = MT<T>::mfma32(aq0[0], kf[0], zero16);
+        dp0 = MT<T>::mfma32(ado0[0], vf[0], nd0);
+        s0 = MT<T>::mfma32(aq0[1], kf[1], s0);
+        dp0 = MT<T>::mfma32(ado0[1], vf[1], dp0);
+        s0 = MT<T>::mfma32(aq0[2], kf[2], s0);
+        dp0 = MT<T>::mfma32(ado0[2], vf[2], dp0);
+        asm volatile("" : "+v"(s0), "+v"(dp0), "+v"(aq1[0]), "+v"(ado1[0]), "+v"(aq1[1]), "+v"(ado1[1]), "+v"(aq1[2]), "+v"(ado1[2]));
+        // A1: S and dP of queries 32-63   || P, dS of queries 0-31, accumulator rows 0-7
+        #pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { fdo00[dt] = tr_afrag<T>(dOt + (32 * dt + l31) * TS, 0, 0, hh); fq00[dt] = tr_afrag<T>(Qt + (32 * dt + l31) * TS, 0, 0, hh); }
+        s1 = MT<T>::mfma32(aq1[0], kf[0], zero16);
+        { const float p = __builtin_amdgcn_exp2f(s0[0] * c - l0[0][0]); s0[0] = p; dp0[0] = p * dp0[0]; }
+        { const float p = __builtin_amdgcn_exp2f(s0[1] * c - l0[0][1]); s0[1] = p; dp0[1] = p * dp0[1]; }
+        asm volatile("" : "+v"(s1), "+v"(s0), "+v"(dp0));
+        dp1 = MT<T>::mfma32(ado1[0], vf[0], nd1);
+        { const float p = __builtin_amdgcn_exp2f(s0[2] * c - l0[0][2]); s0[2] = p; dp0[2] = p * dp0[2]; }
+        asm volatile("" : "+v"(s1), "+v"(dp1), "+v"(s0), "+v"(dp0));
+        s1 = MT<T>::mfma32(aq1[1], kf[1], s1);
+        { const float p = __builtin_amdgcn_exp2f(s0[3] * c - l0[0][3]); s0[3] = p; dp0[3] = p * dp0[3]; }
+        asm volatile("" : "+v"(s1), "+v"(dp1), "+v"(s0), "+v"(dp0));
+        dp1 = MT<T>::mfma32(ado1[1], vf[1], dp1);
+        { const float p = __builtin_amdgcn_exp2f(s0[4] * c - l0[1][0]); s0[4] = p; dp0[4] = p * dp0[4]; }
+        { const float p = __builtin_amdgcn_exp2f(s0[5] * c - l0[1][1]); s0[5] = p; dp0[5] = p * dp0[5]; }
+        asm volatile("" : "+v"(s1), "+v"(dp1), "+v"(s0), "+v"(dp0));
+        s1 = MT<T>::mfma32(aq1[2], kf[2], s1);
+        { const float p = __builtin_amdgcn_exp2f(s0[6] * c - l0[1][2]); s0[6] = p; dp0[6] = p * dp0[6]; }
+        asm volatile("" : "+v"(s1), "+v"(dp1), "+v"(s0), "+v"(dp0));
+        dp1 = MT<T>::mfma32(ado1[2], vf[2], dp1);
+        { const float p = __builtin_amdgcn_exp2f(s0[7] * c - l0[1][3]); s0[7] = p; dp0[7] = p * dp0[7]; }
+        pf0[0] = acc_to_bfrag<T>(s0, 0); dsf0[0] = acc_to_bfrag<T>(dp0, 0);
+        asm volatile("" : "+v"(s1), "+v"(dp1), "+v"(s0), "+v"(dp0), "+v"(pf0[0]), "+v"(dsf0[0]), "+v"(fdo00[0]), "+v"(fq00[0]), "+v"(fdo00[1]), "+v"(fq00[1]));
+        // C0a: dV^T += dO^T P, dK^T += Q^T dS over queries 0-31, contraction rows 0-15   || P, dS rows 8-15 of queries 0-31
+        #pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { fdo01[dt] = tr_afrag<T>(dOt + (32 * dt + l31) * TS, 0, 1, hh); fq01[dt] = tr_afrag<T>(Qt + (32 * dt + l31) * TS, 0, 1, hh); }
+        dvT[0] = MT<T>::mfma32(fdo00[0], pf0[0], dvT[0]);
+        { const float p = __builtin_amdgcn_exp2f(s0[8] * c - l0[2][0]); s0[8] = p; dp0[8] = p * dp0[8]; }
+        { const float p = __builtin_amdgcn_exp2f(s0[9] * c - l0[2][1]); s0[9] = p; dp0[9] = p * dp0[9]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s0), "+v"(dp0));
+        dkT[0] = MT<T>::mfma32(fq00[0], dsf0[0], dkT[0]);
+        { const float p = __builtin_amdgcn_exp2f(s0[10] * c - l0[2][2]); s0[10] = p; dp0[10] = p * dp0[10]; }
+        { const float p = __builtin_amdgcn_exp2f(s0[11] * c - l0[2][3]); s0[11] = p; dp0[11] = p * dp0[11]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s0), "+v"(dp0));
+        dvT[1] = MT<T>::mfma32(fdo00[1], pf0[0], dvT[1]);
+        { const float p = __builtin_amdgcn_exp2f(s0[12] * c - l0[3][0]); s0[12] = p; dp0[12] = p * dp0[12]; }
+        { const float p = __builtin_amdgcn_exp2f(s0[13] * c - l0[3][1]); s0[13] = p; dp0[13] = p * dp0[13]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s0), "+v"(dp0));
+        dkT[1] = MT<T>::mfma32(fq00[1], dsf0[0], dkT[1]);
+        { const float p = __builtin_amdgcn_exp2f(s0[14] * c - l0[3][2]); s0[14] = p; dp0[14] = p * dp0[14]; }
+        { const float p = __builtin_amdgcn_exp2f(s0[15] * c - l0[3][3]); s0[15] = p; dp0[15] = p * dp0[15]; }
+        pf0[1] = acc_to_bfrag<T>(s0, 1); dsf0[1] = acc_to_bfrag<T>(dp0, 1);
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s0), "+v"(dp0), "+v"(pf0[1]), "+v"(dsf0[1]), "+v"(s1), "+v"(dp1), "+v"(fdo01[0]), "+v"(fq01[0]), "+v"(fdo01[1]), "+v"(fq01[1]));
+        // C0b: the second contraction half of queries 0-31   || P, dS rows 0-7 of queries 32-63
+        #pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { fdo10[dt] = tr_afrag<T>(dOt + (32 * dt + l31) * TS, 1, 0, hh); fq10[dt] = tr_afrag<T>(Qt + (32 * dt + l31) * TS, 1, 0, hh); }
+        dvT[0] = MT<T>::mfma32(fdo01[0], pf0[1], dvT[0]);
+        { const float p = __builtin_amdgcn_exp2f(s1[0] * c - l1[0][0]); s1[0] = p; dp1[0] = p * dp1[0]; }
+        { const float p = __builtin_amdgcn_exp2f(s1[1] * c - l1[0][1]); s1[1] = p; dp1[1] = p * dp1[1]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s1), "+v"(dp1));
+        dkT[0] = MT<T>::mfma32(fq01[0], dsf0[1], dkT[0]);
+        { const float p = __builtin_amdgcn_exp2f(s1[2] * c - l1[0][2]); s1[2] = p; dp1[2] = p * dp1[2]; }
+        { const float p = __builtin_amdgcn_exp2f(s1[3] * c - l1[0][3]); s1[3] = p; dp1[3] = p * dp1[3]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s1), "+v"(dp1));
+        dvT[1] = MT<T>::mfma32(fdo01[1], pf0[1], dvT[1]);
+        { const float p = __builtin_amdgcn_exp2f(s1[4] * c - l1[1][0]); s1[4] = p; dp1[4] = p * dp1[4]; }
+        { const float p = __builtin_amdgcn_exp2f(s1[5] * c - l1[1][1]); s1[5] = p; dp1[5] = p * dp1[5]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s1), "+v"(dp1));
+        dkT[1] = MT<T>::mfma32(fq01[1], dsf0[1], dkT[1]);
+        { const float p = __builtin_amdgcn_exp2f(s1[6] * c - l1[1][2]); s1[6] = p; dp1[6] = p * dp1[6]; }
+        { const float p = __builtin_amdgcn_exp2f(s1[7] * c - l1[1][3]); s1[7] = p; dp1[7] = p * dp1[7]; }
+        pf1[0] = acc_to_bfrag<T>(s1, 0); dsf1[0] = acc_to_bfrag<T>(dp1, 0);
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s1), "+v"(dp1), "+v"(pf1[0]), "+v"(dsf1[0]), "+v"(fdo10[0]), "+v"(fq10[0]), "+v"(fdo10[1]), "+v"(fq10[1]));
+        // C1a: queries 32-63, contraction rows 0-15   || P, dS rows 8-15 of queries 32-63
+        #pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { fdo11[dt] = tr_afrag<T>(dOt + (32 * dt + l31) * TS, 1, 1, hh); fq11[dt] = tr_afrag<T>(Qt + (32 * dt + l31) * TS, 1, 1, hh); }
+        dvT[0] = MT<T>::mfma32(fdo10[0], pf1[0], dvT[0]);
+        { const float p = __builtin_amdgcn_exp2f(s1[8] * c - l1[2][0]); s1[8] = p; dp1[8] = p * dp1[8]; }
+        { const float p = __builtin_amdgcn_exp2f(s1[9] * c - l1[2][1]); s1[9] = p; dp1[9] = p * dp1[9]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s1), "+v"(dp1));
+        dkT[0] = MT<T>::mfma32(fq10[0], dsf1[0], dkT[0]);
+        { const float p = __builtin_amdgcn_exp2f(s1[10] * c - l1[2][2]); s1[10] = p; dp1[10] = p * dp1[10]; }
+        { const float p = __builtin_amdgcn_exp2f(s1[11] * c - l1[2][3]); s1[11] = p; dp1[11] = p * dp1[11]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s1), "+v"(dp1));
+        dvT[1] = MT<T>::mfma32(fdo10[1], pf1[0], dvT[1]);
+        { const float p = __builtin_amdgcn_exp2f(s1[12] * c - l1[3][0]); s1[12] = p; dp1[12] = p * dp1[12]; }
+        { const float p = __builtin_amdgcn_exp2f(s1[13] * c - l1[3][1]); s1[13] = p; dp1[13] = p * dp1[13]; }
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s1), "+v"(dp1));
+        dkT[1] = MT<T>::mfma32(fq10[1], dsf1[0], dkT[1]);
+        { const float p = __builtin_amdgcn_exp2f(s1[14] * c - l1[3][2]); s1[14] = p; dp1[14] = p * dp1[14]; }
+        { const float p = __builtin_amdgcn_exp2f(s1[15] * c - l1[3][3]); s1[15] = p; dp1[15] = p * dp1[15]; }
+        pf1[1] = acc_to_bfrag<T>(s1, 1); dsf1[1] = acc_to_bfrag<T>(dp1, 1);
+        asm volatile("" : "+v"(dvT[0]), "+v"(dkT[0]), "+v"(dvT[1]), "+v"(dkT[1]), "+v"(s1), "+v"(dp1), "+v"(pf1[1]), "+v"(dsf1[1]), "+v"(fdo11[0]), "+v"(fq11[0]), "+v"(fdo11[1]), "+v"(fq11[1]));
+        // C1b: the last four MFMAs run under the LDS stores of the next tile below
+        dvT[0] = MT<T>::mfma32(fdo11[0], pf1[1], dvT[0]);
+        dkT[0] = MT<T>::mfma32(fq11[0], dsf1[1], dkT[0]);
+        dvT[1] = MT<T>::mfma32(fdo11[1], pf1[1], dvT[1]);
+        dkT[1] = MT<T>::mfma32(fq11[1], dsf1[1], dkT[1]);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (a.nsplit == 1) {
+        T* dkp = (T*)a.dk + (int64_t)b * a.dk_bs + (int64_t)kvi * a.dk_rs + h * D;
+        T* dvp = (T*)a.dv + (int64_t)b * a.dv_bs + (int64_t)kvi * a.dv_rs + h * D;
+        store_out_rows<T, D>(dkp, kvalid, dkT, a.scale, hh);
+        store_out_rows<T, D>(dvp, kvalid, dvT, 1.0f, hh);
+    } else if (kvalid) {
+        const int64_t bh = (int64_t)b * a.H + h;
+        const int64_t slab = (int64_t)a.B * a.H * a.Nkv * D;
+        float* pk = a.part + ((int64_t)split * slab) + (bh * a.Nkv + kvi) * D;
+        float* pv = pk + (int64_t)a.nsplit * slab;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int db = 32 * dt + 8 * r4 + 4 * hh;
+                if (db < D) {
+                    *reinterpret_cast<f32x4*>(pk + db) = f32x4{dkT[dt][4 * r4] * a.scale, dkT[dt][4 * r4 + 1] * a.scale,
+                                                              dkT[dt][4 * r4 + 2] * a.scale, dkT[dt][4 * r4 + 3] * a.scale};
+                    *reinterpret_cast<f32x4*>(pv + db) = f32x4{dvT[dt][4 * r4], dvT[dt][4 * r4 + 1], dvT[dt][4 * r4 + 2],
+                                                              dvT[dt][4 * r4 + 3]};
+                }
+            }
+    }
+}
+
 // ---- host dispatch -----------------------------------------------------------------------------
 template <int D> constexpr int fwd_qw() { return D <= 80 ? 64 : 32; }
 
@@ -1616,8 +1905,18 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
             hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T, D, PC, 4, CA>), grid, dim3(256), lds, st, a);
         };
         bool done = false;
+        if constexpr (D == 40) {
+            const char* pe_ = getenv("MOS_ATTN_PIPE");
+            // MOS_ATTN_PIPE: unset / 1 = pipelined forward + dK/dV, 2 = forward only, 0 = neither
+            const bool pipe = pe_ == nullptr || atoi(pe_) == 1;
+            if (pipe && !pc && !a.causal && s->Nq % KV_TILE == 0 && a.q_per_split % KV_TILE == 0) {
+                set_lds(&attn_bwd_dkdv_pipe_kernel<T, D>, lds);
+                hipLaunchKernelGGL((attn_bwd_dkdv_pipe_kernel<T, D>), grid, dim3(256), lds, st, a);
+                done = true;
+            }
+        }
         if constexpr (has_causal<D>()) {
-            if (a.causal) {
+            if (!done && a.causal) {
                 if (pc) go(std::true_type{}, std::true_type{}); else go(std::false_type{}, std::true_type{});
                 done = true;
             }

@@ -278,6 +278,36 @@ def test_attention_fwd_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch
         _check(f'attn_fwd pipelined[{name}].lse vs attn_fwd_kernel', lse1, lse0, torch.float16, ulps=1.0)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,Nq,Nkv', [(4, 4096, 4096), (1, 1024, 1024), (2, 256, 200), (1, 6144, 6144)])
+def test_attention_bwd_dkdv_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch):
+    """attn_bwd_dkdv_pipe_kernel (d = 40, slot-interleaved MFMA / softmax VALU) against attn_bwd_dkdv_kernel
+    (MOS_ATTN_PIPE=2: pipelined forward only) and the fp32 emulation; dQ rides along unchanged."""
+    H, d = 8, 40
+    C = H * d
+    q, k, v = _qkv(B, Nq, Nkv, C, dtype, 11, fused=(Nq == Nkv))
+    scale = d**-0.5
+    o_r, lse_r, _ = emu.attn_fwd(q, k, v, H, scale)
+    g = torch.Generator(device='cpu').manual_seed(12)
+    dO = torch.randn(B, Nq, C, generator=g).to('cuda', dtype)
+    res = {}
+    for mode in ('1', '2'):
+        monkeypatch.setenv('MOS_ATTN_PIPE', mode)
+        dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
+        ops.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq, dk, dv)
+        res[mode] = (dq, dk, dv)
+    monkeypatch.delenv('MOS_ATTN_PIPE')
+    dq_r, dk_r, dv_r = torch.empty_like(res['1'][0]), torch.empty_like(res['1'][1]), torch.empty_like(res['1'][2])
+    emu.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq_r, dk_r, dv_r)
+    _check(f'attn_bwd pipelined dK/dV [{B}x{Nq}x{Nkv}].dk vs emulation', res['1'][1], dk_r, dtype, ulps=6.0)
+    _check('attn_bwd pipelined dK/dV .dv vs emulation', res['1'][2], dv_r, dtype, ulps=6.0)
+    _check('attn_bwd pipelined dK/dV .dk vs attn_bwd_dkdv_kernel', res['1'][1], res['2'][1], dtype, ulps=1.0)
+    _check('attn_bwd pipelined dK/dV .dv vs attn_bwd_dkdv_kernel', res['1'][2], res['2'][2], dtype, ulps=1.0)
+    same = torch.equal(res['1'][1], res['2'][1]) and torch.equal(res['1'][2], res['2'][2])
+    print(f'[parity] pipelined dK/dV [{B}x{Nq}x{Nkv}] bit-identical to attn_bwd_dkdv_kernel: {same}')
+    assert torch.equal(res['1'][0], res['2'][0])         # dQ: same kernel both times
+
+
 def test_attention_softmax_rescale_branch(ops, emu):
     """Force the online-softmax rescale: one key far above the rest in a LATE kv tile (cdna guide 5.4 rule 26)."""
     B, H, N, d = 1, 8, 512, 40
