@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
 //     one barrier per tile;
 //   * tells the scheduler the interleave it should build (sched_group_barrier: 1 MFMA, then a few VALU / TRANS, repeated).
 // 32 queries per wave, 128 per workgroup; Nkv % 64 == 0, no probability columns, no causal mask (the UNet's self-attention:
-// 4096 / 1024 / 6144 / 1536 keys); everything else takes attn_fwd_kernel. MOS_ATTN_PIPE=0 disables it.
+// 4096 / 1024 / 6144 / 1536 keys); everything else takes attn_fwd_kernel. Selected by MOS_ATTN_PIPE_FWD=1 (off by default: see launch_fwd).
 constexpr float LAZY_T = 8.0f;
 
 template <typename T, int D>
@@ -1457,7 +1457,7 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part, int nspli
 // with 1-2 elements of softmax work behind every MFMA and an empty volatile asm after each slot that the accumulators and the
 // in-place S / dP vectors pass through (the compiler can neither bunch the MFMAs nor move the exponentials out of their slot).
 // d = 40, no probability columns, no causal mask, whole 64-query tiles: the level-0 self-attention of the UNet; everything else
-// takes attn_bwd_dkdv_kernel. MOS_ATTN_PIPE=0 disables it.
+// takes attn_bwd_dkdv_kernel. MOS_ATTN_PIPE_DKDV=0 disables it.
 template <typename T, int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_pipe_kernel(AttnBwdArgs a) {
     constexpr int NT = 256, NW = 4;
@@ -1784,11 +1784,19 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     // not give every CU at least two workgroups.
     const int64_t wg_big = (int64_t)s->H * s->B * ((s->Nq + 4 * QW - 1) / (4 * QW));
     if constexpr (D == 40) {
-        const char* pe_ = getenv("MOS_ATTN_PIPE");            // read per call: tests and same-box A/Bs flip it in one process
-        const bool pipe = pe_ == nullptr || atoi(pe_) != 0;
+        // MOS_ATTN_PIPE_FWD (default 0; read per call so that tests and same-box A/Bs flip it in one process). Measured, same box
+        // (profiles/r04_kernel_bench_attn_pipe_*.txt): correct, but SLOWER than attn_fwd_kernel -- 185-191 vs 161-164 us at B4 H8
+        // N4096, 215-217 vs 185-186 us at B2 H8 N6144, and 263 us with one wave per SIMD: behind the 14 MFMAs of a tile the
+        // exponentials do not disappear into their shadow the way the isolated microbenchmark suggested (a second wave on the SIMD
+        // helps more than the interleave). Kept for the record and the tests; the dK/dV form of the same idea wins 9 %.
+        const char* pe_ = getenv("MOS_ATTN_PIPE_FWD");
+        const bool pipe = pe_ != nullptr && atoi(pe_) != 0;
         if (pipe && np == 0 && !s->causal && s->Nkv % KV_TILE == 0 && s->Nkv >= 2 * KV_TILE) {
             const AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 128);
-            const size_t plds = (2 * HD<D>::ROW_TILE_ELEMS + 3 * HD<D>::TR_TILE_ELEMS) * sizeof(T);
+            size_t plds = (2 * HD<D>::ROW_TILE_ELEMS + 3 * HD<D>::TR_TILE_ELEMS) * sizeof(T);
+            // MOS_ATTN_PIPE_OCC=1: one workgroup per CU (one wave per SIMD), forced through the LDS request: the interleave is
+            // built for a wave that owns its SIMD (MFMA and VALU of different waves serialise, profiles/r03_microbench_*)
+            { const char* oc = getenv("MOS_ATTN_PIPE_OCC"); if (oc != nullptr && atoi(oc) == 1 && plds < 84 * 1024) plds = 84 * 1024; }
             set_lds(&attn_fwd_pipe_kernel<T, D>, plds);
             hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, D>), dim3((unsigned)(a.H * a.nqb * a.B)), dim3(256), plds, st, a);
             return mos_check_launch("attn_fwd_pipe");
@@ -1906,12 +1914,15 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         };
         bool done = false;
         if constexpr (D == 40) {
-            const char* pe_ = getenv("MOS_ATTN_PIPE");
-            // MOS_ATTN_PIPE: unset / 1 = pipelined forward + dK/dV, 2 = forward only, 0 = neither
-            const bool pipe = pe_ == nullptr || atoi(pe_) == 1;
+            // MOS_ATTN_PIPE_DKDV (default 1): 297.6-304.4 us against 332-334 us for attn_bwd_dkdv_kernel at B4 H8 N4096 on the
+            // same box (profiles/r04_kernel_bench_attn_pipe_*.txt)
+            const char* pe_ = getenv("MOS_ATTN_PIPE_DKDV");
+            const bool pipe = pe_ == nullptr || atoi(pe_) != 0;
             if (pipe && !pc && !a.causal && s->Nq % KV_TILE == 0 && a.q_per_split % KV_TILE == 0) {
-                set_lds(&attn_bwd_dkdv_pipe_kernel<T, D>, lds);
-                hipLaunchKernelGGL((attn_bwd_dkdv_pipe_kernel<T, D>), grid, dim3(256), lds, st, a);
+                size_t plds = lds;
+                { const char* oc = getenv("MOS_ATTN_PIPE_OCC"); if (oc != nullptr && atoi(oc) == 1 && plds < 84 * 1024) plds = 84 * 1024; }
+                set_lds(&attn_bwd_dkdv_pipe_kernel<T, D>, plds);
+                hipLaunchKernelGGL((attn_bwd_dkdv_pipe_kernel<T, D>), grid, dim3(256), plds, st, a);
                 done = true;
             }
         }

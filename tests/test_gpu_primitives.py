@@ -253,7 +253,7 @@ def test_attention_fwd_bwd(ops, emu, dtype, B, H, Nq, Nkv, d):
 @pytest.mark.parametrize('B,Nq,Nkv', [(2, 6144, 6144), (4, 4096, 4096), (1, 200, 256), (1, 128, 128), (2, 1000, 1536)])
 def test_attention_fwd_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch):
     """attn_fwd_pipe_kernel (d = 40, keys % 64 == 0: software-pipelined, lazily moved softmax reference) against
-    attn_fwd_kernel (MOS_ATTN_PIPE=0) and the fp32 emulation; plus a drifting-score case in which every tile's maximum is
+    attn_fwd_kernel (the default) and the fp32 emulation; plus a drifting-score case in which every tile's maximum is
     far above the previous one (the reference moves at every step) and one in which it falls (it never moves)."""
     H, d = 8, 40
     C = H * d
@@ -266,11 +266,11 @@ def test_attention_fwd_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch
         if ramp is not None:          # q.k grows / falls by ~30 raw units per 64-key tile for the first queries
             kk += ramp * 0.75 * (torch.arange(Nkv).float() / 64.0).floor()[None, :, None] * q[:, :1, :] / (q[:, :1, :].pow(2).mean(-1, keepdim=True).sqrt())
         qd, kd, vd = (t.to('cuda', dtype) for t in (q, kk, v))
-        monkeypatch.setenv('MOS_ATTN_PIPE', '1')
+        monkeypatch.setenv('MOS_ATTN_PIPE_FWD', '1')
         o1, lse1, _ = ops.attn_fwd(qd, kd, vd, H, d**-0.5)
-        monkeypatch.setenv('MOS_ATTN_PIPE', '0')
+        monkeypatch.setenv('MOS_ATTN_PIPE_FWD', '0')
         o0, lse0, _ = ops.attn_fwd(qd, kd, vd, H, d**-0.5)
-        monkeypatch.delenv('MOS_ATTN_PIPE')
+        monkeypatch.delenv('MOS_ATTN_PIPE_FWD')
         o_r, lse_r, _ = emu.attn_fwd(qd, kd, vd, H, d**-0.5)
         _check(f'attn_fwd pipelined[{name} {B}x{Nq}x{Nkv}].o vs emulation', o1, o_r, dtype)
         _check(f'attn_fwd pipelined[{name}].lse vs emulation', lse1, lse_r, torch.float16, ulps=2.0)
@@ -282,7 +282,7 @@ def test_attention_fwd_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch
 @pytest.mark.parametrize('B,Nq,Nkv', [(4, 4096, 4096), (1, 1024, 1024), (2, 256, 200), (1, 6144, 6144)])
 def test_attention_bwd_dkdv_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch):
     """attn_bwd_dkdv_pipe_kernel (d = 40, slot-interleaved MFMA / softmax VALU) against attn_bwd_dkdv_kernel
-    (MOS_ATTN_PIPE=2: pipelined forward only) and the fp32 emulation; dQ rides along unchanged."""
+    (MOS_ATTN_PIPE_DKDV=0) and the fp32 emulation; dQ rides along unchanged."""
     H, d = 8, 40
     C = H * d
     q, k, v = _qkv(B, Nq, Nkv, C, dtype, 11, fused=(Nq == Nkv))
@@ -291,12 +291,12 @@ def test_attention_bwd_dkdv_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkey
     g = torch.Generator(device='cpu').manual_seed(12)
     dO = torch.randn(B, Nq, C, generator=g).to('cuda', dtype)
     res = {}
-    for mode in ('1', '2'):
-        monkeypatch.setenv('MOS_ATTN_PIPE', mode)
+    for mode in ('1', '2'):                          # '1' = attn_bwd_dkdv_pipe_kernel, '2' = attn_bwd_dkdv_kernel
+        monkeypatch.setenv('MOS_ATTN_PIPE_DKDV', '1' if mode == '1' else '0')
         dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
         ops.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq, dk, dv)
         res[mode] = (dq, dk, dv)
-    monkeypatch.delenv('MOS_ATTN_PIPE')
+    monkeypatch.delenv('MOS_ATTN_PIPE_DKDV')
     dq_r, dk_r, dv_r = torch.empty_like(res['1'][0]), torch.empty_like(res['1'][1]), torch.empty_like(res['1'][2])
     emu.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq_r, dk_r, dv_r)
     _check(f'attn_bwd pipelined dK/dV [{B}x{Nq}x{Nkv}].dk vs emulation', res['1'][1], dk_r, dtype, ulps=6.0)

@@ -25,11 +25,14 @@ def collect(d, counter):
         for row in csv.DictReader(open(f)):
             if row.get('Counter_Name') != counter:
                 continue
-            m = re.search(r'(attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkdv_kernel|region_attn_kernel|gemm_lora_kernel|'
-                          r'lora_grad_kernel|gram_kernel)I(DF16_|DF16b)Li(\d+)', row.get('Kernel_Name', ''))
+            m = re.search(r'(attn_fwd_kernel|attn_fwd_pipe_kernel|attn_bwd_dq_kernel|attn_bwd_dkdv_kernel|attn_bwd_dkdv_pipe_kernel|'
+                          r'region_attn_kernel|gemm_lora_kernel|lora_grad_kernel|gram_kernel)I(DF16_|DF16b)Li(\d+)',
+                          row.get('Kernel_Name', ''))
             if not m:
                 continue
-            out[(m.group(1), 'f16' if m.group(2) == 'DF16_' else 'bf16', int(m.group(3)), row.get('Grid_Size', ''))].append(
+            # the slot-interleaved forms report under the profiler name of the kernel they replace (same launch site, same grid)
+            sym = m.group(1).replace('_pipe_kernel', '_kernel')
+            out[(sym, 'f16' if m.group(2) == 'DF16_' else 'bf16', int(m.group(3)), row.get('Grid_Size', ''))].append(
                 float(row['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in out.items()}
 
