@@ -314,8 +314,11 @@ inline int conv_ksplit(int M, int Cout, int Cin, int* kt_per, int* bm) {
     } else {
         *bm = 0;                                  // 64 x 64 tiles
         const int64_t tiles = (int64_t)((M + 63) / 64) * ((Cout + 63) / 64);
-        if (tiles > 320) return 1;
+        const char* mt = getenv("MOS_CONV_SPLIT_MAX_TILES");          // A/B knob: the unsplit tiling is kept above this many tiles
+        const int64_t max_tiles = mt != nullptr ? atoi(mt) : 320;
+        if (tiles > max_tiles) return 1;
         ks = (640 + tiles - 1) / tiles;
+        if (tiles > 320 && ks < 2) ks = 2;
     }
     if (ks > nk / 6) ks = nk / 6;               // at least 6 K tiles per workgroup
     if (ks < 2) return 1;

@@ -1,18 +1,27 @@
 #!/usr/bin/env bash
-# One box, the evidence of a round: HBM-traffic PMC passes (attention + regional kernels) for the current kernel sources,
-# the default bench line (train + regional halves), rocprofv3 --kernel-trace --stats of BOTH halves, SQ counter passes of the
-# attention / regional kernels. Copy gpurun_out/<tag>_* into profiles/ afterwards.        bash tools/final_gpu_run.sh <tag>
+# One box, the evidence of a round:
+#   1. the WHOLE GPU test suite (also writes gpurun_out/parity_latents.json -> profiles/, which bench.py embeds in its line)
+#   2. HBM-traffic PMC passes (attention + regional kernels) for the current kernel sources
+#   3. the default bench line (train + regional halves, cpu baselines)
+#   4. rocprofv3 --kernel-trace --stats of BOTH halves
+#   5. the JPEG-fed training step, 6. the configs[3] fusion line
+# Copy gpurun_out/<tag>_* into profiles/ afterwards.        bash tools/final_gpu_run.sh <tag>
 set -u
-TAG="${1:-r03}"
+TAG="${1:-r04}"
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$ROOT"
 O="$ROOT/gpurun_out"; mkdir -p "$O"
+rm -f "$O/parity_latents.json"
+echo "== 1. full GPU test suite"
+timeout ${TESTS_TIMEOUT:-1100} python -m pytest tests -m gpu -q -x --durations=12 > "$O/${TAG}_gpu_tests.log" 2>&1
+echo "rc=$?"; tail -16 "$O/${TAG}_gpu_tests.log" | cut -c1-200
+if [ -f "$O/parity_latents.json" ]; then cp "$O/parity_latents.json" profiles/parity_latents.json; echo "profiles/parity_latents.json refreshed: $(python -c "import json; print(len(json.load(open('profiles/parity_latents.json'))['cases']), 'cases')")"; fi
 # the HBM-traffic PMC passes belong to the attention kernel sources (bench.PMC_SOURCE_FILES): re-collected only when those changed
 if python -c "import json,bench,sys; sys.exit(0 if json.load(open('profiles/pmc_traffic.json')).get('source_sha16') == bench.kernel_source_fingerprint() else 1)" 2>/dev/null \
    && [ -z "${FORCE_PMC:-}" ]; then
-  echo "== PMC: profiles/pmc_traffic.json matches the attention kernel sources in the tree, passes not repeated"
+  echo "== 2. PMC: profiles/pmc_traffic.json matches the attention kernel sources in the tree, passes not repeated"
 else
-echo "== PMC (attn,region): sq1 sq2 fetch write"
+echo "== 2. PMC (attn,region): sq1 sq2 fetch write"
 PMC_BENCH_ARGS="--ref 0" bash tools/pmc_collect.sh attn,region > "$O/${TAG}_pmc_run.log" 2>&1
 cp "$O/pmc_attn,region.txt" "$O/${TAG}_pmc_attention_region_kernels.txt" 2>/dev/null
 python tools/pmc_traffic.py /tmp/pmc_fetch /tmp/pmc_write > "$O/${TAG}_pmc_traffic.json" 2>> "$O/${TAG}_pmc_run.log"
@@ -20,11 +29,11 @@ if python -c "import json,sys; d=json.load(open('$O/${TAG}_pmc_traffic.json')); 
   cp "$O/${TAG}_pmc_traffic.json" profiles/pmc_traffic.json; echo "pmc_traffic.json refreshed: $(python -c "import json; print(list(json.load(open('profiles/pmc_traffic.json'))['kernels']))")"
 else echo "PMC FAILED"; tail -5 "$O/${TAG}_pmc_run.log"; fi
 fi
-echo "== default bench"
+echo "== 3. default bench"
 timeout 900 python bench.py --steps 20 --warmup 5 > "$O/${TAG}_bench_train_n1.json" 2> "$O/${TAG}_bench_train_n1.err"
 tail -2 "$O/${TAG}_bench_train_n1.err"; cut -c1-260 "$O/${TAG}_bench_train_n1.json"
 cd /tmp && export TMPDIR=/tmp
-echo "== rocprofv3 kernel stats: train"
+echo "== 4. rocprofv3 kernel stats: train"
 rm -rf /tmp/prof
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o b -- python "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-regional \
     > "$O/${TAG}_bench_train_under_rocprof.json" 2> "$O/${TAG}_rocprof.err"
@@ -37,15 +46,12 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof2 -
 f=$(find /tmp/prof2 -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && head -100 "$f" > "$O/${TAG}_rocprofv3_kernel_stats_bench_regional.csv"
 cd "$ROOT"
-grep -E "attn_bwd_dkdv_kernelIDF16_Li40|conv3x3_nhwc_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_train.csv" | cut -c1-160 | head -6
-grep -E "attn_fwd_kernelIDF16_Li40|region_attn_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_regional.csv" | cut -c1-160 | head -6
+grep -E "attn_bwd_dkdv(_pipe)?_kernelIDF16_Li40|conv3x3_nhwc_kernel|gn_col_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_train.csv" | cut -c1-160 | head -8
+grep -E "attn_fwd_kernelIDF16_Li40|region_attn_kernel|gn_col_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_regional.csv" | cut -c1-160 | head -8
 cut -c1-200 "$O/${TAG}_bench_train_under_rocprof.json"; cut -c1-200 "$O/${TAG}_bench_regional_under_rocprof.json"
-
-echo "== train step fed by the JPEG data pipeline (SURVEY 8(f).4)"
+echo "== 5. train step fed by the JPEG data pipeline (SURVEY 8(f).4)"
 timeout 150 python bench.py --steps 20 --warmup 5 --data jpeg --no-cpu-baseline --no-regional > "$O/${TAG}_bench_train_jpeg.json" 2> "$O/${TAG}_bench_train_jpeg.err"
 tail -1 "$O/${TAG}_bench_train_jpeg.err"; cut -c1-200 "$O/${TAG}_bench_train_jpeg.json"
-# last, if the box still has time: the end-to-end tests the validation call did not cover (regional parity, fusion on GPU)
-echo "== remaining end-to-end tests (time-capped)"
-timeout ${TAIL_TESTS_TIMEOUT:-100} python -m pytest tests/test_gpu_end_to_end.py -m gpu -q -x -s \
-  -k "regional_sd15_hot_path_error_teacher_forced or fusion_feature_collection or hipgraph_regional" > "$O/${TAG}_tail_tests.log" 2>&1
-echo "rc=$?"; grep -E "^\[parity\]|passed|failed" "$O/${TAG}_tail_tests.log" | cut -c1-300 | tail -8
+echo "== 6. configs[3]: gradient fusion of 14 synthetic ED-LoRAs"
+timeout 420 python bench.py --mode fusion --concepts 14 --steps 2 --warmup 1 > "$O/${TAG}_bench_fusion.json" 2> "$O/${TAG}_bench_fusion.err"
+echo "rc=$?"; grep "fusion pass" "$O/${TAG}_bench_fusion.err"; cut -c1-300 "$O/${TAG}_bench_fusion.json"
