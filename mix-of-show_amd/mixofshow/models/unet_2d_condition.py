@@ -419,7 +419,7 @@ class UNet2DConditionModel(nn.Module):
         timestep = timestep.expand(sample.shape[0])
         t_emb = get_timestep_embedding(timestep, self._time_dim).to(dtype=sample.dtype)
         emb = self.time_embedding(t_emb)
-        if _batch_time_proj:
+        if _batch_time_proj and (sample.is_cuda or _batch_time_proj == 'force'):    # a launch-count optimisation of the device path
             tp = self.__dict__.get('_time_projections')
             if tp is None:
                 tp = _TimeProjections(self)

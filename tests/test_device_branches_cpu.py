@@ -273,7 +273,7 @@ def test_edlora_sampling_on_gpu_branches_fp16_vs_fp32_plain_path(emulated_hip):
 
 
 def test_batched_time_embedding_projections_equal_per_block_projections(emulated_hip, monkeypatch):
-    """MOS_BATCH_TEMB (off by default): one baddbmm per output width for the time-embedding projections of all ResNet blocks
+    """MOS_BATCH_TEMB (on by default since round 4, device tensors only): one baddbmm per output width for the time-embedding projections of all ResNet blocks
     == the per-block nn.Linear calls, in the outputs of the whole UNet; the stacks follow weight updates."""
     from mixofshow.models import unet_2d_condition as U
     from mixofshow.utils import pretrained
@@ -289,7 +289,7 @@ def test_batched_time_embedding_projections_equal_per_block_projections(emulated
 
     monkeypatch.setattr(U, '_batch_time_proj', False)
     ref = run()
-    monkeypatch.setattr(U, '_batch_time_proj', True)
+    monkeypatch.setattr(U, '_batch_time_proj', 'force')          # (the batched form is taken on device tensors only)
     got = run()
     assert unet._time_projections.usable() and len(unet._time_projections.blocks) >= 4
     assert (got - ref).abs().max() <= 1e-4 * ref.abs().max()          # (the emulated attention rounds its operands to half)

@@ -13,7 +13,7 @@ cd "$ROOT"
 O="$ROOT/gpurun_out"; mkdir -p "$O"
 rm -f "$O/parity_latents.json"
 echo "== 1. full GPU test suite"
-timeout ${TESTS_TIMEOUT:-1100} python -m pytest tests -m gpu -q -x --durations=12 > "$O/${TAG}_gpu_tests.log" 2>&1
+timeout ${TESTS_TIMEOUT:-1100} python -m pytest tests -m gpu -q --durations=12 > "$O/${TAG}_gpu_tests.log" 2>&1
 echo "rc=$?"; tail -16 "$O/${TAG}_gpu_tests.log" | cut -c1-200
 if [ -f "$O/parity_latents.json" ]; then cp "$O/parity_latents.json" profiles/parity_latents.json; echo "profiles/parity_latents.json refreshed: $(python -c "import json; print(len(json.load(open('profiles/parity_latents.json'))['cases']), 'cases')")"; fi
 # the HBM-traffic PMC passes belong to the attention kernel sources (bench.PMC_SOURCE_FILES): re-collected only when those changed
