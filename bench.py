@@ -651,6 +651,30 @@ def synthetic_edlora_checkpoints(preset, n, out_dir):
     return cfg
 
 
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X fp64 matrix (v_mfma_f64_16x16x4_f64), vendor figure; the guides give no measured one
+
+
+def fusion_roofline(lsq, gram):
+    """configs[3]: the kernel with the largest share of the job's library time is the L-BFGS closure (fp64 W.G - P on the fp64
+    matrix cores, ~45 k launches); the Gram kernel (one call per layer and concept since round 4) is reported beside it."""
+    out = None
+    if lsq:
+        top = lsq[0]
+        sec = top['avg_us'] * 1e-6
+        ach = top['flops'] / sec / 1e12
+        out = dict(kernel=top['name'], bound='mfma', achieved=round(ach, 3), peak=PEAK_FP64_MFMA_TFLOPS, unit='TFLOP/s',
+                   frac=round(ach / PEAK_FP64_MFMA_TFLOPS, 5), traffic=None, avg_us=round(top['avg_us'], 2), launches=top['calls'],
+                   dtype='f64', algorithmic_flops_per_launch=top['flops'], algorithmic_bytes_per_launch=top['bytes'],
+                   total_ms=round(sum(r['total_ms'] for r in lsq), 1))
+    if gram and out is not None:
+        g = gram[0]
+        sec = g['avg_us'] * 1e-6
+        out['gram'] = dict(kernel=g['name'], achieved_tflops=round(g['flops'] / sec / 1e12, 2), peak=PEAK_MFMA_TFLOPS,
+                           frac=round(g['flops'] / sec / 1e12 / PEAK_MFMA_TFLOPS, 5), gbps=round(g['bytes'] / sec / 1e9, 1),
+                           avg_us=round(g['avg_us'], 2), launches=g['calls'], total_ms=round(sum(r['total_ms'] for r in gram), 1))
+    return out
+
+
 def run_fusion(args, rank, world, device):
     """configs[3]: gradient_fusion.compose_concepts on 14 synthetic ED-LoRAs, iters 500 (CLIP, cross-K/V) / 50 (spatial)
     as fuse.sh:8-9; a "step" is one complete fusion. Roofline: the Gram kernel. cpu_baseline: ONE level-0 spatial layer
@@ -679,7 +703,8 @@ def run_fusion(args, rank, world, device):
         _log(f'fusion pass {i}: {dt:.1f}s')
         if i >= args.warmup:
             times.append(dt)
-    gram = [r for r in recs if r['name'].startswith('gram')]
+    gram = sorted((r for r in recs if r['name'].startswith('gram')), key=lambda r: -r['flops'])      # largest call first
+    lsq = sorted((r for r in recs if r['name'].startswith('lsq_loss_grad')), key=lambda r: -r['total_ms'])
     res = dict(metric='gradient_fusion_wall_seconds_14_edloras_sd15', value=round(statistics.mean(times), 2), unit='s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(statistics.mean(times) * 1e3, 1),
                higher_is_better=False, scaling='weak', vs_baseline=None, dtype='fp16 features / fp64 Gram + L-BFGS',
@@ -688,7 +713,7 @@ def run_fusion(args, rank, world, device):
                                     f'UNet + CLIP, L-BFGS iters {args.textenc_iters} (text encoder, cross K/V) / '
                                     f'{args.unet_iters} (spatial), saving excluded', preset=args.preset, concepts=n,
                            host_cores=os.cpu_count()),
-               roofline=roofline_from_profile(gram) if gram else None, kernels=_kernel_table(recs, 1, 10))
+               roofline=fusion_roofline(lsq, gram), kernels=_kernel_table(recs, 1, 10))
     if not args.no_cpu_baseline:
         from oracle import fusion_ref
         threads = _cpu_threads()

@@ -126,14 +126,46 @@ def parse_new_concepts(concept_cfg):
 
 
 def _solve_layers(accs, original_state_dict, iters, tag):
+    """One L-BFGS per layer on its Gram statistics (reference update_quasi_newton, :38-96). The layers are independent, and an
+    iteration is a handful of small launches plus one read-back -- the host waits on the device for most of it -- so on a HIP
+    device a few worker threads, each with its own stream, solve different layers at the same time (the wait of one overlaps
+    the dispatch of another; MOS_FUSION_THREADS, default 3; 1 = the sequential loop). Every layer's iterates are exactly the
+    sequential ones: nothing is shared between the problems."""
+    names = list(accs)
+    dev = next(iter(accs.values())).G.device if accs else torch.device('cpu')
+    workers = int(os.environ.get('MOS_FUSION_THREADS', 3)) if dev.type == 'cuda' else 1
     out = {}
-    for i, (layer_name, acc) in enumerate(accs.items()):
+
+    def solve(i):
+        layer_name, acc = names[i], accs[names[i]]
         W0 = original_state_dict[layer_name].to(torch.float32)
         logging.info(f'[{i + 1}/{len(accs)}] optimizing {layer_name} ({tag}, n={acc.n})')
         Wn, loss = lbfgs_on_gram(W0.reshape(W0.shape[0], -1), acc, iters)
         logging.info('new_concept loss: %e' % loss)
-        out[layer_name] = Wn.reshape(W0.shape)
-    return out
+        return layer_name, Wn.reshape(W0.shape)
+
+    if workers <= 1 or len(names) < 2:
+        for i in range(len(names)):
+            k, w = solve(i)
+            out[k] = w
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+    torch.cuda.synchronize(dev)                      # the statistics were accumulated on the caller's stream
+    streams = [torch.cuda.Stream(device=dev) for _ in range(workers)]
+
+    def run(slot):
+        res = []
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(streams[slot]):
+            for i in range(slot, len(names), workers):
+                res.append(solve(i))
+            streams[slot].synchronize()
+        return res
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        for res in pool.map(run, range(workers)):
+            out.update(res)
+    return {k: out[k] for k in names}                # the json order of the sequential loop
 
 
 def merge_kv_in_cross_attention(concept_list, optimize_iters, new_concept_cfg, tokenizer, text_encoder, unet,
@@ -216,7 +248,7 @@ def merge_text_encoder(concept_list, optimize_iters, new_concept_cfg, tokenizer,
         keys |= {k.replace('.lora_down', '').replace('.lora_up', '') for k in lora.keys()}
     layer_names = sorted(keys)
     logging.info(f'text_encoder have {len(layer_names)} linear layer need to optimize')
-    rec = _Recorder(device)
+    rec = _Recorder(device, batch_rows=(1 << 20) if torch.device(device).type == 'cuda' else 0)   # one Gram call per layer and concept
     mods = dict(text_encoder.named_modules())
     handles = []
     for wname in layer_names:
@@ -232,6 +264,7 @@ def merge_text_encoder(concept_list, optimize_iters, new_concept_cfg, tokenizer,
         rec.enabled = True
         get_text_feature(prompts, tokenizer, text_encoder, device)
         rec.enabled = False
+        rec.flush()
     for h in handles:
         h.remove()
     text_encoder.load_state_dict(original)

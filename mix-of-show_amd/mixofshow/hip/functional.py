@@ -648,7 +648,7 @@ class _GroupNormSiLU(torch.autograd.Function):
         x, gamma, beta, stats = ctx.saved_tensors
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        if dy.stride() != x.stride():
+        if not ops._same_layout(dy, x):
             dy = dy.contiguous(memory_format=torch.channels_last) if ops._is_nhwc(x) else dy.contiguous()
         return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
 
@@ -674,12 +674,12 @@ class _GroupNormSiLUTap(torch.autograd.Function):
             return ds, None, None, None, None, None
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
-        if dy.stride() != x.stride():
+        if not ops._same_layout(dy, x):
             dy = dy.contiguous(memory_format=torch.channels_last) if ops._is_nhwc(x) else dy.contiguous()
         if ds is None:
             return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
         if ops._is_nhwc(x) and ds.dtype == x.dtype and ds.shape == x.shape:
-            if ds.stride() != x.stride():              # e.g. a channel slice of a concatenated gradient
+            if not ops._same_layout(ds, x):            # e.g. a channel slice of a concatenated gradient
                 ds = ds.contiguous(memory_format=torch.channels_last)
             return (ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu, ds=ds), None, None, None, None,
                     None)

@@ -398,6 +398,11 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
 # ------------------------------------------------------------------------------------------------
 # fused GroupNorm (+ SiLU) — caller-side plumbing kernel
 # ------------------------------------------------------------------------------------------------
+def _same_layout(a, b):
+    """Same shape and the same strides on every dimension of extent > 1 (the stride of a size-1 dimension is arbitrary)."""
+    return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n > 1)
+
+
 def _is_nhwc(x):
     return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
 
@@ -432,10 +437,10 @@ def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None):
     dx = torch.empty_like(x)
     L = _lib.load()
     if _is_nhwc(x):
-        assert dy.stride() == x.stride()
+        assert _same_layout(dy, x)
         ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
         if ds is not None:
-            assert ds.stride() == x.stride() and ds.dtype == x.dtype and ds.shape == x.shape
+            assert _same_layout(ds, x) and ds.dtype == x.dtype
             _lib.check(L.mos_groupnorm_silu_bwd_nhwc_res(_p(dy), _p(ds), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws),
                                                          B, C, HW, groups, int(bool(silu)), _dt(x), _stream()),
                        'mos_groupnorm_silu_bwd_nhwc_res')
@@ -604,7 +609,8 @@ def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=Fal
     if tbias is not None:
         assert tbias.shape == (B, Cout) and tbias.dtype == x.dtype and tbias.is_contiguous()
     if residual is not None:
-        assert residual.shape == y.shape and residual.dtype == x.dtype and residual.stride() == y.stride()
+        # (memory-format check, not a stride comparison: the stride of a size-1 dimension -- batch 1, a 1x1 map -- is arbitrary)
+        assert residual.shape == y.shape and residual.dtype == x.dtype and residual.is_contiguous(memory_format=torch.channels_last)
     L = _lib.load()
     nbytes = L.mos_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout)      # > 0: the split-K form of the low-resolution levels
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device) if nbytes > 0 else None
