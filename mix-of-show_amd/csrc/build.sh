@@ -15,6 +15,12 @@ pids=()
 # The VGPR form keeps them in arch VGPRs (main-loop VALU count -40 %; region kernels -15..-26 % measured, parity
 # unchanged). Two-wave kernels (d = 40) compile to the same code either way.
 EXTRA_mos_attn="-mllvm -amdgpu-mfma-vgpr-form=1 ${MOS_ATTN_FLAGS:-}"
+# mos_gemm / mos_conv (round 4): in the AccVGPR form the DMA-ring variants (3-4 stage K loops of the small grids) come out of
+# register allocation with 20-50 v_accvgpr_read/write/mov per K tile rotating the accumulator tuples (64x64 GEMM ring: 42 VALU
+# for 8 MFMAs, fused 64x128 ring: 94 for 20); the VGPR form has none (22 / 38). VALU and MFMA time add up on this chip.
+# MOS_MFMA_FORM_FLAGS="" restores the AccVGPR form for an A/B build.
+EXTRA_mos_gemm="${MOS_MFMA_FORM_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1}"
+EXTRA_mos_conv="${MOS_MFMA_FORM_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1}"
 for f in ${SRCS}; do
   extra_var="EXTRA_${f}"
   src="${HERE}/${f}.hip"

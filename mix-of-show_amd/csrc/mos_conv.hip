@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
         m_tile = (slot / a.nt) * 8 + (w & 7);
         if (m_tile >= a.mt) return;
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: the LDS-DMA destinations (M0) become SALU values
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lg = lane >> 4;
     const int n0 = n_tile * BN, m0 = m_tile * BM;
     const int M = a.M, N = a.Cout, C = a.Cin, H = a.H, Wd = a.Wd;
@@ -98,13 +99,24 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     // this lane's 16-byte slot in a wave-instruction: row = slot / 8, physical chunk = slot % 8 -> logical chunk
     const int cc8 = ((tid & 7) ^ ((tid >> 3) & 7)) * 8;
     int py[XCH], px[XCH], rowoff[XCH], woff[WCH];
+    // tapmask[i] bit t: tap t of this thread's pixel row i lies inside the image (and the row inside M). Round 4: the nine
+    // validity tests per pixel are made ONCE here instead of per K tile -- the main loop of the 64 x 64 configuration carried 34
+    // VALU (4 compares + selects + an exec-masked branch per staged chunk, a readfirstlane per DMA destination) for 8 MFMAs, and
+    // on this chip VALU and MFMA time add up.
+    [[maybe_unused]] uint32_t tapmask[XCH];
 #pragma unroll
     for (int i = 0; i < XCH; ++i) {
         const int m = m0 + ((tid + 256 * i) >> 3);
+        tapmask[i] = 0u;
         if (m < M) {
             const int b = m / (H * Wd), p = m - b * (H * Wd);
             py[i] = p / Wd; px[i] = p - py[i] * Wd;
             rowoff[i] = UP ? b * Hs : (((b * Hs + py[i]) * Ws_ + px[i]) * C + cc8) * (int)sizeof(T);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = py[i] + t / 3 - 1, xx = px[i] + t % 3 - 1;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < Wd) tapmask[i] |= 1u << t;
+            }
         } else {
             py[i] = -100000; px[i] = 0; rowoff[i] = 0;
         }
@@ -128,14 +140,18 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
         T* xs = Xs + buf * BM * CBK + wave * 512;
         T* ws = Ws + buf * BN * CBK + wave * 512;
         const int delta = ((dy * Ws_ + dx) * C + cch * CBK) * (int)sizeof(T);      // non-upsampled source: linear in the tap
+        if constexpr (UP) {
 #pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int yy = py[i] + dy, xx = px[i] + dx;
-            const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
-            int off;
-            if (UP) off = (((rowoff[i] + (yy >> 1)) * Ws_ + (xx >> 1)) * C + cch * CBK + cc8) * (int)sizeof(T);
-            else off = rowoff[i] + delta;
-            dma16(xsrc, xs + i * 2048, ok ? off : OOB);
+            for (int i = 0; i < XCH; ++i) {
+                const int yy = py[i] + dy, xx = px[i] + dx;
+                const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+                const int off = (((rowoff[i] + (yy >> 1)) * Ws_ + (xx >> 1)) * C + cch * CBK + cc8) * (int)sizeof(T);
+                dma16(xsrc, xs + i * 2048, ok ? off : OOB);
+            }
+        } else {
+            const uint32_t tbit = live ? (1u << tap) : 0u;          // uniform: tap and `live` are scalars
+#pragma unroll
+            for (int i = 0; i < XCH; ++i) dma16(xsrc, xs + i * 2048, (tapmask[i] & tbit) ? rowoff[i] + delta : OOB);
         }
         const int kb = kt * CBK * (int)sizeof(T);
 #pragma unroll

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: LDS-DMA destinations (M0) become SALU values
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
     const int n0 = n_tile * BN;
