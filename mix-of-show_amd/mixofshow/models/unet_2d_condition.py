@@ -26,15 +26,27 @@ from mixofshow.hip.functional import (add_layer_norm, conv1x1, conv3x3, geglu, g
 from mixofshow.models.attention import Attention
 
 
+_freq_cache = {}
+
+
+def _timestep_frequencies(half, downscale_freq_shift, max_period, device):
+    """exp(-ln(max_period) * k / (half - shift)), k < half: a constant of the model, kept per device (4 tiny launches per UNet
+    call otherwise). Not memoised while a hipGraph is being captured (the tensor would live in the graph's private pool)."""
+    key = (half, float(downscale_freq_shift), float(max_period), str(device))
+    f = _freq_cache.get(key)
+    if f is None:
+        exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=device)
+        f = torch.exp(exponent / (half - downscale_freq_shift))
+        if not (f.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+            _freq_cache[key] = f
+    return f
+
+
 def get_timestep_embedding(timesteps, dim, flip_sin_to_cos=True, downscale_freq_shift=0.0, max_period=10000):
     half = dim // 2
-    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=timesteps.device)
-    exponent = exponent / (half - downscale_freq_shift)
-    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
-    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
-    if flip_sin_to_cos:
-        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
-    return emb
+    emb = timesteps[:, None].float() * _timestep_frequencies(half, downscale_freq_shift, max_period, timesteps.device)[None, :]
+    # (diffusers: cat([sin, cos]) and, with flip_sin_to_cos, a second cat that swaps the halves -- the same values, one launch)
+    return torch.cat([torch.cos(emb), torch.sin(emb)] if flip_sin_to_cos else [torch.sin(emb), torch.cos(emb)], dim=-1)
 
 
 class TimestepEmbedding(nn.Module):
@@ -85,9 +97,11 @@ class _TimeProjections:
         self.key, self.groups = None, []
 
     def usable(self):
+        # (under no_grad -- every sampling pipeline -- ordinary requires_grad=True modules count as frozen, cf. functional._frozen)
+        grad = torch.is_grad_enabled()
         return bool(self.blocks) and all(
-            not (p.weight.requires_grad or p.bias is None or p.bias.requires_grad or p._forward_hooks or p._forward_pre_hooks)
-            and type(p) is nn.Linear for p in (b.time_emb_proj for b in self.blocks))
+            not (p.bias is None or (grad and (p.weight.requires_grad or p.bias.requires_grad)) or p._forward_hooks
+                 or p._forward_pre_hooks) and type(p) is nn.Linear for p in (b.time_emb_proj for b in self.blocks))
 
     def __call__(self, act):
         key = tuple((b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version,

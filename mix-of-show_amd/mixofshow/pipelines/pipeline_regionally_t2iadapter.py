@@ -37,10 +37,18 @@ class RegionT2I_AttnProcessor:
         self.cross_attention_idx = cross_attention_idx
         self._kv_key = None
         self._kv = None
+        self._cd = None
 
     def reset_cache(self):
         self._kv_key = None
         self._kv = None
+
+    def refresh_source_kv(self, attn, encoder_hidden_states, region_list, cd):
+        """Recompute the cached source K/V for new prompt / region embeddings WITHOUT running the layer: what step 0 of a call
+        does as a side effect. The pipeline calls it before replaying a graph captured by an earlier call (the graph reads the
+        buffer `_kv` by address; `_source_kv` refills it in place)."""
+        with torch.no_grad():
+            return self._source_kv(attn, self._layer_states(encoder_hidden_states), region_list, cd)
 
     def _layer_states(self, states):
         return states[:, self.cross_attention_idx] if states.dim() == 4 else states
@@ -78,6 +86,7 @@ class RegionT2I_AttnProcessor:
         feat_h, feat_w = int(height // downscale), int(width // downscale)
         assert feat_h * feat_w == n_tok, f'{n_tok} tokens do not form a {feat_h}x{feat_w} map'
         cd = F_hip.compute_dtype_for(hidden_states)
+        self._cd = cd
         with torch.no_grad():
             kv = self._source_kv(attn, context, region_list, cd)
         C = kv.shape[-1] // 2
@@ -213,17 +222,32 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
         region_list = []
         if prompt_embeds is None:
             context_prompt, regions = prompt[0][0], prompt[0][1]
-            pos = self._encode(bind_concept_prompt([context_prompt], new_concept_cfg), device)
-            pos = pos.reshape(batch_size, -1, *pos.shape[1:])
+            # ONE text-encoder forward over all prompts of the call (the reference runs 2 + 2R of them, :237-296: the same
+            # rows, a sequence's embedding does not depend on its batch neighbours) -- an eager CLIP forward is ~130 launches
+            groups, texts, spans = [], [], {}
+
+            def want(strs):
+                strs = [strs] if isinstance(strs, str) else list(strs)
+                key = tuple(strs)
+                if key not in spans:                         # (the negative prompts of the regions are usually one string)
+                    spans[key] = (len(texts), len(texts) + len(strs))
+                    texts.extend(strs)
+                groups.append(spans[key])
+
+            want(bind_concept_prompt([context_prompt], new_concept_cfg))
+            want(negative_prompt if negative_prompt is not None else [''] * batch_size)
+            for region_prompt, region_neg, _ in regions:
+                want(bind_concept_prompt([region_prompt], new_concept_cfg))
+                want(region_neg if region_neg is not None else [''] * batch_size)
+            emb = self._encode(texts, device)
+            parts = [emb[a:b] for a, b in groups]
+            pos = parts[0].reshape(batch_size, -1, *emb.shape[1:])
             layer_num, seq_len = pos.shape[1], pos.shape[2]
-            neg = self._encode(negative_prompt if negative_prompt is not None else [''] * batch_size, device)
-            neg = neg.view(batch_size, 1, seq_len, -1).repeat(1, layer_num, 1, 1)
+            neg = parts[1].view(batch_size, 1, seq_len, -1).repeat(1, layer_num, 1, 1)
             prompt_embeds = torch.cat([neg, pos])
-            for region_prompt, region_neg, box in regions:
-                rp = self._encode(bind_concept_prompt([region_prompt], new_concept_cfg), device)
-                rp = rp.reshape(batch_size, -1, *rp.shape[1:])
-                rn = self._encode(region_neg if region_neg is not None else [''] * batch_size, device)
-                rn = rn.view(batch_size, 1, seq_len, -1).repeat(1, layer_num, 1, 1)
+            for k, (_, _, box) in enumerate(regions):
+                rp = parts[2 + 2 * k].reshape(batch_size, -1, *emb.shape[1:])
+                rn = parts[3 + 2 * k].view(batch_size, 1, seq_len, -1).repeat(1, layer_num, 1, 1)
                 region_list.append((torch.cat([rn, rp]), box))
         return prompt_embeds, region_list
 
@@ -279,6 +303,9 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
                 adapter_states = kp if kp is not None else sk
         if adapter_states is not None and do_cfg:
             adapter_states = [torch.cat([s] * 2, dim=0) if s.shape[0] == batch_size else s for s in adapter_states]
+        if adapter_states is not None and getattr(self.unet, 'channels_last', False):
+            # the layout of the activations they are added to, once per call (a mixed-layout add is a strided kernel, x 4 x 50)
+            adapter_states = [s.contiguous(memory_format=torch.channels_last) for s in adapter_states]
         # hipGraph replay (`hipgraph=None` -> hipgraph_util.sampling_default(), on): step 0 runs eagerly (it fills the
         # per-layer source K/V caches), the UNet call is captured at step 1 and replayed from then on: 544 vs 774 ms per
         # 50-step sample. Not with forward hooks on the UNet (they would only run at capture time).
@@ -328,14 +355,23 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
         # prompts can re-use the very same addresses (caching allocator), so every call starts with stale caches
         for proc in procs:
             proc.reset_cache()
+        replay_from = 1
         if graphed is not None:
             # the graph reads the K/V buffers it was captured with (an eager call in between gave the processors new ones):
-            # hand them back, stale, so that step 0 of this call refreshes exactly those
-            for proc, buf in ent.kv:
+            # hand them back, stale, and refill exactly those from this call's embeddings. With every cross-attention layer
+            # refreshed that way step 0 is a replay as well (an eager UNet call is ~1.4 k launches, dispatcher-bound);
+            # otherwise (no regions: the layers keep no source cache) step 0 runs eagerly as in the capturing call.
+            for proc, buf, attn, cd in ent.kv:
                 proc._kv = buf
+                if len(region_list) > 0:
+                    proc.refresh_source_kv(attn, prompt_embeds, region_list, cd)
+            if len(region_list) > 0 and ent.kv and len(ent.kv) == ent.n_cross:
+                replay_from = 0
 
         def unet_call(x, t):
-            residuals = [s.clone() for s in adapter_states] if adapter_states is not None else None
+            # (the UNet pops the LIST and adds the tensors to its activations -- `sample += r`, `x + r` -- it never writes to
+            # them: a fresh list per call, no clones; the reference clones because diffusers' UNet may add in place into them)
+            residuals = list(adapter_states) if adapter_states is not None else None
             return self.unet(x, t, encoder_hidden_states=prompt_embeds, cross_attention_kwargs=cak,
                              down_block_additional_residuals=residuals).sample
 
@@ -349,10 +385,14 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
                 self.last_call_graphed = hipgraph
                 if ent is not None:
                     ent.graphed = graphed
-                    ent.kv = [(proc, proc._kv) for proc in procs if proc._kv is not None]   # owned by the entry
+                    ent.kv = [(m.processor, m.processor._kv, m, m.processor._cd) for m in self.unet.modules()
+                              if isinstance(getattr(m, 'processor', None), RegionT2I_AttnProcessor)
+                              and m.processor._kv is not None]                        # buffers owned by the entry
+                    ent.n_cross = sum(1 for n, m in self.unet.named_modules()
+                                      if isinstance(getattr(m, 'processor', None), RegionT2I_AttnProcessor) and n.endswith('attn2'))
                     if graphed is None:
                         self._sampling_graphs.pop(gkey, None)
-            use_graph = graphed is not None and i >= 1
+            use_graph = graphed is not None and i >= replay_from
             noise_pred = graphed(model_in, t) if use_graph else unet_call(model_in, t)
             if do_cfg:
                 uncond, text = noise_pred.chunk(2)

@@ -299,8 +299,10 @@ def test_batched_time_embedding_projections_equal_per_block_projections(emulated
     monkeypatch.setattr(U, '_batch_time_proj', False)
     ref2 = run()
     assert not torch.allclose(ref2, ref) and (got2 - ref2).abs().max() <= 1e-4 * ref2.abs().max()
-    unet.down_blocks[0].resnets[0].time_emb_proj.weight.requires_grad_(True)      # trainable projection: not batched
+    unet.down_blocks[0].resnets[0].time_emb_proj.weight.requires_grad_(True)      # trainable projection: not batched ...
     assert not unet._time_projections.usable()
+    with torch.no_grad():                 # ... except under no_grad: the sampling pipelines never freeze their modules, and the
+        assert unet._time_projections.usable()      # round-4 rocprofv3 trace of the regional sample showed 24 tiny GEMMs per call
 
 
 # ---- round 4: GEMM epilogues (residual add, GEGLU) on the feed-forward and the 1x1 proj_out -------------------------------

@@ -181,3 +181,90 @@ def test_adapter_region_weighting_vs_reference_golden(golden):
         assert len(got) == len(case['out']) == 4
         for g, r in zip(got, case['out']):
             torch.testing.assert_close(g, r, rtol=1e-6, atol=1e-6, msg=name)
+
+
+def test_region_prompts_are_encoded_in_one_forward_with_the_rows_of_separate_forwards(emulated_hip):
+    """`_encode_region_prompt` runs ONE text-encoder forward over every prompt of the call (the reference: 2 + 2R forwards,
+    pipeline_regionally_t2iadapter.py:237-296); the rows must be the ones separate forwards give, in the reference's layout:
+    context (2, 16, 77, C) = cat[neg, pos], per region (cat[neg_r, pos_r], box)."""
+    from mixofshow.pipelines.pipeline_edlora import bind_concept_prompt
+    from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionallyT2IAdapterPipeline
+    pipe = RegionallyT2IAdapterPipeline.from_pretrained('synthetic://tiny?seed=0', torch_dtype=torch.float32)
+    cfg = _concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>', '<hermione1>', '<hermione2>'])
+    pipe.set_new_concept_cfg(cfg)
+    neg = 'lowres, bad anatomy'
+    regions = [('a <potter1> <potter2>, in uniform', neg, [0.0, 0.0, 1.0, 0.45]),
+               ('a <hermione1> <hermione2>, girl', 'blurry', [0.1, 0.4, 0.9, 1.0]),
+               ('a castle', None, [0.5, 0.2, 0.75, 0.7])]
+    calls = []
+    real = pipe.text_encoder.forward
+    pipe.text_encoder.forward = lambda *a, **k: (calls.append(a[0].shape[0]), real(*a, **k))[1]
+    emb, region_list = pipe._encode_region_prompt([('three people near the castle', regions)], cfg, 'cpu', 1, True, [neg])
+    pipe.text_encoder.forward = real
+    assert calls == [16 + 1 + 16 + 16 + 1 + 16 + 1]            # one forward; the repeated negative prompt is encoded once
+    enc = lambda strs: pipe._encode(strs, 'cpu')               # noqa: E731
+    pos = enc(bind_concept_prompt(['three people near the castle'], cfg))
+    assert emb.shape == (2, 16, 77, pos.shape[-1]) and len(region_list) == 3
+    torch.testing.assert_close(emb[1], pos, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(emb[0], enc([neg]).expand(16, -1, -1), rtol=1e-5, atol=1e-6)
+    for (r_emb, box), (text, rneg, rbox) in zip(region_list, regions):
+        assert box == rbox and r_emb.shape == emb.shape
+        torch.testing.assert_close(r_emb[1], enc(bind_concept_prompt([text], cfg)), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(r_emb[0], enc([rneg if rneg is not None else '']).expand(16, -1, -1), rtol=1e-5, atol=1e-6)
+
+
+def test_cached_sampling_graph_replays_step_0_after_an_explicit_kv_refresh(emulated_hip, monkeypatch):
+    """A later call of the same layout refills the processors' source-K/V buffers from ITS embeddings
+    (`refresh_source_kv`) and replays the captured UNet call for every step, step 0 included. The replay is emulated by a
+    callable that -- like a hipGraph -- runs no host code of the processors' cache logic: it reads the K/V buffers that were
+    current at capture time, whatever they hold. The second call must equal an eager call with ITS prompts."""
+    from mixofshow.pipelines import pipeline_regionally_t2iadapter as P
+    from mixofshow.utils import hipgraph as G
+    H, W = 64, 96
+    pipe = P.RegionallyT2IAdapterPipeline.from_pretrained('synthetic://tiny?seed=0', torch_dtype=torch.float32)
+    pipe.set_new_concept_cfg(_concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>']))
+    latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(5))
+    replays = []
+
+    class _FakeGraph:
+        def __init__(self, fn, *example):
+            self.fn = fn
+            self.frozen = [(m.processor, m.processor._kv) for m in pipe.unet.modules()
+                           if isinstance(getattr(m, 'processor', None), P.RegionT2I_AttnProcessor) and m.processor._kv is not None]
+
+        def __call__(self, x, t):
+            replays.append(int(t))
+            real = P.RegionT2I_AttnProcessor._source_kv
+            bufs = {id(p): b for p, b in self.frozen}
+            monkeypatch.setattr(P.RegionT2I_AttnProcessor, '_source_kv', lambda self_, *a: bufs[id(self_)])
+            try:
+                return self.fn(x, t)
+            finally:
+                monkeypatch.setattr(P.RegionT2I_AttnProcessor, '_source_kv', real)
+
+    monkeypatch.setattr(G, 'graphs_usable', lambda device: True)
+    monkeypatch.setattr(G, 'try_capture', lambda fn, *ex: _FakeGraph(fn, *ex))
+
+    def run(text, graph):
+        prompt = [('two people', [(text, '', [0.0, 0.0, 1.0, 0.6]), ('a dog', 'blurry', [0.2, 0.5, 0.9, 1.0])])]
+        return pipe(prompt=prompt, negative_prompt=[''], height=H, width=W, num_inference_steps=5, guidance_scale=7.5,
+                    latents=latents.clone(), output_type='latent', hipgraph=graph).images
+
+    a_graph = run('a <potter1> <potter2>', True)
+    n_first = len(replays)
+    assert pipe.last_call_graphed and n_first == 4                 # capturing call: step 0 eager, steps 1..4 replayed
+    b_graph = run('a red car', True)
+    assert len(replays) - n_first == 5, 'a cached graph replays every step, step 0 included'
+    b_eager = run('a red car', False)
+    a_eager = run('a <potter1> <potter2>', False)
+    torch.testing.assert_close(b_graph, b_eager, rtol=0, atol=0)
+    torch.testing.assert_close(a_graph, a_eager, rtol=0, atol=0)
+    assert not torch.allclose(a_eager, b_eager)
+    # no regions: the layers keep no source cache, so step 0 of a cached layout stays eager (and the result is the eager one)
+    plain = [('two people', [])]
+    kw = dict(negative_prompt=[''], height=H, width=W, num_inference_steps=5, guidance_scale=7.5, output_type='latent')
+    p1 = pipe(prompt=plain, latents=latents.clone(), hipgraph=True, **kw).images
+    n = len(replays)
+    p2 = pipe(prompt=plain, latents=latents.clone(), hipgraph=True, **kw).images
+    assert len(replays) - n == 4
+    torch.testing.assert_close(p1, p2, rtol=0, atol=0)
