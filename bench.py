@@ -604,7 +604,9 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
                                     'latent out (SURVEY 8(d) cfg #5)',
                            replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all()) and img_ok,
                            hipgraph=graphed, graph_reused_across_calls=graphed,
-                           timed_calls='steady state: same layout as the warm-up calls, UNet graph captured there and replayed; '
+                           steady_state_eager_steps=int(getattr(pipe, 'last_call_replay_from', 1)) if graphed else 50,
+                           timed_calls='steady state: same layout as the warm-up calls, UNet graph captured there and replayed '
+                                       '(all 50 steps once the source K/V buffers are refilled explicitly); '
                                        'cold_call_ms = first call of the layout (eager step 0 + capture)',
                            adapter_feature_std=adapter_stds,
                            channels_last=bool(args.channels_last), host_cores=os.cpu_count(),

@@ -376,6 +376,7 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
                              down_block_additional_residuals=residuals).sample
 
         self.last_call_graphed = graphed is not None
+        self.last_call_replay_from = replay_from if graphed is not None else 1     # first step served by the graph
         for i, t in enumerate(timesteps):
             model_in = torch.cat([latents] * 2) if do_cfg else latents
             model_in = self.scheduler.scale_model_input(model_in, t)
