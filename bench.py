@@ -585,6 +585,7 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
     sample(graph, image_out=False)
     dt_lat, out = timed(steps, image_out=False)
     graphed = bool(getattr(pipe, 'last_call_graphed', False))
+    eager_steps = int(getattr(pipe, 'last_call_replay_from', 1)) if graphed else 50     # (read before the profiled eager pass)
     import numpy as np
     img_ok = (len(images) == 1 and images[0].size == (W, H) and bool(np.isfinite(np.asarray(images[0], dtype=np.float32)).all()))
     recs = []
@@ -604,7 +605,7 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
                                     'latent out (SURVEY 8(d) cfg #5)',
                            replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all()) and img_ok,
                            hipgraph=graphed, graph_reused_across_calls=graphed,
-                           steady_state_eager_steps=int(getattr(pipe, 'last_call_replay_from', 1)) if graphed else 50,
+                           steady_state_eager_steps=eager_steps,
                            timed_calls='steady state: same layout as the warm-up calls, UNet graph captured there and replayed '
                                        '(all 50 steps once the source K/V buffers are refilled explicitly); '
                                        'cold_call_ms = first call of the layout (eager step 0 + capture)',
