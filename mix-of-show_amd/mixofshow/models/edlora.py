@@ -50,6 +50,20 @@ def attach_layer_major_states(states):
     return states
 
 
+def refresh_layer_major_states(states):
+    """After an IN-PLACE update of `states` (a sampling pipeline refilling the static prompt embedding a captured hipGraph
+    reads): rewrite the attached layer-major copy in place as well -- the graph holds the addresses of its slices -- and
+    re-key it to the new version. No-op when nothing is attached."""
+    ent = getattr(states, '_mos_layers', None)
+    if ent is None:
+        return states
+    with torch.no_grad():
+        for dst, src in zip(ent[1], states.transpose(0, 1).unbind(0)):
+            dst.copy_(src)
+    states._mos_layers = (states._version, ent[1], ent[2])
+    return states
+
+
 def _select_layer_states(encoder_hidden_states, idx):
     # (B, 16, 77, 768) layer-wise ED-LoRA embedding -> this layer's slice (reference :56-59, :130-133)
     if encoder_hidden_states is not None and encoder_hidden_states.dim() == 4:

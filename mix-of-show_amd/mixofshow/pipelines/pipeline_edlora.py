@@ -220,28 +220,60 @@ class StableDiffusionPipeline:
         latents = self.prepare_latents(batch_size * num_images_per_prompt, self.unet.in_channels, height, width,
                                        prompt_embeds.dtype, device, generator, latents)
 
-        def unet_call(x, t):
-            return self.unet(x, t, encoder_hidden_states=prompt_embeds,
-                             cross_attention_kwargs=cross_attention_kwargs).sample
-
         # hipGraph replay (`hipgraph=None` -> hipgraph_util.sampling_default(), on; not with an attention-recording
         # controller or forward hooks, which keep Python-side state per call): step 0 is eager, the UNet call is
-        # captured at step 1 and replayed afterwards.
+        # captured at step 1 and replayed afterwards. The graph is kept ACROSS calls of the same shape (a validation loop
+        # samples many prompts at one resolution): everything it reads besides (latents, t) is the prompt embedding -- a
+        # static tensor that a later call refills in place, together with its layer-major copy -- so a later call replays
+        # all steps instead of paying an eager step and a capture per prompt.
+        from mixofshow.models import edlora
         from mixofshow.utils import hipgraph as hipgraph_util
         if hipgraph is None:
             hipgraph = hipgraph_util.sampling_default()
         hipgraph = (bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
                     and not hasattr(self, 'controller') and not hipgraph_util.has_forward_hooks(self.unet))
-        graphed = None
-        self.last_call_graphed = False
+        graphed, ent, replay_from = None, None, 1
+        if hipgraph and cross_attention_kwargs is None:
+            # (model epoch: see RegionallyT2IAdapterPipeline.__call__ -- weights, derived weight copies, processor objects)
+            epoch = (hipgraph_util.model_epoch(self.unet),
+                     tuple(id(getattr(m, 'processor', None)) for m in self.unet.modules() if hasattr(m, 'processor')))
+            gkey = (tuple(prompt_embeds.shape), prompt_embeds.dtype, height, width, bool(do_cfg), tuple(latents.shape))
+            cache = self.__dict__.setdefault('_sampling_graphs', {})
+            ent = cache.get(gkey)
+            if ent is not None and ent.epoch != epoch:
+                cache.pop(gkey)
+                ent = None
+            if ent is None:
+                ent = SimpleNamespace(pe=prompt_embeds.clone(), graphed=None, epoch=epoch)
+                while len(cache) >= 2:                       # at most two shapes resident (graphs pin their memory pools)
+                    cache.pop(next(iter(cache)))
+                cache[gkey] = ent
+            else:
+                ent.pe.copy_(prompt_embeds)
+                edlora.refresh_layer_major_states(ent.pe)
+            prompt_embeds, graphed = ent.pe, ent.graphed
+            if graphed is not None:
+                replay_from = 0
+
+        def unet_call(x, t):
+            return self.unet(x, t, encoder_hidden_states=prompt_embeds,
+                             cross_attention_kwargs=cross_attention_kwargs).sample
+
+        self.last_call_graphed = graphed is not None
+        self.last_call_replay_from = replay_from
         for i, t in enumerate(timesteps):
             model_in = torch.cat([latents] * 2) if do_cfg else latents
             model_in = self.scheduler.scale_model_input(model_in, t)
-            if hipgraph and i == 1:
+            if hipgraph and i == 1 and graphed is None:
                 graphed = hipgraph_util.try_capture(unet_call, model_in, t)
                 hipgraph = graphed is not None
                 self.last_call_graphed = hipgraph
-            noise_pred = graphed(model_in, t) if graphed is not None else unet_call(model_in, t)
+                if ent is not None:
+                    ent.graphed = graphed
+                    if graphed is None:
+                        self._sampling_graphs.pop(gkey, None)
+            use_graph = graphed is not None and i >= replay_from
+            noise_pred = graphed(model_in, t) if use_graph else unet_call(model_in, t)
             if do_cfg:
                 uncond, text = noise_pred.chunk(2)
                 noise_pred = uncond + guidance_scale * (text - uncond)

@@ -426,6 +426,43 @@ def test_regional_sampling_graph_is_reused_across_calls_and_refreshed():
     assert d_b <= 0.05 and d_a <= 0.05 and _absmax(a_graph - a_again) / scale <= 0.05
 
 
+def test_edlora_sampling_graph_is_reused_across_calls_and_refreshed():
+    """EDLoRAPipeline keeps the captured UNet graph across calls of one shape (a validation loop samples many prompts): the
+    static prompt embedding and its layer-major copy are refilled in place and ALL steps of a later call are replays. A second
+    call with ANOTHER prompt must reproduce the eager result of that prompt, and be faster than a capturing call."""
+    import time
+    from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline
+    pipe = EDLoRAPipeline.from_pretrained('synthetic://small?seed=0', torch_dtype=torch.float16).to(DEV)
+    pipe.set_new_concept_cfg(_concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>']))
+    latents = torch.randn((1, 4, 64, 64), generator=torch.manual_seed(1))
+
+    def run(prompt, g):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = pipe(prompt=prompt, negative_prompt='blurry', height=512, width=512, num_inference_steps=12, guidance_scale=7.5,
+                   latents=latents.clone(), output_type='latent', hipgraph=g).images.float()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+
+    pa, pb = 'a <potter1> <potter2> in the park', 'a photo of a dog on the beach'
+    run(pa, False)                                                     # warm the weight caches
+    a_graph, t_capture = run(pa, True)
+    assert pipe.last_call_graphed and pipe.last_call_replay_from == 1 and len(pipe._sampling_graphs) == 1
+    b_graph, t_replay = run(pb, True)
+    assert pipe.last_call_graphed and pipe.last_call_replay_from == 0 and len(pipe._sampling_graphs) == 1
+    b_eager, t_eager = run(pb, False)
+    a_eager, _ = run(pa, False)
+    a_again, _ = run(pa, True)
+    scale = max(1.0, _absmax(b_eager))
+    d_b, d_a, d_ab = _absmax(b_graph - b_eager) / scale, _absmax(a_again - a_eager) / scale, _absmax(a_eager - b_eager) / scale
+    print(f'[parity] edlora graph reuse (small, 12 steps): replayed vs eager, prompt B {d_b:.3e}, prompt A again {d_a:.3e}; '
+          f'prompts A vs B differ by {d_ab:.3e}; call latency: capturing {t_capture * 1e3:.0f} ms, replaying {t_replay * 1e3:.0f} ms, '
+          f'eager {t_eager * 1e3:.0f} ms')
+    assert d_ab > 20 * max(d_a, d_b, 1e-4), 'fixture: the two prompts should give clearly different latents'
+    assert d_b <= 0.05 and d_a <= 0.05 and _absmax(a_graph - a_again) / scale <= 0.05
+    assert t_replay < t_capture
+
+
 def test_pipeline_call_equals_written_out_loop():
     """The product's own `pipe(...)` entry points run the loop the teacher-forced tests write out: same latent after
     the first scheduler update (later steps inherit MIOpen's run-to-run noise; the final latent is a report)."""

@@ -268,3 +268,57 @@ def test_cached_sampling_graph_replays_step_0_after_an_explicit_kv_refresh(emula
     p2 = pipe(prompt=plain, latents=latents.clone(), hipgraph=True, **kw).images
     assert len(replays) - n == 4
     torch.testing.assert_close(p1, p2, rtol=0, atol=0)
+
+
+def test_edlora_pipeline_keeps_its_sampling_graph_across_calls(gpu_branches, monkeypatch):
+    """EDLoRAPipeline / StableDiffusionPipeline: a later call of the same shape refills the static prompt embedding AND its
+    layer-major copy in place and replays the captured UNet call for every step. The replay is emulated by a callable that
+    reads the layer-major slices that existed at capture time (a hipGraph holds their addresses), whatever they contain."""
+    from mixofshow.models import edlora
+    from mixofshow.pipelines.pipeline_edlora import EDLoRAPipeline
+    from mixofshow.utils import hipgraph as G
+    pipe = EDLoRAPipeline.from_pretrained('synthetic://tiny?seed=0', torch_dtype=torch.float32)
+    pipe.set_new_concept_cfg(_concept_cfg(pipe.tokenizer, pipe.text_encoder, ['<potter1>', '<potter2>']))
+    latents = torch.randn((1, 4, 8, 8), generator=torch.manual_seed(7))
+    replays = []
+
+    class _FakeGraph:
+        def __init__(self, fn, *example):
+            self.fn = fn
+            self.frozen = next(iter(pipe._sampling_graphs.values())).pe._mos_layers[1]
+
+        def __call__(self, x, t):
+            replays.append(int(t))
+            real_sel, real_att = edlora._select_layer_states, edlora.attach_layer_major_states
+            monkeypatch.setattr(edlora, '_select_layer_states', lambda states, idx: self.frozen[idx])
+            monkeypatch.setattr(edlora, 'attach_layer_major_states', lambda states: states)
+            try:
+                return self.fn(x, t)
+            finally:
+                monkeypatch.setattr(edlora, '_select_layer_states', real_sel)
+                monkeypatch.setattr(edlora, 'attach_layer_major_states', real_att)
+
+    monkeypatch.setattr(G, 'graphs_usable', lambda device: True)
+    monkeypatch.setattr(G, 'try_capture', lambda fn, *ex: _FakeGraph(fn, *ex))
+
+    def run(text, graph, **kw):
+        return pipe(prompt=text, negative_prompt='blurry', height=64, width=64, num_inference_steps=5, guidance_scale=7.5,
+                    latents=latents.clone(), output_type='latent', hipgraph=graph, **kw).images
+
+    a_graph = run('a <potter1> <potter2> in the park', True)
+    assert pipe.last_call_graphed and len(replays) == 4 and pipe.last_call_replay_from == 1
+    b_graph = run('a photo of a dog', True)
+    assert len(replays) == 9 and pipe.last_call_replay_from == 0 and len(pipe._sampling_graphs) == 1
+    b_eager = run('a photo of a dog', False)
+    a_eager = run('a <potter1> <potter2> in the park', False)
+    torch.testing.assert_close(b_graph, b_eager, rtol=0, atol=0)
+    torch.testing.assert_close(a_graph, a_eager, rtol=0, atol=0)
+    assert not torch.allclose(a_eager, b_eager)
+    # a changed weight is a new model epoch: the entry is dropped and the call captures again (step 0 eager)
+    with torch.no_grad():
+        next(pipe.unet.parameters()).add_(0.0)
+    run('a photo of a dog', True)
+    assert pipe.last_call_replay_from == 1 and len(pipe._sampling_graphs) == 1
+    # cross_attention_kwargs: not cached (nothing is known about what they reference), still graphed within the call
+    run('a photo of a dog', True, cross_attention_kwargs={})
+    assert pipe.last_call_graphed and pipe.last_call_replay_from == 1
