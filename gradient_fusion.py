@@ -27,7 +27,8 @@ from mixofshow.models.edlora import revise_edlora_unet_attention_forward
 from mixofshow.models.schedulers import DPMSolverMultistepScheduler
 from mixofshow.pipelines.pipeline_edlora import StableDiffusionPipeline, bind_concept_prompt
 from mixofshow.utils.convert_edlora_to_diffusers import lora_down_name
-from mixofshow.utils.lsq import GramAccumulator, lbfgs_on_gram, update_quasi_newton  # noqa: F401 (re-exported)
+from mixofshow.utils.lsq import (GramAccumulator, lbfgs_on_gram, lbfgs_on_gram_many,  # noqa: F401 (re-exported)
+                                 update_quasi_newton)
 
 TEMPLATE_SIMPLE = 'photo of a {}'
 NUM_CROSS_ATTENTION_LAYERS = 16
@@ -125,7 +126,19 @@ def parse_new_concepts(concept_cfg):
     return emb, te, kv, spatial, concept_list
 
 
+SOLVE_SECONDS = {}     # stage tag -> wall seconds of its layer solves in the last compose_concepts call (read by bench.py)
+
+
 def _solve_layers(accs, original_state_dict, iters, tag):
+    import time
+    t0 = time.perf_counter()
+    out = _solve_layers_impl(accs, original_state_dict, iters, tag)
+    SOLVE_SECONDS[tag] = round(time.perf_counter() - t0, 3)      # (the results are on the host: the device work is complete)
+    logging.info(f'{tag}: {len(accs)} layers solved in {SOLVE_SECONDS[tag]:.2f} s')
+    return out
+
+
+def _solve_layers_impl(accs, original_state_dict, iters, tag):
     """One L-BFGS per layer on its Gram statistics (reference update_quasi_newton, :38-96). The layers are independent, and an
     iteration is a handful of small launches plus one read-back -- the host waits on the device for most of it -- so on a HIP
     device a few worker threads, each with its own stream, solve different layers at the same time (the wait of one overlaps
@@ -133,8 +146,34 @@ def _solve_layers(accs, original_state_dict, iters, tag):
     sequential ones: nothing is shared between the problems."""
     names = list(accs)
     dev = next(iter(accs.values())).G.device if accs else torch.device('cpu')
-    workers = int(os.environ.get('MOS_FUSION_THREADS', 3)) if dev.type == 'cuda' else 1
     out = {}
+    # Lock-step solve (MOS_FUSION_BATCH, default on for a HIP device; 0 = the worker-thread form below): the layers advance
+    # together, ONE host read-back per round answers the pending requests of all of them (mixofshow.utils.lbfgs.minimize_many)
+    # -- bit-identical iterates per layer, no thread contention for the interpreter. Groups are cut so that the L-BFGS
+    # histories of a group (2 x 25 rows of Cout*Cin fp64 per layer) stay within MOS_FUSION_BATCH_GB (default 24 GB).
+    lockstep = os.environ.get('MOS_FUSION_BATCH', '1')               # ('force': also on the CPU -- the tests' way in)
+    if (lockstep == 'force' or (dev.type == 'cuda' and lockstep != '0')) and len(names) >= 2:
+        budget = float(os.environ.get('MOS_FUSION_BATCH_GB', 24)) * 2**30
+        groups, cur, used = [], [], 0.0
+        for name in names:
+            need = 2.0 * 25 * accs[name].cout * accs[name].cin * 8
+            if cur and used + need > budget:
+                groups.append(cur)
+                cur, used = [], 0.0
+            cur.append(name)
+            used += need
+        groups.append(cur)
+        done = 0
+        for group in groups:
+            W0s = [original_state_dict[k].to(torch.float32) for k in group]
+            logging.info(f'[{done + 1}-{done + len(group)}/{len(names)}] optimizing {len(group)} layers in lock step ({tag})')
+            res = lbfgs_on_gram_many([w.reshape(w.shape[0], -1) for w in W0s], [accs[k] for k in group], iters)
+            for k, w0, (Wn, loss) in zip(group, W0s, res):
+                logging.info(f'{k} (n={accs[k].n}) new_concept loss: %e' % loss)
+                out[k] = Wn.reshape(w0.shape)
+            done += len(group)
+        return out
+    workers = int(os.environ.get('MOS_FUSION_THREADS', 3)) if dev.type == 'cuda' else 1
 
     def solve(i):
         layer_name, acc = names[i], accs[names[i]]

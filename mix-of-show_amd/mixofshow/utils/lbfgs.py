@@ -21,6 +21,13 @@ Update rules, constants (c1 = 1e-4, c2 = 0.9, curvature threshold 1e-10, first s
 5/4 max_iter, max_ls = max_eval - evals so far), termination tests and their order follow torch.optim.LBFGS.step, so the
 iterates agree with it to rounding (tests/test_fusion_cpu.py compares them on random and on the reference's golden
 problems).
+
+The iteration is written as a GENERATOR (`minimize_steps`): wherever the host needs device values it yields the small device
+vector and is sent back its values as a Python list. `minimize` drives one problem (read-back = `.tolist()`); `minimize_many`
+drives any number of independent problems in lock step on one stream and answers ALL their pending requests with ONE
+concatenation and ONE read-back per round -- the layers of a fusion are independent problems, and the host round trip, not
+the arithmetic, is what an iteration costs. Each problem executes exactly the operations of its own
+sequential run, in the same order: the iterates are bit-identical.
 """
 import math
 
@@ -46,9 +53,10 @@ def _cubic_interpolate(x1, f1, g1, x2, f2, g2, bounds=None):
 
 
 def _strong_wolfe(evaluate, t, d_norm, f, g, gtd, c1=1e-4, c2=0.9, tolerance_change=1e-9, max_ls=25):
-    """Bracketing + zoom line search for the strong Wolfe conditions. `evaluate(t)` -> (f(t), g(t), g(t).d) with f and
-    g.d Python floats and g a device tensor that is not modified afterwards. Returns (f, g, t, evaluations, g.d)."""
-    f_new, g_new, gtd_new = evaluate(t)
+    """Bracketing + zoom line search for the strong Wolfe conditions (a generator, see the module docstring: use with
+    `yield from`). `evaluate(t)` is a generator returning (f(t), g(t), g(t).d) with f and g.d Python floats and g a device
+    tensor that is not modified afterwards. Returns (f, g, t, evaluations, g.d)."""
+    f_new, g_new, gtd_new = yield from evaluate(t)
     evals = 1
     t_prev, f_prev, g_prev, gtd_prev = 0.0, f, g, gtd
     done = False
@@ -70,7 +78,7 @@ def _strong_wolfe(evaluate, t, d_norm, f, g, gtd, c1=1e-4, c2=0.9, tolerance_cha
         tmp = t
         t = _cubic_interpolate(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, bounds=(min_step, max_step))
         t_prev, f_prev, g_prev, gtd_prev = tmp, f_new, g_new, gtd_new
-        f_new, g_new, gtd_new = evaluate(t)
+        f_new, g_new, gtd_new = yield from evaluate(t)
         evals += 1
         ls_iter += 1
     if ls_iter == max_ls:
@@ -92,7 +100,7 @@ def _strong_wolfe(evaluate, t, d_norm, f, g, gtd, c1=1e-4, c2=0.9, tolerance_cha
                 insuf_progress = True
         else:
             insuf_progress = False
-        f_new, g_new, gtd_new = evaluate(t)
+        f_new, g_new, gtd_new = yield from evaluate(t)
         evals += 1
         ls_iter += 1
         if f_new > (f + c1 * t * gtd) or f_new >= bracket_f[low_pos]:
@@ -161,12 +169,10 @@ class _History:
         return q * gamma + S.t() @ v1[back] + (Y.t() @ v2[back]) * gamma
 
 
-def minimize(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolerance_grad=1e-16, tolerance_change=1e-16,
-             max_eval=None, on_eval=None):
-    """Minimise f from x0 (1-D device tensor). `value_and_grad(x)` -> (f(x) as a 0-dim device tensor, grad f(x) as a
-    1-D tensor that the caller does not modify afterwards). `on_eval(x, f_float)` is called after every evaluation
-    (the reference keeps the best-loss iterate over ALL evaluations, line-search trials included).
-    Returns (x, f(x), evaluations)."""
+def minimize_steps(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolerance_grad=1e-16, tolerance_change=1e-16,
+                   max_eval=None, on_eval=None):
+    """The generator behind `minimize` / `minimize_many`: yields a small 1-D device tensor whenever the host needs its
+    values and expects them back (`send`) as a list of Python floats; returns (x, f(x), evaluations)."""
     max_eval = max_iter * 5 // 4 if max_eval is None else max_eval
     x = x0
 
@@ -175,12 +181,12 @@ def minimize(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolerance_gr
         parts = [f_t.reshape(()), g_t.abs().max()]
         if d is not None:
             parts.append(g_t.dot(d))
-        vals = torch.stack(parts).tolist()           # the one host read-back of this evaluation
+        vals = yield torch.stack(parts)              # the one host read-back of this evaluation
         if on_eval is not None:
             on_eval(xt, vals[0])
         return vals, g_t
 
-    (loss, gmax), g = evaluate_at(x)
+    (loss, gmax), g = yield from evaluate_at(x)
     evals = 1
     if gmax <= tolerance_grad:
         return x, loss, evals
@@ -201,7 +207,7 @@ def minimize(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolerance_gr
                 gamma = ys / y.dot(y)                # stays on the device
             d = hist.direction(g, gamma)
         prev_g, prev_loss = g, loss
-        gtd, d_norm, g_l1 = torch.stack([g.dot(d), d.abs().max(), g.abs().sum()]).tolist()
+        gtd, d_norm, g_l1 = yield torch.stack([g.dot(d), d.abs().max(), g.abs().sum()])
         t = min(1.0, 1.0 / g_l1) * lr if n_iter == 1 else lr
         if gtd > -tolerance_change:
             break
@@ -209,13 +215,13 @@ def minimize(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolerance_gr
 
         def evaluate(step):
             xt = torch.add(x_init, d, alpha=step)
-            (f_t, gmax_t, gtd_t), g_t = evaluate_at(xt, d)
+            (f_t, gmax_t, gtd_t), g_t = yield from evaluate_at(xt, d)
             trial[step] = (xt, gmax_t)
             return f_t, g_t, gtd_t
 
         trial = {}
-        loss, g, t, ls_evals, gtd_new = _strong_wolfe(evaluate, t, d_norm, loss, g, gtd, tolerance_change=1e-9,
-                                                      max_ls=max_eval - evals)
+        loss, g, t, ls_evals, gtd_new = yield from _strong_wolfe(evaluate, t, d_norm, loss, g, gtd, tolerance_change=1e-9,
+                                                                 max_ls=max_eval - evals)
         x, gmax = trial[t] if t in trial else (x_init, gmax)       # t == 0: the search returned the starting point
         evals += ls_evals
         if n_iter == max_iter or evals >= max_eval:
@@ -227,3 +233,46 @@ def minimize(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolerance_gr
         if abs(loss - prev_loss) < tolerance_change:
             break
     return x, loss, evals
+
+
+def minimize(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolerance_grad=1e-16, tolerance_change=1e-16,
+             max_eval=None, on_eval=None):
+    """Minimise f from x0 (1-D device tensor). `value_and_grad(x)` -> (f(x) as a 0-dim device tensor, grad f(x) as a
+    1-D tensor that the caller does not modify afterwards). `on_eval(x, f_float)` is called after every evaluation
+    (the reference keeps the best-loss iterate over ALL evaluations, line-search trials included).
+    Returns (x, f(x), evaluations)."""
+    gen = minimize_steps(value_and_grad, x0, max_iter, history_size, lr, tolerance_grad, tolerance_change, max_eval, on_eval)
+    try:
+        req = next(gen)
+        while True:
+            req = gen.send(req.tolist())
+    except StopIteration as stop:
+        return stop.value
+
+
+def minimize_many(problems):
+    """`problems`: generators made by `minimize_steps` (independent problems on ONE device / stream). Advances all of them in
+    lock step; per round the pending requests of all unfinished problems are concatenated and read back together (one
+    synchronisation per round instead of one per problem and request). Returns their results in order."""
+    gens = list(problems)
+    results = [None] * len(gens)
+    pending = {}
+    for i, gen in enumerate(gens):
+        try:
+            pending[i] = next(gen)
+        except StopIteration as stop:
+            results[i] = stop.value
+    while pending:
+        keys = list(pending)
+        reqs = [pending[k].reshape(-1) for k in keys]
+        host = (torch.cat(reqs) if len(reqs) > 1 else reqs[0]).tolist()
+        off = 0
+        for k, r in zip(keys, reqs):
+            vals = host[off:off + r.numel()]
+            off += r.numel()
+            try:
+                pending[k] = gens[k].send(vals)
+            except StopIteration as stop:
+                results[k] = stop.value
+                del pending[k]
+    return results

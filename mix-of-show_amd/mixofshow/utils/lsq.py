@@ -105,6 +105,36 @@ def lbfgs_on_gram(W0, acc, iters, solver='lean'):
     return best['W'].to(torch.float32).cpu(), best['loss']
 
 
+def lbfgs_on_gram_many(W0s, accs, iters):
+    """`lbfgs_on_gram(W0, acc, iters)` for several independent layers at once, advanced in lock step by
+    mixofshow.utils.lbfgs.minimize_many: ONE host read-back per round for all layers instead of one per layer and request.
+    Every layer runs exactly the operations of its own `lbfgs_on_gram` call (bit-identical results); all of them live on the
+    device of the statistics and are issued on the current stream. Returns [(W fp32 on the CPU, best loss), ...]."""
+    from mixofshow.utils import lbfgs
+    bests, gens, shapes = [], [], []
+    for W0, acc in zip(W0s, accs):
+        dev = acc.G.device
+        nm = float(acc.n) * acc.cout
+        shape = (acc.cout, acc.cin)
+        best = {'loss': float('inf'), 'W': None}
+
+        def value_and_grad(x, acc=acc, shape=shape, nm=nm):
+            loss, grad = ops.lsq_loss_grad(x.view(shape), acc.G, acc.P, acc.c, nm)
+            return loss, grad.reshape(-1)
+
+        def on_eval(x, lv, best=best):
+            if lv < best['loss']:
+                best['loss'], best['W'] = lv, x          # evaluation points are never modified afterwards
+
+        x0 = W0.detach().to(dev, torch.float64).reshape(-1).contiguous().clone()
+        gens.append(lbfgs.minimize_steps(value_and_grad, x0, iters, history_size=25, lr=1.0, tolerance_grad=1e-16,
+                                         tolerance_change=1e-16, on_eval=on_eval))
+        bests.append(best)
+        shapes.append(shape)
+    lbfgs.minimize_many(gens)
+    return [(b['W'].view(sh).to(torch.float32).cpu(), b['loss']) for b, sh in zip(bests, shapes)]
+
+
 def lbfgs_direct_form(K_target, V_target, W, iters, device, chunk=5000):
     """PARITY / DIAGNOSTIC mode (not the fusion path): the same optimiser loop (mixofshow.utils.lbfgs) on the reference's
     own closure arithmetic -- fp32, loss = mean((K W^T - V)^2) summed over 5000-row chunks as chunk_compute_mse does

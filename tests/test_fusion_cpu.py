@@ -28,6 +28,7 @@ def test_compose_concepts_end_to_end(emulated_hip, tmp_path):
         json.dump(ckpts, f)
     base = RegionallyT2IAdapterPipeline.from_pretrained('synthetic://tiny?seed=0', torch_dtype=torch.float16)
     base_unet = {k: v.clone() for k, v in base.unet.state_dict().items()}
+    torch.manual_seed(77)                      # (the spatial stage draws its start latents from the global generator, like the reference)
     pipe, new_cfg = gf.compose_concepts(cfg, 20, 8, 'synthetic://tiny?seed=0', str(tmp_path), 'base', torch.device('cpu'))
     # concept table: order of the json, 16 layer tokens per word, numbering advances by 16 per word
     assert list(new_cfg) == ['<potter1>', '<potter2>', '<thanos1>', '<thanos2>']
@@ -52,6 +53,19 @@ def test_compose_concepts_end_to_end(emulated_hip, tmp_path):
     for k, v in again.unet.state_dict().items():
         assert torch.equal(v, fused[k]), k
     assert again.tokenizer.convert_tokens_to_ids('<new32>') == new_cfg['<thanos1>']['concept_token_ids'][0]
+    # the lock-step solve (the default on a HIP device: all layers of a stage advance together, one host read-back per round)
+    # writes the very same fused model, text encoder included; a small history budget forces several groups per stage
+    fused_te = {k: v.clone() for k, v in pipe.text_encoder.state_dict().items()}
+    os.environ['MOS_FUSION_BATCH'], os.environ['MOS_FUSION_BATCH_GB'] = 'force', '1e-5'
+    torch.manual_seed(77)
+    try:
+        pipe2, _ = gf.compose_concepts(cfg, 20, 8, 'synthetic://tiny?seed=0', str(tmp_path / 'lockstep'), 'base', torch.device('cpu'))
+    finally:
+        del os.environ['MOS_FUSION_BATCH'], os.environ['MOS_FUSION_BATCH_GB']
+    for k, v in pipe2.unet.state_dict().items():
+        assert torch.equal(v, fused[k]), k
+    for k, v in pipe2.text_encoder.state_dict().items():
+        assert torch.equal(v, fused_te[k]), k
     # and through the sampling CLI's loader (adds the concept tokens again: must be idempotent)
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

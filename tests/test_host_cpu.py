@@ -391,6 +391,55 @@ def test_lean_lbfgs_follows_torch_lbfgs(emulated_hip, golden):
         assert evals == n_ref[0] == len(seen) and rel < 1e-5 and abs(loss - rosen(xr.detach()).item()) <= 1e-4 * max(1e-12, abs(loss))
 
 
+def test_lockstep_lbfgs_is_bit_identical_to_the_sequential_solves(emulated_hip, golden):
+    """lbfgs.minimize_many / lsq.lbfgs_on_gram_many advance independent problems together and answer all their pending
+    read-backs at once (one synchronisation per round): every problem must execute exactly its own sequential run --
+    identical iterates, losses and evaluation counts -- whatever the others do (different sizes, different iteration
+    counts, problems that stop at once, non-quadratic functions whose line searches take different numbers of trials)."""
+    from mixofshow.utils import lbfgs, lsq
+    # (a) the reference's golden layer problems through the Gram-form entry points
+    W0s, accs, iters = [], [], None
+    for name, c in golden['lbfgs'].items():
+        cout, cin = c['W0'].shape[:2]
+        acc = lsq.GramAccumulator(cin, cout, torch.device('cpu'))
+        acc.add(c['X'], c['Y'], exact_fp32=True)
+        W0s.append(c['W0'].reshape(cout, cin))
+        accs.append(acc)
+        iters = c['iters'] if iters is None else min(iters, c['iters'])
+    seq = [lsq.lbfgs_on_gram(w, a, iters) for w, a in zip(W0s, accs)]
+    many = lsq.lbfgs_on_gram_many(W0s, accs, iters)
+    assert len(many) == len(seq) >= 2
+    for (Ws, ls), (Wm, lm) in zip(seq, many):
+        assert torch.equal(Ws, Wm) and ls == lm
+
+    # (b) Rosenbrock problems of different sizes / starts / budgets, plus one that is already at its minimum
+    def rosen(x):
+        return ((1 - x[:-1])**2).sum() + 100 * ((x[1:] - x[:-1]**2)**2).sum()
+
+    def value_and_grad(x):
+        xx = x.detach().clone().requires_grad_(True)
+        loss = rosen(xx)
+        (g, ) = torch.autograd.grad(loss, xx)
+        return loss.detach(), g
+
+    g = torch.Generator().manual_seed(4)
+    specs = [(torch.randn(n, dtype=torch.float64, generator=g) * 0.5, it, h)
+             for n, it, h in ((20, 12, 25), (7, 60, 5), (33, 40, 25), (4, 3, 2))] + [(torch.ones(6, dtype=torch.float64), 10, 25)]
+    want, traces = [], []
+    for x0, it, h in specs:
+        seen = []
+        want.append(lbfgs.minimize(value_and_grad, x0.clone(), it, history_size=h, on_eval=lambda xt, fv, seen=seen: seen.append(fv)))
+        traces.append(seen)
+    seen_many = [[] for _ in specs]
+    got = lbfgs.minimize_many([lbfgs.minimize_steps(value_and_grad, x0.clone(), it, history_size=h,
+                                                    on_eval=lambda xt, fv, seen=seen: seen.append(fv))
+                               for (x0, it, h), seen in zip(specs, seen_many)])
+    for (xw, lw, ew), (xg, lg, eg), tw, tg in zip(want, got, traces, seen_many):
+        assert torch.equal(xw, xg) and lw == lg and ew == eg and tw == tg
+    assert got[-1][2] == 1 and len({e for _, _, e in got}) > 2          # the converged start stops at once; the others differ
+    assert lbfgs.minimize_many([]) == []
+
+
 def test_gram_accumulator_chunks_and_split(emulated_hip):
     """G, P, c are independent of chunking and of the representation of the features (half, fp32-on-a-half-grid,
     general fp32 through the hi+lo split)."""
