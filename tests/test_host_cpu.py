@@ -440,6 +440,48 @@ def test_lockstep_lbfgs_is_bit_identical_to_the_sequential_solves(emulated_hip, 
     assert lbfgs.minimize_many([]) == []
 
 
+def test_lbfgs_iteration_is_a_few_dozen_device_operations():
+    """An L-BFGS iteration of a fusion layer is bound by the interpreter dispatching its small device operations (DESIGN.md
+    5.8: 0.49 ms per iteration of a 768 x 768 layer at 57 operations). The doubled ring buffers of `_History` keep the pairs
+    in age order as a VIEW: count what is dispatched per iteration with the history full (function evaluation excluded) and
+    pin it, so that an index shuffle does not creep back in."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from mixofshow.utils import lbfgs
+    views = {'view', '_unsafe_view', 'reshape', 'unsqueeze', 'squeeze', 't', 'transpose', 'slice', 'select', 'diagonal',
+             'detach', 'alias', 'expand', 'permute', 'as_strided', '_reshape_alias', '_local_scalar_dense'}
+
+    class Count(TorchDispatchMode):
+        n = 0
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            if func.overloadpacket.__name__ not in views:
+                Count.n += 1
+            return func(*args, **(kwargs or {}))
+
+    g = torch.Generator().manual_seed(0)
+    cin = cout = 40
+    X = torch.randn(400, cin, dtype=torch.float64, generator=g) * torch.logspace(0, -4, cin, dtype=torch.float64)   # ill-conditioned
+    G = X.t() @ X
+    P = torch.randn(cout, cin, dtype=torch.float64, generator=g) @ G
+    in_closure = [0]
+
+    def value_and_grad(x):
+        before = Count.n
+        W = x.view(cout, cin)
+        WG = W @ G
+        out = ((W * WG).sum() - 2 * (W * P).sum()) / 1e3, ((WG - P) * (2 / 1e3)).reshape(-1)
+        in_closure[0] += Count.n - before
+        return out
+
+    for hist, iters in ((5, 40), (25, 80)):
+        Count.n, in_closure[0] = 0, 0
+        with Count():
+            x, loss, evals = lbfgs.minimize(value_and_grad, torch.zeros(cout * cin, dtype=torch.float64), iters, history_size=hist)
+        per_eval = (Count.n - in_closure[0]) / evals
+        print(f'[launches] L-BFGS history {hist}: {evals} evaluations, {per_eval:.1f} device operations per evaluation outside the closure')
+        assert evals >= iters * 0.9 and per_eval <= 36.0
+
+
 def test_gram_accumulator_chunks_and_split(emulated_hip):
     """G, P, c are independent of chunking and of the representation of the features (half, fp32-on-a-half-grid,
     general fp32 through the hi+lo split)."""
