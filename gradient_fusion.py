@@ -150,13 +150,13 @@ def _solve_layers_impl(accs, original_state_dict, iters, tag):
     # Lock-step solve (MOS_FUSION_BATCH, default on for a HIP device; 0 = the worker-thread form below): the layers advance
     # together, ONE host read-back per round answers the pending requests of all of them (mixofshow.utils.lbfgs.minimize_many)
     # -- bit-identical iterates per layer, no thread contention for the interpreter. Groups are cut so that the L-BFGS
-    # histories of a group (2 x 25 rows of Cout*Cin fp64 per layer) stay within MOS_FUSION_BATCH_GB (default 24 GB).
+    # histories of a group (4 x 25 rows of Cout*Cin fp64 per layer) stay within MOS_FUSION_BATCH_GB (default 24 GB).
     lockstep = os.environ.get('MOS_FUSION_BATCH', '1')               # ('force': also on the CPU -- the tests' way in)
     if (lockstep == 'force' or (dev.type == 'cuda' and lockstep != '0')) and len(names) >= 2:
         budget = float(os.environ.get('MOS_FUSION_BATCH_GB', 24)) * 2**30
         groups, cur, used = [], [], 0.0
         for name in names:
-            need = 2.0 * 25 * accs[name].cout * accs[name].cin * 8
+            need = 4.0 * 25 * accs[name].cout * accs[name].cin * 8        # S and Y, each kept twice (lbfgs._History)
             if cur and used + need > budget:
                 groups.append(cur)
                 cur, used = [], 0.0

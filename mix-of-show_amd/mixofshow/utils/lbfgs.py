@@ -118,67 +118,81 @@ def _strong_wolfe(evaluate, t, d_norm, f, g, gtd, c1=1e-4, c2=0.9, tolerance_cha
 
 class _History:
     """The last `size` accepted (s, y) pairs as rows of S, Y in a ring (the oldest row is overwritten in place: no
-    shifting of the (size x n) buffers), with S Y^T and Y Y^T kept up to date.
+    shifting of the (size x n) buffers), with S^T Y and Y^T Y kept up to date, and the next search direction.
 
+    What an iteration costs on the device is the traffic over S and Y (25 rows of Cout*Cin fp64 each: 2 x 118 MB for a
+    768 x 768 layer -- the closure itself is an 84 us kernel), so `step` touches them as little as the algorithm allows:
+      * the direction needs S g, Y g and one combination each of the rows of S and of Y: FOUR passes (the two-loop
+        recursion needs the same four);
+      * the inner products of a NEW pair with the stored ones need no pass at all: y = g - g_prev, so
+        s_i.y = (S g)_i - (S g_prev)_i and y_i.y = (Y g)_i - (Y g_prev)_i with both vectors already computed for the
+        directions of this and of the previous iteration (kept in `Sg`, `Yg`); s.y of the new pair is known on the host
+        (t (g.d - g_prev.d)), y.y is one dot product. Only the upper triangle of S^T Y (pairs in age order) enters the
+        compact representation, so the products s_new.y_i are not needed. (The earlier form spent three more passes on
+        S y, Y s, Y y.)
     Every buffer is kept TWICE, back to back (rows r and r + size hold the same pair; the small matrices repeat in all four
-    quadrants), so that the pairs in AGE order -- what the compact representation needs -- are always one contiguous window
-    [start, start + k) of the doubled buffer: a view. No gathers, no permutation scatters: an iteration of a 768 x 768 layer is
-    bound by the interpreter dispatching its few dozen small device operations, not by their arithmetic, and
-    the earlier single-buffer form spent 18 of its 57 operations per iteration on index shuffles."""
+    quadrants), so that the pairs in AGE order are always one contiguous window [start, start + k) of the doubled buffer:
+    a view, no gathers and no permutation scatters."""
 
     def __init__(self, size, n, like):
         self.size, self.n = size, n
         kw = dict(dtype=like.dtype, device=like.device)
         self.S = torch.empty(2 * size, n, **kw)
         self.Y = torch.empty(2 * size, n, **kw)
-        self.SY = torch.zeros(2 * size, 2 * size, **kw)
+        self.SY = torch.zeros(2 * size, 2 * size, **kw)      # [i, j] = s_i . y_j, valid where pair i is not younger than pair j
         self.YY = torch.zeros(2 * size, 2 * size, **kw)
+        self.Sg = torch.zeros(size, **kw)                    # S g, Y g of the previous `step` (physical row order)
+        self.Yg = torch.zeros(size, **kw)
         self.k = 0              # pairs stored
         self.start = 0          # physical row of the oldest pair once the ring is full
 
-    def push(self, s, y):
-        """Store the pair; returns y.y (0-dim device tensor)."""
+    def step(self, pair, g, gamma):
+        """Optionally store `pair` = (s, y = g - g_prev, s.y as a Python float), then return (-H g, gamma) with H the L-BFGS
+        inverse Hessian of the stored pairs and H0 = gamma I, gamma = s.y / y.y of the newest pair (a device scalar)."""
         size = self.size
-        if self.k == size:
-            slot = self.start
-            self.start = (self.start + 1) % size
-        else:
-            slot = self.k
-            self.k += 1
+        slot = None
+        if pair is not None:
+            s, y, ys = pair
+            if self.k == size:
+                slot = self.start
+                self.start = (self.start + 1) % size
+            else:
+                slot = self.k
+                self.k += 1
+            self.S.view(2, size, self.n)[:, slot] = s
+            self.Y.view(2, size, self.n)[:, slot] = y
+            yy_new = y.dot(y)
+            gamma = ys / yy_new
         k = self.k
-        self.S.view(2, size, self.n)[:, slot] = s
-        self.Y.view(2, size, self.n)[:, slot] = y
-        sy_col = self.S[:k] @ y                      # s_i . y_new   (physical rows; includes the new pair itself)
-        sy_row = self.Y[:k] @ s                      # s_new . y_i
-        yy = self.Y[:k] @ y
-        SY4, YY4 = self.SY.view(2, size, 2, size), self.YY.view(2, size, 2, size)
-        SY4[:, :k, :, slot] = sy_col.view(1, k, 1)
-        SY4[:, slot, :, :k] = sy_row.view(1, 1, k)
-        YY4[:, :k, :, slot] = yy.view(1, k, 1)
-        YY4[:, slot, :, :k] = yy.view(1, 1, k)
-        return yy[slot]
-
-    def direction(self, g, gamma):
-        """-H g with H the L-BFGS inverse Hessian of the stored pairs and H0 = gamma I."""
-        k = self.k
-        q = g.neg()
         if k == 0:
-            return q * gamma
-        lo = self.start if k == self.size else 0     # the age-ordered window of the doubled buffers
+            return g.neg() * gamma, gamma
+        Sg, Yg = self.S[:k] @ g, self.Y[:k] @ g              # physical row order, the new pair included
+        if slot is not None:
+            sy_col, yy_col = Sg - self.Sg[:k], Yg - self.Yg[:k]           # (entry `slot` is meaningless: set below)
+            sy_col[slot] = ys
+            yy_col[slot] = yy_new
+            SY4, YY4 = self.SY.view(2, size, 2, size), self.YY.view(2, size, 2, size)
+            SY4[:, :k, :, slot] = sy_col.view(1, k, 1)
+            YY4[:, :k, :, slot] = yy_col.view(1, k, 1)
+            YY4[:, slot, :, :k] = yy_col.view(1, 1, k)
+        self.Sg[:k] = Sg
+        self.Yg[:k] = Yg
+        lo = self.start if k == size else 0                  # the age-ordered window of the doubled buffers
+        if lo:
+            Sg, Yg = Sg.repeat(2)[lo:lo + k], Yg.repeat(2)[lo:lo + k]
         S, Y = self.S[lo:lo + k], self.Y[lo:lo + k]
         SY, YY = self.SY[lo:lo + k, lo:lo + k], self.YY[lo:lo + k, lo:lo + k]
+        # compact representation (module docstring) with q = -g:  -H g = gamma (Y^T u - g) + S^T v,
+        #   u = R^-1 S g,   v = R^-T (gamma Y g - (D + gamma Y^T Y) u),   R = triu(S^T Y), D = diag(S^T Y)
         R = torch.triu(SY)
-        a = S @ q
-        b = (Y @ q) * gamma
-        Ra = torch.linalg.solve_triangular(R, a.unsqueeze(1), upper=True).squeeze(1)           # R^-1 a
+        u = torch.linalg.solve_triangular(R, Sg.unsqueeze(1), upper=True).squeeze(1)
         M = YY * gamma
-        M.diagonal().add_(SY.diagonal())                                                        # D + gamma Y^T Y
-        mid = torch.addmv(b, M, Ra, beta=-1)                                                    # (D + gamma YY) R^-1 a - b
-        v1 = torch.linalg.solve_triangular(R.t(), mid.unsqueeze(1), upper=False).squeeze(1)    # R^-T (...)
-        # gamma q + S^T v1 - gamma Y^T R^-1 a
-        out = torch.addmv(q, Y.t(), Ra, alpha=-1)
+        M.diagonal().add_(SY.diagonal())
+        mid = torch.addmv(Yg * gamma, M, u, alpha=-1)
+        v = torch.linalg.solve_triangular(R.t(), mid.unsqueeze(1), upper=False).squeeze(1)
+        out = torch.addmv(g, Y.t(), u, beta=-1)
         out *= gamma
-        return torch.addmv(out, S.t(), v1)
+        return torch.addmv(out, S.t(), v), gamma
 
 
 def _absmax(v):
@@ -217,10 +231,8 @@ def minimize_steps(value_and_grad, x0, max_iter, history_size=25, lr=1.0, tolera
             d = g.neg()
         else:
             ys = t * (gtd_new - gtd)                 # y.s = (g_new - g_old).(t d)
-            if ys > 1e-10:
-                yy = hist.push(d if t == 1.0 else d * t, g - prev_g)
-                gamma = ys / yy                      # stays on the device
-            d = hist.direction(g, gamma)
+            pair = (d if t == 1.0 else d * t, g - prev_g, ys) if ys > 1e-10 else None
+            d, gamma = hist.step(pair, g, gamma)     # (gamma stays on the device)
         prev_g, prev_loss = g, loss
         if n_iter == 1:                              # (|g|_1 only scales the very first step)
             gtd, d_norm, g_l1 = yield torch.stack([g.dot(d), _absmax(d), torch.linalg.vector_norm(g, 1)])
