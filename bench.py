@@ -710,7 +710,7 @@ def run_fusion(args, rank, world, device):
     lsq = sorted((r for r in recs if r['name'].startswith('lsq_loss_grad')), key=lambda r: -r['total_ms'])
     res = dict(metric='gradient_fusion_wall_seconds_14_edloras_sd15', value=round(statistics.mean(times), 2), unit='s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(statistics.mean(times) * 1e3, 1),
-               solve_seconds_last_pass=dict(gf.SOLVE_SECONDS),
+               stage_seconds_last_pass=dict(gf.STAGE_SECONDS), solve_seconds_last_pass=dict(gf.SOLVE_SECONDS),
                lockstep_solve=os.environ.get('MOS_FUSION_BATCH', '1') != '0',
                higher_is_better=False, scaling='weak', vs_baseline=None, dtype='fp16 features / fp64 Gram + L-BFGS',
                data='synthetic',

@@ -127,6 +127,7 @@ def parse_new_concepts(concept_cfg):
 
 
 SOLVE_SECONDS = {}     # stage tag -> wall seconds of its layer solves in the last compose_concepts call (read by bench.py)
+STAGE_SECONDS = {}     # step of compose_concepts -> wall seconds in the last call
 
 
 def _solve_layers(accs, original_state_dict, iters, tag):
@@ -383,17 +384,31 @@ def merge_spatial_attention(concept_list, optimize_iters, new_concept_cfg, token
 
 def compose_concepts(concept_cfg, optimize_textenc_iters, optimize_unet_iters, pretrained_model_path, save_path, suffix,
                      device, save=True):
+    import time
+    STAGE_SECONDS.clear()
+    SOLVE_SECONDS.clear()
+    marks = [('start', time.perf_counter())]
+
+    def mark(name):                     # wall seconds per stage of this call (bench.py reports them: where a pass goes)
+        if torch.device(device).type == 'cuda':
+            torch.cuda.synchronize()
+        marks.append((name, time.perf_counter()))
+        STAGE_SECONDS[name] = round(marks[-1][1] - marks[-2][1], 3)
+
     logging.info('------Step 1: load stable diffusion checkpoint------')
     pipe, _, test_scheduler = init_stable_diffusion(pretrained_model_path, device)
     tokenizer, text_encoder, unet, vae = pipe.tokenizer, pipe.text_encoder, pipe.unet, pipe.vae
     for p in itertools.chain(text_encoder.parameters(), unet.parameters(), vae.parameters()):
         p.requires_grad = False
+    mark('1 load model')
     logging.info('------Step 2: load new concepts checkpoints------')
     emb_list, te_list, kv_list, spatial_list, concept_list = parse_new_concepts(concept_cfg)
+    mark('2 load concept checkpoints')
     new_concept_cfg = {}
     if any(x is not None for x in emb_list):
         logging.info('------Step 3: merge token embedding------')
         _, new_concept_cfg = merge_new_concepts_(emb_list, concept_list, tokenizer, text_encoder)
+    mark('3 token embeddings')
     if any(x is not None for x in te_list):
         logging.info('------Step 4: merge text encoder------')
         new_w = merge_text_encoder(concept_list, optimize_textenc_iters, new_concept_cfg, tokenizer, text_encoder,
@@ -401,6 +416,7 @@ def compose_concepts(concept_cfg, optimize_textenc_iters, optimize_unet_iters, p
         sd = text_encoder.state_dict()
         sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
         text_encoder.load_state_dict(sd)
+    mark('4 text encoder (features + solves)')
     if any(x is not None for x in kv_list):
         logging.info('------Step 5: merge kv of cross-attention in unet------')
         new_w = merge_kv_in_cross_attention(concept_list, optimize_textenc_iters, new_concept_cfg, tokenizer,
@@ -408,6 +424,7 @@ def compose_concepts(concept_cfg, optimize_textenc_iters, optimize_unet_iters, p
         sd = unet.state_dict()
         sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
         unet.load_state_dict(sd)
+    mark('5 cross-attention k/v (features + solves)')
     if any(x is not None for x in spatial_list):
         logging.info('------Step 6: merge spatial attention (q in cross-attention, qkv in self-attention) in unet------')
         new_w = merge_spatial_attention(concept_list, optimize_unet_iters, new_concept_cfg, tokenizer, text_encoder,
@@ -415,6 +432,7 @@ def compose_concepts(concept_cfg, optimize_textenc_iters, optimize_unet_iters, p
         sd = unet.state_dict()
         sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
         unet.load_state_dict(sd)
+    mark('6 spatial attention (sampling + features + solves)')
     if save:
         out = f'{save_path}/combined_model_{suffix}'
         pipe.save_pretrained(out)
