@@ -59,6 +59,18 @@ def _snapshot(model):
     return {k: v.detach().clone() for k, v in model.state_dict().items()}
 
 
+def _load_layers(model, state_dict, layer_names):
+    """`model.load_state_dict(state_dict)` for a state dict that differs from the live weights in `layer_names` only (a LoRA
+    merge of those layers, or their restoration): copy exactly those tensors. A full load_state_dict would also rewrite --
+    and bump the version counters of -- the several hundred untouched tensors, and with them throw away every derived copy
+    the HIP path keeps per weight (fused / cast projection weights, re-laid-out convolution kernels, fp32 norm parameters,
+    stacked time projections), to be rebuilt by the next forward: once per concept and stage."""
+    live = model.state_dict()
+    with torch.no_grad():
+        for k in layer_names:
+            live[k].copy_(state_dict[k])
+
+
 def init_stable_diffusion(pretrained_model_path, device):
     pipe = StableDiffusionPipeline.from_pretrained(pretrained_model_path, torch_dtype=torch.float16).to(device)
     pipe.scheduler = DPMSolverMultistepScheduler()
@@ -298,7 +310,7 @@ def merge_text_encoder(concept_list, optimize_iters, new_concept_cfg, tokenizer,
     original = _snapshot(text_encoder)          # deep: load_state_dict below writes into the live tensors
     for concept, lora in zip(concept_list, text_encoder_list):
         merged = merge_lora_into_weight(original, lora, layer_names, 'text_encoder', concept['text_encoder_alpha'], device)
-        text_encoder.load_state_dict(merged)
+        _load_layers(text_encoder, merged, layer_names)
         prompts = bind_concept_prompt([TEMPLATE_SIMPLE.format(concept['concept_name']), concept['concept_name']],
                                       new_concept_cfg)
         rec.enabled = True
@@ -307,7 +319,7 @@ def merge_text_encoder(concept_list, optimize_iters, new_concept_cfg, tokenizer,
         rec.flush()
     for h in handles:
         h.remove()
-    text_encoder.load_state_dict(original)
+    _load_layers(text_encoder, original, layer_names)
     return _solve_layers({k: rec.accs[k] for k in layer_names}, original, optimize_iters, 'text-encoder')
 
 
@@ -369,7 +381,7 @@ def merge_spatial_attention(concept_list, optimize_iters, new_concept_cfg, token
     revise_edlora_unet_attention_forward(unet)
     for concept, lora in zip(concept_list, unet_spatial_attn_list):
         merged = merge_lora_into_weight(original, lora, layer_names, 'unet', concept['unet_alpha'], device)
-        unet.load_state_dict(merged)
+        _load_layers(unet, merged, layer_names)
         decode_to_latents(TEMPLATE_SIMPLE.format(concept['concept_name']), new_concept_cfg, tokenizer, text_encoder,
                           unet, test_scheduler, num_inference_steps=20, device=device, record_nums=20, batch_size=1,
                           recorder=rec)
@@ -378,7 +390,7 @@ def merge_spatial_attention(concept_list, optimize_iters, new_concept_cfg, token
         h.remove()
     for a in tapped:
         object.__setattr__(a, '_mos_tap', None)
-    unet.load_state_dict(original)
+    _load_layers(unet, original, layer_names)
     return _solve_layers({k: rec.accs[k] for k in layer_names}, original, optimize_iters, 'spatial')
 
 
@@ -414,24 +426,21 @@ def compose_concepts(concept_cfg, optimize_textenc_iters, optimize_unet_iters, p
         new_w = merge_text_encoder(concept_list, optimize_textenc_iters, new_concept_cfg, tokenizer, text_encoder,
                                    te_list, device)
         sd = text_encoder.state_dict()
-        sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
-        text_encoder.load_state_dict(sd)
+        _load_layers(text_encoder, {k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()}, list(new_w))
     mark('4 text encoder (features + solves)')
     if any(x is not None for x in kv_list):
         logging.info('------Step 5: merge kv of cross-attention in unet------')
         new_w = merge_kv_in_cross_attention(concept_list, optimize_textenc_iters, new_concept_cfg, tokenizer,
                                             text_encoder, unet, kv_list, device)   # (sic) textenc iters, reference :787
         sd = unet.state_dict()
-        sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
-        unet.load_state_dict(sd)
+        _load_layers(unet, {k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()}, list(new_w))
     mark('5 cross-attention k/v (features + solves)')
     if any(x is not None for x in spatial_list):
         logging.info('------Step 6: merge spatial attention (q in cross-attention, qkv in self-attention) in unet------')
         new_w = merge_spatial_attention(concept_list, optimize_unet_iters, new_concept_cfg, tokenizer, text_encoder,
                                         unet, spatial_list, test_scheduler, device)
         sd = unet.state_dict()
-        sd.update({k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()})
-        unet.load_state_dict(sd)
+        _load_layers(unet, {k: v.to(sd[k].device, sd[k].dtype) for k, v in new_w.items()}, list(new_w))
     mark('6 spatial attention (sampling + features + solves)')
     if save:
         out = f'{save_path}/combined_model_{suffix}'

@@ -219,22 +219,32 @@ def test_original_weights_survive_each_concept(emulated_hip, tmp_path):
     _, ncfg = gf.merge_new_concepts_(emb, concepts, pipe.tokenizer, pipe.text_encoder)
     w0 = {k: v.detach().clone() for k, v in pipe.text_encoder.state_dict().items()}
     seen = []
-    real_load = pipe.text_encoder.load_state_dict
+    real_load = gf._load_layers
 
-    def spy(sd, *a, **k):
-        seen.append({n: v.detach().clone().float() for n, v in sd.items() if 'q_proj.weight' in n})
-        return real_load(sd, *a, **k)
+    def spy(model, sd, names):                           # (the per-concept loads copy the merged LAYERS only, see _load_layers)
+        real_load(model, sd, names)
+        assert model is pipe.text_encoder
+        seen.append({n: v.detach().clone().float() for n, v in model.state_dict().items()})    # the LIVE weights afterwards
 
-    pipe.text_encoder.load_state_dict = spy
-    gf.merge_text_encoder(concepts, 3, ncfg, pipe.tokenizer, pipe.text_encoder, te, dev)
+    gf._load_layers = spy
+    try:
+        gf.merge_text_encoder(concepts, 3, ncfg, pipe.tokenizer, pipe.text_encoder, te, dev)
+    finally:
+        gf._load_layers = real_load
     assert len(seen) == 3                                # concept 1, concept 2, restore
     for ci in (0, 1):
+        checked = 0
         for n, v in seen[ci].items():
-            dn = n.replace('q_proj.weight', 'q_proj.lora_down.weight')
-            want = w0[n].float() + concepts[ci]['text_encoder_alpha'] * te[ci][dn.replace('lora_down', 'lora_up')] @ te[ci][dn]
-            torch.testing.assert_close(v, want.to(w0[n].dtype).float(), rtol=0, atol=0)
+            if 'q_proj.weight' in n:
+                dn = n.replace('q_proj.weight', 'q_proj.lora_down.weight')
+                want = w0[n].float() + concepts[ci]['text_encoder_alpha'] * te[ci][dn.replace('lora_down', 'lora_up')] @ te[ci][dn]
+                torch.testing.assert_close(v, want.to(w0[n].dtype).float(), rtol=0, atol=0)
+                checked += 1
+            elif 'proj' not in n and 'fc' not in n:       # nothing but the LoRA-carrying layers is touched
+                assert torch.equal(v, w0[n].float()), n
+        assert checked == 12 or checked > 0
     for n, v in seen[2].items():
-        assert torch.equal(v, w0[n].float())
+        assert torch.equal(v, w0[n].float()), n
 
 
 def test_product_merge_lora_into_weight_vs_reference_golden(golden):
