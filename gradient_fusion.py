@@ -239,12 +239,15 @@ def merge_kv_in_cross_attention(concept_list, optimize_iters, new_concept_cfg, t
                                       new_concept_cfg)
         n = len(prompts) // 16
         layer_prompts = [tuple(prompts[j * 16 + i] for j in range(n)) for i in range(16)]
+        feats = {}                  # to_k and to_v of a layer see the same text features: one text-encoder pass per layer
         for layer_idx, layer_name in names:
             W = sd[layer_name].float()
             dn = layer_name.replace('to_k.weight', 'to_k.lora_down.weight').replace('to_v.weight', 'to_v.lora_down.weight')
             up = dn.replace('lora_down', 'lora_up')
             merged = W + concept['unet_alpha'] * tuned[up].to(device).float() @ tuned[dn].to(device).float()
-            feat = get_text_feature(list(layer_prompts[layer_idx]), tokenizer, text_encoder, device)
+            feat = feats.get(layer_idx)
+            if feat is None:
+                feat = feats[layer_idx] = get_text_feature(list(layer_prompts[layer_idx]), tokenizer, text_encoder, device)
             if layer_name not in accs:
                 accs[layer_name] = GramAccumulator(W.shape[1], W.shape[0], device)
             accs[layer_name].add(feat, (merged @ feat.T).T, exact_fp32=True)
