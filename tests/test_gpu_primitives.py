@@ -350,6 +350,11 @@ def test_region_attention(ops, emu, dtype, fh, fw, d):
     both = torch.stack([kv[0], kv[0]])
     o1 = ops.region_attn_fwd(q, both[..., :C], both[..., C:], H, d**-0.5, [(0, 0, fh, fw)], fh, fw)
     _check('region_attn.full_cover', o1, base, dtype)
+    # two identical overlapping regions == one region (the covering regions' attentions are summed and divided by their count)
+    one = ops.region_attn_fwd(q, k_src[:2], v_src[:2], H, d**-0.5, boxes[:1], fh, fw)
+    twin = torch.stack([kv[0], kv[1], kv[1]])
+    two = ops.region_attn_fwd(q, twin[..., :C], twin[..., C:], H, d**-0.5, [boxes[0], boxes[0]], fh, fw)
+    _check('region_attn.twin_regions', two, one.float(), dtype)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
