@@ -322,3 +322,58 @@ def test_edlora_pipeline_keeps_its_sampling_graph_across_calls(gpu_branches, mon
     # cross_attention_kwargs: not cached (nothing is known about what they reference), still graphed within the call
     run('a photo of a dog', True, cross_attention_kwargs={})
     assert pipe.last_call_graphed and pipe.last_call_replay_from == 1
+
+
+def test_sampling_graph_cache_over_mixed_layouts_and_eager_calls(emulated_hip, monkeypatch):
+    """The regional pipeline's graph cache under a mixed call sequence: four layouts (two region lists of one shape, no
+    regions, one region), eager calls in between, eviction at two resident graphs. Every call must give EXACTLY what a fresh
+    pipeline computes eagerly for its prompts (the emulated replay reads the K/V buffers that were current at its capture)."""
+    from mixofshow.pipelines import pipeline_regionally_t2iadapter as P
+    from mixofshow.utils import hipgraph as G
+    H, W = 64, 96
+
+    def make():
+        p = P.RegionallyT2IAdapterPipeline.from_pretrained('synthetic://tiny?seed=0', torch_dtype=torch.float32)
+        p.set_new_concept_cfg(_concept_cfg(p.tokenizer, p.text_encoder, ['<potter1>', '<potter2>']))
+        return p
+
+    pipe, ref = make(), make()
+    latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(5))
+
+    class _FakeGraph:
+        def __init__(self, fn, *example):
+            self.fn = fn
+            self.frozen = {id(m.processor): m.processor._kv for m in pipe.unet.modules()
+                           if isinstance(getattr(m, 'processor', None), P.RegionT2I_AttnProcessor) and m.processor._kv is not None}
+
+        def __call__(self, x, t):
+            real = P.RegionT2I_AttnProcessor._source_kv
+            if self.frozen:
+                monkeypatch.setattr(P.RegionT2I_AttnProcessor, '_source_kv', lambda s, *a: self.frozen[id(s)])
+            try:
+                return self.fn(x, t)
+            finally:
+                monkeypatch.setattr(P.RegionT2I_AttnProcessor, '_source_kv', real)
+
+    monkeypatch.setattr(G, 'graphs_usable', lambda device: True)
+    monkeypatch.setattr(G, 'try_capture', lambda fn, *ex: _FakeGraph(fn, *ex))
+    prompts = {
+        'A': [('two people', [('a <potter1> <potter2>', '', [0.0, 0.0, 1.0, 0.6]), ('a dog', 'blurry', [0.2, 0.5, 0.9, 1.0])])],
+        'B': [('a street', [('a red car', '', [0.0, 0.0, 1.0, 0.6]), ('a cat', 'blurry', [0.2, 0.5, 0.9, 1.0])])],
+        'C': [('two people', [])],
+        'D': [('a forest', [('a <potter1> <potter2>, hat', '', [0.1, 0.1, 0.8, 0.5])])],
+    }
+
+    def run(p, key, graph):
+        return p(prompt=prompts[key], negative_prompt=[''], height=H, width=W, num_inference_steps=5, guidance_scale=7.5,
+                 latents=latents.clone(), output_type='latent', hipgraph=graph).images
+
+    want = {k: run(ref, k, False) for k in prompts}
+    seen = []
+    for key, graph in zip('ABCADCBDABCD', (1, 1, 1, 0, 1, 1, 1, 1, 1, 0, 1, 1)):
+        got = run(pipe, key, bool(graph))
+        torch.testing.assert_close(got, want[key], rtol=0, atol=0, msg=f'{key} graph={graph}')
+        seen.append((key, pipe.last_call_replay_from if graph else None))
+        assert len(pipe._sampling_graphs) <= 2
+    assert ('B', 0) in seen and ('D', 0) in seen and ('A', 0) in seen          # cached layouts replay every step ...
+    assert all(r == 1 for k, r in seen if k == 'C' and r is not None)            # ... the region-free one keeps its eager step 0
