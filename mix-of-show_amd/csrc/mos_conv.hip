@@ -401,6 +401,12 @@ int launch_conv(ConvArgs a, hipStream_t st) {
         if (sbm == 64) return a.up ? launch_conv_split<T, 64, 128, true>(a, st) : launch_conv_split<T, 64, 128, false>(a, st);
         return a.up ? launch_conv_split<T, 64, 64, true>(a, st) : launch_conv_split<T, 64, 64, false>(a, st);
     }
+    if (const char* e = getenv("MOS_CONV_TILE")) {
+        const int v = atoi(e);
+        if (v == 256128 && a.Cout % 128 == 0) return launch_conv_cfg<T, 256, 128, 3>(a, st);
+        if (v == 256256 && a.Cout % 256 == 0) return launch_conv_cfg<T, 256, 256, 2>(a, st);
+        if (v == 25664) return launch_conv_cfg<T, 256, 64, 3>(a, st);
+    }
     int bn = (a.Cout % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
     if (tiles(bm, bn) < 384) bm = 64;
