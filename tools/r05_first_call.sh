@@ -46,5 +46,16 @@ for half in train regional; do
       > "$O/${TAG}_bench_${half}_under_rocprof.json" 2> "$O/${TAG}_rocprof_${half}.err"
   f=$(find /tmp/prof_$half -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp "$f" "$O/${TAG}_rocprofv3_kernel_stats_bench_${half}.csv"
+  # the launch ORDER of the last steps (which kernels surround the ~76 strided copies per training step that the CPU replay of
+  # the host code does not show? DESIGN 8): name + start + duration of the last 9000 launches
+  t=$(find /tmp/prof_$half -name "*kernel_trace.csv" | head -1)
+  [ -n "$t" ] && python - "$t" "$O/${TAG}_kernel_order_${half}.csv" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+with open(sys.argv[2], 'w') as f:
+    for r in rows[-9000:]:
+        f.write(f"{r['Kernel_Name'][:110]},{r['Start_Timestamp']},{int(r['End_Timestamp']) - int(r['Start_Timestamp'])}\n")
+PY
 done
 cd "$ROOT"
