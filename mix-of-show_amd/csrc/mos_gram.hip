@@ -306,7 +306,14 @@ inline int64_t gram_rows_per_chunk(int64_t n, int Cin, int Cout) {
 constexpr int HD_COLS = 2048;        // columns per block: 32 per lane of a wave; wave w of the 4 owns the rows i % 4 == w
 constexpr int HD_KMAX = 64;          // rows of S plus rows of Y handled per launch (history 25: 50)
 
-__global__ __launch_bounds__(256) void hist_dots_kernel(const double* __restrict__ S, const double* __restrict__ Y, int64_t ld,
+template <typename HT> struct HT2;
+template <> struct HT2<double> { typedef double2 type; };
+template <> struct HT2<float> { typedef float2 type; };
+
+// HT = storage type of the history rows: double, or float (rows rounded once when stored, all arithmetic in fp64: half the traffic
+// of the passes; the reference's own L-BFGS keeps its whole state in fp32)
+template <typename HT>
+__global__ __launch_bounds__(256) void hist_dots_kernel(const HT* __restrict__ S, const HT* __restrict__ Y, int64_t ld,
                                                         const double* __restrict__ g, int k, int64_t n,
                                                         double* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -319,14 +326,14 @@ __global__ __launch_bounds__(256) void hist_dots_kernel(const double* __restrict
         gv[2 * t + 1] = c + 1 < n ? g[c + 1] : 0.0;
     }
     for (int r = wave; r < 2 * k; r += 4) {          // row r < k: S[r]; otherwise Y[r - k]
-        const double* row = r < k ? S + (int64_t)r * ld : Y + (int64_t)(r - k) * ld;
+        const HT* row = r < k ? S + (int64_t)r * ld : Y + (int64_t)(r - k) * ld;
         double acc = 0.0;
 #pragma unroll
         for (int t = 0; t < HD_COLS / 128; ++t) {
             const int64_t c = c0 + (int64_t)(t * 64 + lane) * 2;
             double a0 = 0.0, a1 = 0.0;
-            if (c + 1 < n) { const double2 v = *reinterpret_cast<const double2*>(row + c); a0 = v.x; a1 = v.y; }
-            else if (c < n) a0 = row[c];
+            if (c + 1 < n) { const typename HT2<HT>::type v = *reinterpret_cast<const typename HT2<HT>::type*>(row + c); a0 = (double)v.x; a1 = (double)v.y; }
+            else if (c < n) a0 = (double)row[c];
             acc = fma(a0, gv[2 * t], acc);
             acc = fma(a1, gv[2 * t + 1], acc);
         }
@@ -344,7 +351,8 @@ __global__ void hist_dots_finalize_kernel(const double* __restrict__ partial, in
     out[r] = acc;
 }
 
-__global__ __launch_bounds__(256) void hist_combine_kernel(const double* __restrict__ S, const double* __restrict__ Y, int64_t ld,
+template <typename HT>
+__global__ __launch_bounds__(256) void hist_combine_kernel(const HT* __restrict__ S, const HT* __restrict__ Y, int64_t ld,
                                                            const double* __restrict__ u, const double* __restrict__ v,
                                                            const double* __restrict__ g, const double* __restrict__ gamma,
                                                            int k, int64_t n, double* __restrict__ d) {
@@ -356,12 +364,13 @@ __global__ __launch_bounds__(256) void hist_combine_kernel(const double* __restr
     const bool two = c + 1 < n;
     double y0 = 0.0, y1 = 0.0, s0 = 0.0, s1 = 0.0;
     for (int i = 0; i < k; ++i) {
-        const double* yr = Y + (int64_t)i * ld + c;
-        const double* sr = S + (int64_t)i * ld + c;
+        const HT* yr = Y + (int64_t)i * ld + c;
+        const HT* sr = S + (int64_t)i * ld + c;
         double ya, yb = 0.0, sa, sb = 0.0;
-        if (two) { const double2 a = *reinterpret_cast<const double2*>(yr), b = *reinterpret_cast<const double2*>(sr);
-                   ya = a.x; yb = a.y; sa = b.x; sb = b.y; }
-        else { ya = yr[0]; sa = sr[0]; }
+        if (two) { const typename HT2<HT>::type a = *reinterpret_cast<const typename HT2<HT>::type*>(yr),
+                                                b = *reinterpret_cast<const typename HT2<HT>::type*>(sr);
+                   ya = (double)a.x; yb = (double)a.y; sa = (double)b.x; sb = (double)b.y; }
+        else { ya = (double)yr[0]; sa = (double)sr[0]; }
         y0 = fma(cu[i], ya, y0); y1 = fma(cu[i], yb, y1);
         s0 = fma(cv[i], sa, s0); s1 = fma(cv[i], sb, s1);
     }
@@ -442,7 +451,7 @@ int64_t mos_lbfgs_history_workspace_bytes(int k, int64_t n) {
     return ((n + HD_COLS - 1) / HD_COLS) * (int64_t)(2 * k) * (int64_t)sizeof(double);
 }
 
-int mos_lbfgs_history_dots(const double* S, const double* Y, int64_t ld, const double* g, int k, int64_t n, double* out,
+int mos_lbfgs_history_dots(const void* S, const void* Y, int64_t ld, int hist_f32, const double* g, int k, int64_t n, double* out,
                            void* ws, void* stream) {
     MOS_REQUIRE(S && Y && g && out && ws, "mos_lbfgs_history_dots: NULL argument");
     MOS_REQUIRE(k > 0 && 2 * k <= HD_KMAX && n > 0 && ld >= n && ld % 2 == 0, "mos_lbfgs_history_dots: k=%d n=%lld ld=%lld (2k <= %d, even ld)",
@@ -451,15 +460,16 @@ int mos_lbfgs_history_dots(const double* S, const double* Y, int64_t ld, const d
     const int nblk = (int)((n + HD_COLS - 1) / HD_COLS);
     char key[64];
     snprintf(key, sizeof(key), "k%d n%lld", k, (long long)n);
-    MosProfScope prof(st, "lbfgs_history_dots", key, 4.0 * k * (double)n, 8.0 * (2.0 * k + 1.0) * (double)n);
-    hipLaunchKernelGGL(hist_dots_kernel, dim3(nblk), dim3(256), 0, st, S, Y, ld, g, k, n, (double*)ws);
+    MosProfScope prof(st, "lbfgs_history_dots", key, 4.0 * k * (double)n, (hist_f32 ? 4.0 : 8.0) * 2.0 * k * (double)n + 8.0 * (double)n);
+    if (hist_f32) hipLaunchKernelGGL(hist_dots_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)S, (const float*)Y, ld, g, k, n, (double*)ws);
+    else hipLaunchKernelGGL(hist_dots_kernel<double>, dim3(nblk), dim3(256), 0, st, (const double*)S, (const double*)Y, ld, g, k, n, (double*)ws);
     int rc = mos_check_launch("hist_dots");
     if (rc) return rc;
     hipLaunchKernelGGL(hist_dots_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblk, 2 * k, out);
     return mos_check_launch("hist_dots_finalize");
 }
 
-int mos_lbfgs_history_combine(const double* S, const double* Y, int64_t ld, const double* u, const double* v, const double* g,
+int mos_lbfgs_history_combine(const void* S, const void* Y, int64_t ld, int hist_f32, const double* u, const double* v, const double* g,
                               const double* gamma, int k, int64_t n, double* d, void* stream) {
     MOS_REQUIRE(S && Y && u && v && g && gamma && d, "mos_lbfgs_history_combine: NULL argument");
     MOS_REQUIRE(k > 0 && k <= HD_KMAX && n > 0 && ld >= n && ld % 2 == 0, "mos_lbfgs_history_combine: k=%d n=%lld ld=%lld", k,
@@ -467,8 +477,9 @@ int mos_lbfgs_history_combine(const double* S, const double* Y, int64_t ld, cons
     hipStream_t st = (hipStream_t)stream;
     char key[64];
     snprintf(key, sizeof(key), "k%d n%lld", k, (long long)n);
-    MosProfScope prof(st, "lbfgs_history_combine", key, 4.0 * k * (double)n, 8.0 * (2.0 * k + 2.0) * (double)n);
-    hipLaunchKernelGGL(hist_combine_kernel, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, st, S, Y, ld, u, v, g, gamma, k, n, d);
+    MosProfScope prof(st, "lbfgs_history_combine", key, 4.0 * k * (double)n, (hist_f32 ? 4.0 : 8.0) * 2.0 * k * (double)n + 16.0 * (double)n);
+    if (hist_f32) hipLaunchKernelGGL(hist_combine_kernel<float>, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, st, (const float*)S, (const float*)Y, ld, u, v, g, gamma, k, n, d);
+    else hipLaunchKernelGGL(hist_combine_kernel<double>, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, st, (const double*)S, (const double*)Y, ld, u, v, g, gamma, k, n, d);
     return mos_check_launch("hist_combine");
 }
 

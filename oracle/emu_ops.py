@@ -191,11 +191,11 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
 
 
 def lbfgs_hist_dots(S, Y, g, k):
-    return S[:k] @ g, Y[:k] @ g
+    return S[:k].double() @ g, Y[:k].double() @ g
 
 
 def lbfgs_hist_combine(S, Y, u, v, g, gamma):
-    return gamma.reshape(()) * (Y.t() @ u - g) + S.t() @ v
+    return gamma.reshape(()) * (Y.double().t() @ u - g) + S.double().t() @ v
 
 
 def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):

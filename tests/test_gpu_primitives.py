@@ -877,3 +877,11 @@ def test_lbfgs_history_kernels_vs_torch():
         assert (d - want_d).abs().max().item() <= 1e-12 * (k ** 0.5) * 10
         sg2, yg2 = ops.lbfgs_hist_dots(Sw, Yw, gv, k)                       # deterministic
         assert torch.equal(sg, sg2) and torch.equal(yg, yg2)
+        # fp32-stored rows, fp64 arithmetic: exact on the rounded rows
+        S32, Y32 = S.float(), Y.float()
+        sg, yg = ops.lbfgs_hist_dots(S32[lo:lo + k], Y32[lo:lo + k], gv, k)
+        d = ops.lbfgs_hist_combine(S32[lo:lo + k], Y32[lo:lo + k], u, v, gv, gamma)
+        torch.cuda.synchronize()
+        Sd, Yd = S32[lo:lo + k].double(), Y32[lo:lo + k].double()
+        assert (sg - Sd @ gv).abs().max().item() <= 1e-11 * scale and (yg - Yd @ gv).abs().max().item() <= 1e-11 * scale
+        assert (d - (gamma * (Yd.t() @ u - gv) + Sd.t() @ v)).abs().max().item() <= 1e-12 * (k ** 0.5) * 10

@@ -521,6 +521,13 @@ def test_lbfgs_fused_history_passes_follow_the_torch_path(gpu_branches, monkeypa
         monkeypatch.setattr(lbfgs, '_fused_history', False)
         xb, lb, eb = lbfgs.minimize(value_and_grad, x0.clone(), 12, history_size=hist)
         assert ea == eb and ((xa - xb).norm() / xb.norm()).item() < 1e-9
+    # fp32-stored pairs (MOS_LBFGS_HIST=f32): a perturbed quasi-Newton model, same minimiser -- the loss reached stays within the
+    # spread the rounding-separated fp64 runs show among themselves
+    monkeypatch.setattr(lbfgs, '_fused_history', True)
+    monkeypatch.setattr(lbfgs, '_hist_f32', True)
+    x32, l32, e32 = lbfgs.minimize(value_and_grad, x0.clone(), 60, history_size=25)
+    print(f'[parity] fp32-stored history: evaluations {e32}, loss {l32:.12e} (fp64 rows: {lt:.12e})')
+    assert abs(l32 - lt) <= 1e-4 * abs(lt) and abs(e32 - et) <= 4
 
 
 def test_gram_accumulator_chunks_and_split(emulated_hip):

@@ -16,7 +16,7 @@ done > "$O/r05_wide_tiles.txt" 2>&1
 cat "$O/r05_wide_tiles.txt"
 echo "== L-BFGS history kernels: primitive parity, then one fusion pass with / without them (MOS_LBFGS_FUSED)"
 timeout 120 python -m pytest tests/test_gpu_primitives.py -m gpu -q -x -k "lbfgs_history" 2>&1 | tail -2
-for knob in "" "MOS_LBFGS_FUSED=0"; do
+for knob in "" "MOS_LBFGS_HIST=f32" "MOS_LBFGS_FUSED=0"; do
   env $knob timeout 150 python bench.py --mode fusion --concepts 14 --steps 1 --warmup 0 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$knob]', d['value'], d.get('solve_seconds_last_pass'))"
