@@ -283,6 +283,16 @@ int mos_gram_accumulate(const void* X, int64_t ldx, const void* Y, int64_t ldy, 
                         int Cin, int Cout, int dtype, double* G, double* P, double* c,
                         void* ws, void* stream);
 int64_t mos_lsq_workspace_bytes(int Cout, int Cin);
+/* L-BFGS history passes of the layer solves (mixofshow/utils/lbfgs.py::_History.step; the reference runs torch.optim.LBFGS,
+ * gradient_fusion.py:78-85, whose two-loop recursion makes the same passes): S, Y hold k stored pairs as rows of n fp64 (row stride ld).
+ *   mos_lbfgs_history_dots   : out[i] = S[i,:] . g, out[k + i] = Y[i,:] . g, i < k   (one pass over both; ws: mos_lbfgs_history_workspace_bytes)
+ *   mos_lbfgs_history_combine: d[j] = gamma[0] * (sum_i u[i] Y[i,j] - g[j]) + sum_i v[i] S[i,j]          (u, v, gamma on the device)
+ *   hist_f32 = 1: the rows of S, Y are stored as fp32 (rounded once when stored; arithmetic stays fp64): half the traffic of the passes */
+int64_t mos_lbfgs_history_workspace_bytes(int k, int64_t n);
+int mos_lbfgs_history_dots(const void* S, const void* Y, int64_t ld, int hist_f32, const double* g, int k, int64_t n, double* out,
+                           void* ws, void* stream);
+int mos_lbfgs_history_combine(const void* S, const void* Y, int64_t ld, int hist_f32, const double* u, const double* v, const double* g,
+                              const double* gamma, int k, int64_t n, double* d, void* stream);
 int mos_lsq_loss_grad_gram(const double* W, const double* G, const double* P, const double* c,
                            double n_times_cout, int Cout, int Cin, double* loss, double* grad,
                            void* ws, void* stream);

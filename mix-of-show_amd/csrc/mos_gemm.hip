@@ -535,6 +535,11 @@ int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
 template <typename T, bool FUSED>
 int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
     if (a.K % GEMM_BK != 0) return launch_gemm_cfg<T, 64, 64, 64, FUSED, true, false, 2>(a, st);
+    if (const char* e = getenv("MOS_GEMM_TILE")) {
+        const int v = atoi(e);
+        if (v == 256128 && a.N % 128 == 0 && a.M >= 2048) return launch_gemm_cfg<T, 256, 128, 64, FUSED, false, true, 3>(a, st);
+        if (v == 25664 && a.M >= 2048) return launch_gemm_cfg<T, 256, 64, 64, FUSED, false, true, 3>(a, st);
+    }
     int bn = (a.N % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
     if (tiles(bm, bn) < 384) bm = 64;

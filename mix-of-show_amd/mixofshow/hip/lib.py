@@ -161,6 +161,9 @@ SIGNATURES = {
     'mos_quick_gelu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     'mos_lsq_workspace_bytes': (_i64, [_i, _i]),
     'mos_lsq_loss_grad_gram': (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),
+    'mos_lbfgs_history_workspace_bytes': (_i64, [_i, _i64]),
+    'mos_lbfgs_history_dots': (_i, [_vp, _vp, _i64, _i, _vp, _i, _i64, _vp, _vp, _vp]),
+    'mos_lbfgs_history_combine': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
 }
 
 _lib = None

@@ -395,6 +395,34 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
     return loss, grad
 
 
+def lbfgs_hist_dots(S, Y, g, k):
+    """(S[:k] @ g, Y[:k] @ g) in ONE pass over both row-major fp64 matrices (rows of n, row stride S.stride(0))."""
+    _dev(S, Y, g)
+    n = g.numel()
+    assert S.dtype == Y.dtype and S.dtype in (torch.float64, torch.float32) and g.dtype == torch.float64
+    assert S.stride(1) == 1 and Y.stride(1) == 1 and g.is_contiguous()
+    assert S.stride(0) == Y.stride(0) and S.shape[1] == Y.shape[1] == n and 0 < k <= min(S.shape[0], Y.shape[0])
+    out = torch.empty(2 * k, dtype=torch.float64, device=g.device)
+    L = _lib.load()
+    ws = torch.empty((L.mos_lbfgs_history_workspace_bytes(k, n) + 7) // 8, dtype=torch.float64, device=g.device)
+    _lib.check(L.mos_lbfgs_history_dots(_p(S), _p(Y), S.stride(0), int(S.dtype == torch.float32), _p(g), k, n, _p(out), _p(ws), _stream()),
+               'mos_lbfgs_history_dots')
+    return out[:k], out[k:]
+
+
+def lbfgs_hist_combine(S, Y, u, v, g, gamma):
+    """gamma * (Y^T u - g) + S^T v for row-major fp64 S, Y (k rows of n) and device vectors u, v (k), g (n), gamma (1)."""
+    _dev(S, Y, u, v, g, gamma)
+    k, n = S.shape[0], g.numel()
+    assert S.dtype == Y.dtype and S.dtype in (torch.float64, torch.float32) and g.dtype == u.dtype == v.dtype == gamma.dtype == torch.float64
+    assert S.stride(1) == 1 and Y.stride(1) == 1 and S.stride(0) == Y.stride(0) and Y.shape[0] == k and S.shape[1] == Y.shape[1] == n
+    assert u.numel() == v.numel() == k and u.is_contiguous() and v.is_contiguous() and g.is_contiguous() and gamma.numel() == 1
+    d = torch.empty_like(g)
+    _lib.check(_lib.load().mos_lbfgs_history_combine(_p(S), _p(Y), S.stride(0), int(S.dtype == torch.float32), _p(u), _p(v), _p(g), _p(gamma),
+                                                     k, n, _p(d), _stream()), 'mos_lbfgs_history_combine')
+    return d
+
+
 # ------------------------------------------------------------------------------------------------
 # fused GroupNorm (+ SiLU) — caller-side plumbing kernel (SURVEY.md 8(f).1)
 # ------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ Emulations compute in fp32 from the (possibly half) inputs and round the result 
 import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_fwd_ex', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
-            'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
+            'gram_accumulate', 'lsq_loss_grad', 'lbfgs_hist_dots', 'lbfgs_hist_combine', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
             'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
 PAD = 16
 
@@ -188,6 +188,14 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
     R = W @ G - P
     loss = ((R * W).sum() - (P * W).sum() + c.reshape(())) / n_times_cout
     return loss, 2.0 * R / n_times_cout
+
+
+def lbfgs_hist_dots(S, Y, g, k):
+    return S[:k].double() @ g, Y[:k].double() @ g
+
+
+def lbfgs_hist_combine(S, Y, u, v, g, gamma):
+    return gamma.reshape(()) * (Y.double().t() @ u - g) + S.double().t() @ v
 
 
 def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):

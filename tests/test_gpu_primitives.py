@@ -857,3 +857,36 @@ def test_conv3x3_nhwc(ops, emu, dtype, B, Cin, Cout, H, W, extras):
             os.environ.pop('MOS_CONV_SPLITK')
         _check(f'conv3x3 split-K vs unsplit [{B}x{Cin}->{Cout}x{H}x{W} {extras}]', y, y1, dtype, ulps=1.0)
         print(f'[parity] conv3x3 split-K [{B}x{Cin}->{Cout}x{Ho}x{Wo}] bit-identical to the unsplit kernel: {torch.equal(y, y1)}')
+
+
+def test_lbfgs_history_kernels_vs_torch():
+    """mos_lbfgs_history_dots / _combine (the four passes of an L-BFGS iteration over the stored pairs as two streaming kernels)
+    against the fp64 torch mat-vecs, on whole buffers and on a row window of a larger buffer, k < 25 and k = 25."""
+    from mixofshow.hip import ops
+    g = torch.Generator().manual_seed(5)
+    for n, rows, lo, k in ((320 * 320, 50, 0, 25), (768 * 768, 50, 7, 25), (1280 * 320, 50, 0, 3), (2050, 10, 2, 5)):
+        S = torch.randn(rows, n, generator=g, dtype=torch.float64).to(DEV)
+        Y = torch.randn(rows, n, generator=g, dtype=torch.float64).to(DEV)
+        gv = torch.randn(n, generator=g, dtype=torch.float64).to(DEV)
+        u = torch.randn(k, generator=g, dtype=torch.float64).to(DEV)
+        v = torch.randn(k, generator=g, dtype=torch.float64).to(DEV)
+        gamma = torch.tensor([0.37], dtype=torch.float64, device=DEV)
+        Sw, Yw = S[lo:lo + k], Y[lo:lo + k]
+        sg, yg = ops.lbfgs_hist_dots(Sw, Yw, gv, k)
+        d = ops.lbfgs_hist_combine(Sw, Yw, u, v, gv, gamma)
+        torch.cuda.synchronize()
+        want_sg, want_yg = Sw @ gv, Yw @ gv
+        want_d = gamma * (Yw.t() @ u - gv) + Sw.t() @ v
+        scale = n ** 0.5
+        assert (sg - want_sg).abs().max().item() <= 1e-11 * scale and (yg - want_yg).abs().max().item() <= 1e-11 * scale
+        assert (d - want_d).abs().max().item() <= 1e-12 * (k ** 0.5) * 10
+        sg2, yg2 = ops.lbfgs_hist_dots(Sw, Yw, gv, k)                       # deterministic
+        assert torch.equal(sg, sg2) and torch.equal(yg, yg2)
+        # fp32-stored rows, fp64 arithmetic: exact on the rounded rows
+        S32, Y32 = S.float(), Y.float()
+        sg, yg = ops.lbfgs_hist_dots(S32[lo:lo + k], Y32[lo:lo + k], gv, k)
+        d = ops.lbfgs_hist_combine(S32[lo:lo + k], Y32[lo:lo + k], u, v, gv, gamma)
+        torch.cuda.synchronize()
+        Sd, Yd = S32[lo:lo + k].double(), Y32[lo:lo + k].double()
+        assert (sg - Sd @ gv).abs().max().item() <= 1e-11 * scale and (yg - Yd @ gv).abs().max().item() <= 1e-11 * scale
+        assert (d - (gamma * (Yd.t() @ u - gv) + Sd.t() @ v)).abs().max().item() <= 1e-12 * (k ** 0.5) * 10

@@ -482,6 +482,54 @@ def test_lbfgs_iteration_is_a_few_dozen_device_operations():
         assert evals >= iters * 0.9 and per_eval <= 36.0
 
 
+def test_lbfgs_fused_history_passes_follow_the_torch_path(gpu_branches, monkeypatch):
+    """On a HIP device `_History.step` hands its four passes over S, Y to two streaming kernels (mos_lbfgs_history_dots /
+    _combine; emulated here): same iterates as the torch mat-vec form to rounding, same evaluation counts."""
+    from mixofshow.utils import lbfgs
+    g = torch.Generator().manual_seed(3)
+    cin, cout = 48, 40
+    X = torch.randn(300, cin, dtype=torch.float64, generator=g) * torch.logspace(0, -3, cin, dtype=torch.float64)
+    G = X.t() @ X
+    P = torch.randn(cout, cin, dtype=torch.float64, generator=g) @ G
+
+    def value_and_grad(x):
+        W = x.view(cout, cin)
+        WG = W @ G
+        return ((W * WG).sum() - 2 * (W * P).sum()) / 1e3, ((WG - P) * (2 / 1e3)).reshape(-1)
+
+    x0 = torch.zeros(cout * cin, dtype=torch.float64)
+    calls = {'dots': 0, 'combine': 0}
+    import mixofshow.hip.ops as ops
+    real_d, real_c = ops.lbfgs_hist_dots, ops.lbfgs_hist_combine
+    monkeypatch.setattr(ops, 'lbfgs_hist_dots', lambda *a: (calls.__setitem__('dots', calls['dots'] + 1), real_d(*a))[1])
+    monkeypatch.setattr(ops, 'lbfgs_hist_combine', lambda *a: (calls.__setitem__('combine', calls['combine'] + 1), real_c(*a))[1])
+    for hist in (4, 25):
+        monkeypatch.setattr(lbfgs, '_fused_history', True)
+        xf, lf, ef = lbfgs.minimize(value_and_grad, x0.clone(), 60, history_size=hist)
+        n_fused = dict(calls)
+        monkeypatch.setattr(lbfgs, '_fused_history', False)
+        xt, lt, et = lbfgs.minimize(value_and_grad, x0.clone(), 60, history_size=hist)
+        assert calls == n_fused and n_fused['dots'] == n_fused['combine'] > 30           # (only the fused run calls the kernels)
+        calls.update(dots=0, combine=0)
+        rel = ((xf - xt).norm() / xt.norm()).item()
+        print(f'[parity] fused vs torch history passes, history {hist}: evaluations {ef} / {et}, loss {lf:.12e} / {lt:.12e}, rel dx {rel:.2e}')
+        # (60 iterations on an ill-conditioned problem: the trajectories separate by rounding, like torch's own do between runs
+        # of different summation order; the first 12 iterations must coincide)
+        assert abs(ef - et) <= 2 and abs(lf - lt) <= 1e-4 * abs(lt) and rel < 2e-2
+        monkeypatch.setattr(lbfgs, '_fused_history', True)
+        xa, la, ea = lbfgs.minimize(value_and_grad, x0.clone(), 12, history_size=hist)
+        monkeypatch.setattr(lbfgs, '_fused_history', False)
+        xb, lb, eb = lbfgs.minimize(value_and_grad, x0.clone(), 12, history_size=hist)
+        assert ea == eb and ((xa - xb).norm() / xb.norm()).item() < 1e-9
+    # fp32-stored pairs (MOS_LBFGS_HIST=f32): a perturbed quasi-Newton model, same minimiser -- the loss reached stays within the
+    # spread the rounding-separated fp64 runs show among themselves
+    monkeypatch.setattr(lbfgs, '_fused_history', True)
+    monkeypatch.setattr(lbfgs, '_hist_f32', True)
+    x32, l32, e32 = lbfgs.minimize(value_and_grad, x0.clone(), 60, history_size=25)
+    print(f'[parity] fp32-stored history: evaluations {e32}, loss {l32:.12e} (fp64 rows: {lt:.12e})')
+    assert abs(l32 - lt) <= 1e-4 * abs(lt) and abs(e32 - et) <= 4
+
+
 def test_gram_accumulator_chunks_and_split(emulated_hip):
     """G, P, c are independent of chunking and of the representation of the features (half, fp32-on-a-half-grid,
     general fp32 through the hi+lo split)."""

@@ -1,0 +1,139 @@
+"""Lane-level model of the data movement of conv3x3_halo_kernel (branch next/): LDS as an element array, dma16 = 16 B per lane at
+(wave-uniform base) + lane * 16 from a global byte offset (zeros out of range), ld16 = 8 elements at an LDS element address, the
+16x16x32 MFMA by its lane layout. The kernel's index arithmetic is transcribed literally; the sum is compared with conv2d.
+The same model with the raster kernel's arithmetic (known to be right on the device) validates the model itself."""
+import numpy as np
+import torch
+
+CBK = 64
+
+
+def mfma16(acc, afrag, bfrag):
+    """acc[lane][r] (D row = (lane >> 4) * 4 + r, col = lane & 15) += sum_k A[row][k] B[k][col];
+    afrag[lane] = A[row = lane & 15][k = (lane >> 4) * 8 + e], bfrag[lane] = B[k = (lane >> 4) * 8 + e][col = lane & 15]."""
+    A = np.zeros((16, 32)); Bm = np.zeros((32, 16))
+    for lane in range(64):
+        A[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = afrag[lane]
+        Bm[(lane >> 4) * 8:(lane >> 4) * 8 + 8, lane & 15] = bfrag[lane]
+    D = A @ Bm
+    for lane in range(64):
+        for r in range(4):
+            acc[lane][r] += D[(lane >> 4) * 4 + r, lane & 15]
+
+
+def run_halo(x, w, TH, BN):
+    """x (B, H, W, C) NHWC, w (Cout, 3, 3, C). Returns y (B, H, W, Cout) computed tile by tile like the kernel."""
+    B, H, Wd, C = x.shape
+    N = w.shape[0]
+    K = 9 * C
+    MI, NJ, WCH = TH // 2, BN // 32, BN * 8 // 256
+    HW18 = 18
+    HR = (TH + 2) * HW18
+    NP = (HR + 7) // 8
+    NPW = (NP + 3) // 4
+    HB = NPW * 4 * 8 * CBK
+    xg = x.reshape(-1).astype(np.float64)           # element-addressed global memory (offsets below are in BYTES, 2 per element)
+    wg = w.reshape(-1).astype(np.float64)
+    y = np.zeros((B, H, Wd, N))
+    tx_n, ty_n = (Wd + 15) // 16, (H + TH - 1) // TH
+    mt, nt = B * tx_n * ty_n, (N + BN - 1) // BN
+    cpt = C // 64
+
+    def gload(mem, byte_off, limit_bytes):
+        if byte_off < 0 or byte_off + 16 > limit_bytes:
+            return np.zeros(8)
+        return mem[byte_off // 2: byte_off // 2 + 8]
+
+    for m_tile in range(mt):
+        for n_tile in range(nt):
+            b, tr = divmod(m_tile, tx_n * ty_n)
+            y0, x0 = (tr // tx_n) * TH, (tr - (tr // tx_n) * tx_n) * 16
+            n0 = n_tile * BN
+            lds_h = np.zeros(2 * HB)
+            lds_w = np.zeros(3 * BN * CBK)
+            acc = {(wave, j, i): [[0.0] * 4 for _ in range(64)] for wave in range(4) for j in range(NJ) for i in range(MI)}
+            OOB = 1 << 40
+
+            def hoff(wave, lane, i):
+                hr = (wave + 4 * i) * 8 + (lane >> 3)
+                hy, hx = divmod(hr, HW18)
+                yy, xx = y0 + hy - 1, x0 + hx - 1
+                lc = (lane & 7) ^ (hr & 7)
+                ok = hr < HR and 0 <= yy < H and 0 <= xx < Wd
+                return (((b * H + yy) * Wd + xx) * C + lc * 8) * 2 if ok else -1
+
+            def issue_halo(cch, hb):
+                live = cch < cpt
+                for wave in range(4):
+                    for i in range(NPW):
+                        if True:
+                            base = hb * HB + (wave + 4 * i) * 512
+                            for lane in range(64):
+                                o = hoff(wave, lane, i)
+                                src = o + cch * CBK * 2 if (live and o >= 0) else OOB
+                                lds_h[base + lane * 8: base + lane * 8 + 8] = gload(xg, src, xg.size * 2) if src != OOB else 0.0
+
+            def issue_w(cch, tap, buf):
+                live = cch < cpt
+                kb = (tap * C + cch * CBK) * 2
+                for wave in range(4):
+                    for i in range(WCH):
+                        base = buf * BN * CBK + wave * 512 + i * 2048
+                        for lane in range(64):
+                            tid = wave * 64 + lane
+                            cc8 = ((tid & 7) ^ ((tid >> 3) & 7)) * 8
+                            wo = ((n0 + ((tid + 256 * i) >> 3)) * K + cc8) * 2
+                            lds_w[base + lane * 8: base + lane * 8 + 8] = gload(wg, wo + kb, ((N - 1) * K + K) * 2) if live else 0.0
+
+            issue_halo(0, 0)
+            for cch in range(cpt):
+                if cch + 1 < cpt:
+                    issue_halo(cch + 1, (cch + 1) & 1)     # (timing is not modelled: buffers are distinct, order is irrelevant here)
+                hsb = (cch & 1) * HB
+                for tap in range(9):
+                    issue_w(cch, tap, tap % 3)
+                    tapoff = (tap // 3 - 1) * HW18 + (tap % 3 - 1)
+                    for wave in range(4):
+                        wm, wn = wave >> 1, wave & 1
+                        for kk in range(CBK // 32):
+                            bfr = {i: [None] * 64 for i in range(MI)}
+                            afr = {j: [None] * 64 for j in range(NJ)}
+                            for lane in range(64):
+                                l15, lg = lane & 15, lane >> 4
+                                for i in range(MI):
+                                    hr = (wm * MI + i + 1) * HW18 + l15 + 1 + tapoff
+                                    sw = ((kk * 4 + lg) ^ (hr & 7)) * 8
+                                    a0 = hsb + hr * CBK + sw
+                                    bfr[i][lane] = lds_h[a0:a0 + 8].copy()
+                                wsw0 = (lg ^ (l15 & 7)) * 8
+                                for j in range(NJ):
+                                    a0 = (tap % 3) * BN * CBK + (wn * (BN // 2) + l15) * CBK + j * 16 * CBK + (wsw0 ^ 32 if kk else wsw0)
+                                    afr[j][lane] = lds_w[a0:a0 + 8].copy()
+                            for j in range(NJ):
+                                for i in range(MI):
+                                    mfma16(acc[(wave, j, i)], afr[j], bfr[i])
+            for wave in range(4):
+                wm, wn = wave >> 1, wave & 1
+                for j in range(NJ):
+                    for i in range(MI):
+                        for lane in range(64):
+                            l15, lg = lane & 15, lane >> 4
+                            nl = wn * (BN // 2) + j * 16 + lg * 4
+                            ml = (wm * MI + i) * 16 + l15
+                            yy, xx = y0 + (ml >> 4), x0 + (ml & 15)
+                            for r in range(4):
+                                if yy < H and xx < Wd and n0 + nl + r < N:
+                                    y[b, yy, xx, n0 + nl + r] = acc[(wave, j, i)][lane][r]
+    return y
+
+
+if __name__ == '__main__':
+    g = torch.Generator().manual_seed(0)
+    for (B, H, Wd, C, N, TH, BN) in ((1, 8, 16, 64, 64, 8, 64), (2, 10, 20, 128, 64, 8, 64), (1, 17, 33, 64, 128, 16, 128), (1, 9, 16, 64, 96, 8, 64)):
+        x = torch.randn(B, H, Wd, C, generator=g, dtype=torch.float64)
+        w = torch.randn(N, 3, 3, C, generator=g, dtype=torch.float64)
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        got = torch.from_numpy(run_halo(x.numpy(), w.numpy(), TH, BN))
+        err = (got - ref).abs().max().item()
+        print(f'B{B} {H}x{Wd} C{C} N{N} TH{TH} BN{BN}: max|d| = {err:.3e}')
+        assert err < 1e-9
