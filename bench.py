@@ -474,6 +474,38 @@ def run_train(args, rank, world, device):
 
 # ---- part 2: regional sampling ---------------------------------------------------------------------------------------
 REGION_PX = [[2, 2, 512, 184], [7, 184, 512, 345], [1, 488, 512, 747]]  # regionally_sample.sh boxes x (1/2, 768/2048)
+REGION_PX_SHIPPED = [[4, 6, 1024, 490], [14, 490, 1024, 920], [2, 1302, 1024, 1992]]   # regionally_sample.sh:64-74, at 1024x2048
+
+
+def region_px(height, width):
+    """Pixel boxes [h0, w0, h1, w1] of the three regions: the reference's shipped example as is at 1024x2048
+    (regionally_sample.sh:52-90, N = 32768 at level 0), BASELINE configs[4]'s scaled boxes at 512x768, scaled otherwise."""
+    if (height, width) == (1024, 2048):
+        return REGION_PX_SHIPPED
+    if (height, width) == (512, 768):
+        return REGION_PX
+    return [[round(b[0] * height / 1024), round(b[1] * width / 2048), round(b[2] * height / 1024), round(b[3] * width / 2048)]
+            for b in REGION_PX_SHIPPED]
+
+
+def regional_attention_gflop(height, width, n_regions_px):
+    """SURVEY 8(d)'s attention-path count (QK^T, PV, q/k/v/out projections of the 16 transformer blocks, region K/V and boxed
+    attention) for one CFG-pair regional UNet call at any size: 829.5 GFLOP at 512x768 with the three configs[4] boxes."""
+    B, T = 2, 77
+    levels = [(320, 1, 5), (640, 2, 5), (1280, 4, 5), (1280, 8, 1)]
+    area = sum(max(0, b[2] - b[0]) * max(0, b[3] - b[1]) for b in n_regions_px) / float(height * width)
+    R = len(n_regions_px)
+    fl = 0.0
+    for C, down, blocks in levels:
+        N = (height // (8 * down)) * (width // (8 * down))
+        self_core = 4.0 * N * N * C
+        self_proj = 2.0 * N * C * C * 4
+        cross_proj = 2.0 * N * C * C * 2
+        cross_kv = 2.0 * T * 768 * C * 2
+        cross_core = 4.0 * N * T * C
+        region = R * cross_kv + 4.0 * (area * N) * T * C
+        fl += blocks * B * (self_core + self_proj + cross_proj + cross_kv + cross_core + region)
+    return fl / 1e9
 
 
 def build_regional_pipe(preset, device, dtype=torch.float16):
@@ -497,7 +529,7 @@ def regional_prompt(height, width):
     regs = ['a <potter1> <potter2>, in Hogwarts uniform, holding hands, near the castle',
             'a <hermione1> <hermione2>, girl, in Hogwarts uniform, near the castle',
             'a <thanos1> <thanos2>, purple armor, near the castle']
-    regions = [(p, neg, [b[0] / height, b[1] / width, b[2] / height, b[3] / width]) for p, b in zip(regs, REGION_PX)]
+    regions = [(p, neg, [b[0] / height, b[1] / width, b[2] / height, b[3] / width]) for p, b in zip(regs, region_px(height, width))]
     return [(ctx, regions)], neg
 
 
@@ -517,7 +549,7 @@ def synthetic_adapter_states(pipe, height, width, device, dtype, seed=15):
         def forward(self, x):
             return feats
 
-    b = REGION_PX[0]
+    b = region_px(height, width)[0]
     return pipe._adapter_states(_Fixed(), torch.zeros(1, 3, height, width), 1.0, f'[{b[0]}, {b[1]}, {b[2]}, {b[3]}]-0.6',
                                 height, width)
 
@@ -546,7 +578,7 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
     regional UNet steps, VAE decode at 512x768, PIL conversion on the host. `value_ms_latent` = the same 50 steps with
     precomputed adapter states and `output_type='latent'` (the round-1..3 line) for continuity."""
     from mixofshow.hip import profiler
-    H, W = 512, 768
+    H, W = int(getattr(args, 'height', 512)), int(getattr(args, 'width', 768))
     steps = steps or args.steps
     warmup = args.warmup if warmup is None else warmup
     pipe = build_regional_pipe(args.preset, device)
@@ -558,7 +590,7 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
     graph = None if args.regional_graph < 0 else bool(args.regional_graph)
     adapter_states = synthetic_adapter_states(pipe, H, W, device, torch.float16)
     pipe.keypose_adapter, pose, adapter_stds = synthetic_keypose_adapter(pipe, H, W, device, torch.float16)
-    b = REGION_PX[0]
+    b = region_px(H, W)[0]
     region_w = f'[{b[0]}, {b[1]}, {b[2]}, {b[3]}]-0.6'
 
     def sample(g, image_out=True):
@@ -593,16 +625,18 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
         sample(False)
         torch.cuda.synchronize()
     lib_ms = sum(r['total_ms'] for r in recs)
-    res = dict(metric='regional_sample_latency_ms_50step_512x768_3regions', value=round(dt / steps * 1e3, 2),
+    res = dict(metric=f'regional_sample_latency_ms_50step_{H}x{W}_3regions', value=round(dt / steps * 1e3, 2),
                unit='ms', n_gpus=world, steps=steps, warmup=warmup, ms_per_step=round(dt / steps * 1e3, 2),
                value_ms_image=round(dt / steps * 1e3, 2), value_ms_latent=round(dt_lat / steps * 1e3, 2),
                cold_call_ms=round(cold_s * 1e3, 1),
                higher_is_better=False, scaling='weak', vs_baseline=None, dtype='fp16', data='synthetic',
-               config=dict(workload='BASELINE.json configs[4]: 3-region (potter/hermione/thanos) 512x768, 50 '
+               config=dict(workload=('BASELINE.json configs[4]' if (H, W) == (512, 768) else "the reference's shipped example "
+                                     '(regionally_sample.sh:52-90)' if (H, W) == (1024, 2048) else 'regional sample') +
+                                    f': 3-region (potter/hermione/thanos) {H}x{W}, 50 '
                                     'DPM-Solver++(2M) steps, CFG 7.5, batch 1, SD-1.5 random init (calibrated); value / '
                                     'value_ms_image: T2I-Adapter network forward on a seeded pose image + region weight, VAE '
                                     'decode, PIL out (the reference call); value_ms_latent: precomputed seeded adapter states, '
-                                    'latent out (SURVEY 8(d) cfg #5)',
+                                    'latent out (SURVEY 8(d) cfg #5)', height=H, width=W, region_boxes_px=region_px(H, W),
                            replicas=world, preset=args.preset, finite=bool(torch.isfinite(out).all()) and img_ok,
                            hipgraph=graphed, graph_reused_across_calls=graphed,
                            steady_state_eager_steps=eager_steps,
@@ -613,12 +647,13 @@ def run_regional(args, rank, world, device, steps=None, warmup=None):
                            channels_last=bool(args.channels_last), host_cores=os.cpu_count(),
                            **_tuning_switches()),
                roofline=roofline_from_profile(recs) if recs else None,
-               attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_REGIONAL_CALL, 50, recs, 1) if recs else None,
+               attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_REGIONAL_CALL if (H, W) == (512, 768) else
+                                                       regional_attention_gflop(H, W, region_px(H, W)), 50, recs, 1) if recs else None,
                dominant_kernels_by_name=dominant_by_kernel_name(recs, 1) if recs else None,
                kernels=_kernel_table(recs, 1), library_kernel_ms_per_sample=round(lib_ms, 3))
     del pipe
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and H * W <= 512 * 768:     # (a 1024x2048 oracle call takes minutes)
         res['cpu_baseline'] = cpu_baseline_regional(args.preset, H, W)
     return res
 
@@ -810,6 +845,8 @@ def main():
                          'through the dataset / transform chain by DataLoader workers inside the timed region')
     ap.add_argument('--workers', type=int, default=8, help='--data jpeg: DataLoader worker processes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--height', type=int, default=512, help='regional mode: image height (1024 with --width 2048 = the shipped example)')
+    ap.add_argument('--width', type=int, default=768)
     ap.add_argument('--no-regional', action='store_true', help='train mode: skip the regional-sample half of the metric')
     ap.add_argument('--channels-last', type=int, default=1, help='NHWC UNet/VAE (the product default)')
     ap.add_argument('--graph', type=int, default=1, help='train: forward+backward replayed from a hipGraph (the product '

@@ -265,6 +265,20 @@ int mos_region_cross_attn_fwd(const void* q, const void* k_src, const void* v_sr
                               int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Cross-attention with the probabilities MATERIALISED: the controller half of the processor boundary. The reference hands
+ * the full (B*H, N, 77) tensor to any controller between softmax and P.V (mixofshow/models/edlora.py:81-83;
+ * AttentionControl.__call__ / AttentionStore.forward, mixofshow/utils/ptp_util.py:37-53,79-82, store it or edit its conditional
+ * half in place). Controllers that declare the key columns they read take mos_cross_attn_fwd's probability columns instead;
+ * every other controller gets exactly the reference's split:
+ *   mos_attn_probs: probs[(b*H + h), q, j] = softmax_j(scale * q_h[q] . k_h[j])   dense (B*H, Nq, Nkv) in `dtype`
+ *   mos_attn_pv   : o[b, q, h*d + c]       = sum_j probs[(b*H + h), q, j] * v_h[j, c]
+ * shape as for mos_attn_fwd (q/k strides for _probs, v/o strides for _pv); Nkv <= 96, d in {40, 80, 160}, no causal mask.
+ * Inference only (no backward).
+ * ------------------------------------------------------------------------------------------ */
+int mos_attn_probs(const void* q, const void* k, void* probs, const mos_attn_shape* shape_host, int dtype, void* stream);
+int mos_attn_pv(const void* probs, const void* v, void* o, const mos_attn_shape* shape_host, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Gradient-fusion least squares: replaces chunk_compute_mse + the closure of
  * update_quasi_newton (gradient_fusion.py:22-35,62-76). The loss
  *     L(W) = mean((X W^T - Y)^2) = (tr(W G W^T) - 2 tr(W P^T) + c) / (n * Cout)
@@ -283,16 +297,7 @@ int mos_gram_accumulate(const void* X, int64_t ldx, const void* Y, int64_t ldy, 
                         int Cin, int Cout, int dtype, double* G, double* P, double* c,
                         void* ws, void* stream);
 int64_t mos_lsq_workspace_bytes(int Cout, int Cin);
-/* L-BFGS history passes of the layer solves (mixofshow/utils/lbfgs.py::_History.step; the reference runs torch.optim.LBFGS,
- * gradient_fusion.py:78-85, whose two-loop recursion makes the same passes): S, Y hold k stored pairs as rows of n fp64 (row stride ld).
- *   mos_lbfgs_history_dots   : out[i] = S[i,:] . g, out[k + i] = Y[i,:] . g, i < k   (one pass over both; ws: mos_lbfgs_history_workspace_bytes)
- *   mos_lbfgs_history_combine: d[j] = gamma[0] * (sum_i u[i] Y[i,j] - g[j]) + sum_i v[i] S[i,j]          (u, v, gamma on the device)
- *   hist_f32 = 1: the rows of S, Y are stored as fp32 (rounded once when stored; arithmetic stays fp64): half the traffic of the passes */
-int64_t mos_lbfgs_history_workspace_bytes(int k, int64_t n);
-int mos_lbfgs_history_dots(const void* S, const void* Y, int64_t ld, int hist_f32, const double* g, int k, int64_t n, double* out,
-                           void* ws, void* stream);
-int mos_lbfgs_history_combine(const void* S, const void* Y, int64_t ld, int hist_f32, const double* u, const double* v, const double* g,
-                              const double* gamma, int k, int64_t n, double* d, void* stream);
+
 int mos_lsq_loss_grad_gram(const double* W, const double* G, const double* P, const double* c,
                            double n_times_cout, int Cout, int Cin, double* loss, double* grad,
                            void* ws, void* stream);
@@ -376,7 +381,7 @@ int mos_add_layernorm_fwd(const void* x, const void* r, const float* gamma, cons
 int mos_add_layernorm_bwd(const void* dy, const void* ds, const void* s, const float* gamma, const float* stats, void* dx,
                           void* dx_half, int rows, int C, int dtype, int stream_fp32, void* stream);
 int mos_geglu_fwd(const void* h, void* y, int64_t rows, int F, int dtype, void* stream);
-/* y[r, :] = softmax(scale * x[r, :]), x / y (rows, N) contiguous in `dtype` (may alias), N % 8 == 0, N <= 8192: the VAE
+/* y[r, :] = softmax(scale * x[r, :]), x / y (rows, N) contiguous in `dtype` (may alias), N % 8 == 0, N <= 32768: the VAE
  * mid-block attention (single head, d = 512, N = 4096) as scores GEMM -> this -> values GEMM on the library's GEMM. */
 int mos_softmax_rows(const void* x, void* y, int rows, int N, float scale, int dtype, void* stream);
 int mos_geglu_bwd(const void* dy, const void* h, void* dh, int64_t rows, int F, int dtype, void* stream);

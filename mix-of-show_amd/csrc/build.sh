@@ -7,7 +7,7 @@ OUT="${MOS_OUT:-${HERE}/../libmos_hip.so}"
 BUILD="${MOS_BUILD_DIR:-${HERE}/_build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=fast"
-SRCS="mos_api mos_gemm mos_attn mos_gram mos_norm mos_elem mos_conv"
+SRCS="mos_api mos_gemm mos_attn mos_probs mos_gram mos_norm mos_elem mos_conv"
 mkdir -p "${BUILD}"
 pids=()
 # mos_attn only: at one wave per SIMD hipcc selects the AccVGPR form of every MFMA and then copies the accumulators the

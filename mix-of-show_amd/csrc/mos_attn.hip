@@ -472,243 +472,6 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
     }
 }
 
-// ---- forward, software-pipelined (round 4) -------------------------------------------------------------------------------
-// Why (profiles/r03_attention_ablation.txt, r03_microbench_mfma_*.txt): at d = 40 the softmax VALU work of a 64-key tile
-// (32 fma + 32 v_exp + 16 cvt + 16 max3 per lane per 32 queries: ~700 SIMD cycles) costs more than its 14 MFMAs (448 cycles),
-// and in attn_fwd_kernel the two run strictly one after the other -- the matrix pipe idles through the softmax, the VALU through
-// the MFMAs; a second wave on the SIMD does not fill either gap (measured: MFMA and VALU of DIFFERENT waves serialise). Only
-// independent VALU issued by the SAME wave behind an MFMA runs in its shadow. So this kernel
-//   * computes S(j+1) = K(j+1).Q^T while it exponentiates S(j): the two are independent, one basic block;
-//   * keeps that block free of branches: the running maximum is a REFERENCE m_ref that only moves when a tile's maximum
-//     exceeds it by more than 2^LAZY_T (in the exp2 domain); p = exp2(c s - c m_ref) <= 2^LAZY_T fits the half P operand and
-//     the fp32 accumulators; the (rare) move rescales O^T in a cold block at the END of a step, using the maximum of S(j+1)
-//     that this step computed anyway -- no per-tile alpha, no per-tile vote in the hot block;
-//   * row sums from the ones row of the V^T padding (as attn_fwd_kernel), K two tiles ahead in 2 buffers, V^T in 3 buffers:
-//     one barrier per tile;
-//   * tells the scheduler the interleave it should build (sched_group_barrier: 1 MFMA, then a few VALU / TRANS, repeated).
-// 32 queries per wave, 128 per workgroup; Nkv % 64 == 0, no probability columns, no causal mask (the UNet's self-attention:
-// 4096 / 1024 / 6144 / 1536 keys); everything else takes attn_fwd_kernel. Selected by MOS_ATTN_PIPE_FWD=1 (off by default: see launch_fwd).
-constexpr float LAZY_T = 8.0f;
-
-template <typename T, int D>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pipe_kernel(AttnArgs a) {
-    typedef typename MT<T>::v8 v8;
-    constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS;
-    constexpr int KT = HD<D>::ROW_TILE_ELEMS, VT = HD<D>::TR_TILE_ELEMS;
-    static_assert(HD<D>::DV > D, "needs a spare V^T row for the row sums");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* Ks_ = reinterpret_cast<T*>(smem_raw);        // [2] K tiles
-    T* Vt_ = Ks_ + 2 * KT;                          // [3] V^T tiles
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.x % a.H;
-    const int rest = blockIdx.x / a.H;
-    const int qb = rest % a.nqb, b = rest / a.nqb;
-    const int q0 = qb * 128 + wave * 32;
-
-    zero_row_pads<T, D>(Ks_, tid); zero_row_pads<T, D>(Ks_ + KT, tid);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) zero_tr_pads<T, D>(Vt_ + i * VT, tid);
-    __syncthreads();
-    if (tid < KV_TILE) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) Vt_[i * VT + D * TS + tid] = (T)1.0f;       // ones row: O^T row D = running row sum
-    }
-    const T* qp = (const T*)a.q + (int64_t)b * a.q_bs + h * D;
-    const T* kp = (const T*)a.k + (int64_t)b * a.k_bs + h * D;
-    const T* vp = (const T*)a.v + (int64_t)b * a.v_bs + h * D;
-    T* op = (T*)a.o + (int64_t)b * a.o_bs + h * D;
-    const int qi = q0 + l31;
-    v8 qf[KS];
-    load_row_frags<T, D>(qf, qp + (int64_t)min(qi, a.Nq - 1) * a.q_rs, qi < a.Nq, hh);
-    const float c = a.scale * LOG2E;
-
-    RowStage<T, D> kst;
-    TrStage<T, D> vst;
-    kst.init(a.k_rs, tid);
-    vst.init(a.v_rs, tid);
-    const rsrc_t ksrc = make_rsrc(kp, slice_bytes<T, D>(a.Nkv, a.k_rs));
-    const rsrc_t vsrc = make_rsrc(vp, slice_bytes<T, D>(a.Nkv, a.v_rs));
-    const int ktb = KV_TILE * (int)a.k_rs * (int)sizeof(T), vtb = KV_TILE * (int)a.v_rs * (int)sizeof(T);
-    const int nt = a.Nkv / KV_TILE;
-    constexpr int OOB = 0x7FFFFF00;               // past every descriptor: the loads return zeros, no traffic
-
-    // prologue: tiles 0 and 1 resident, S(0) and its maximum
-    kst.load(ksrc, 0);
-    vst.load(vsrc, 0);
-    __syncthreads();                               // (the ones rows / pads above)
-    kst.store(Ks_, tid);
-    vst.store(Vt_, tid);
-    kst.load(ksrc, nt > 1 ? ktb : OOB);
-    vst.load(vsrc, nt > 1 ? vtb : OOB);
-    kst.store(Ks_ + KT, tid);
-    vst.store(Vt_ + VT, tid);
-    __syncthreads();
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-
-    auto scores = [&](const T* Ks, f32x16 (&s)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const v8 af = as_v8<T>(ld16(Ks + (32 * t + l31) * RS + ks * 16 + hh * 8));
-                s[t] = MT<T>::mfma32(af, qf[ks], s[t]);
-            }
-        }
-    };
-    auto tile_max = [&](const f32x16 (&s)[2]) __attribute__((always_inline)) {
-        float mx = s[0][0];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-        return fmaxf(mx, __shfl_xor(mx, 32));
-    };
-
-    f32x16 s_cur[2], s_nxt[2], o[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-    scores(Ks_, s_cur);
-    float m_ref = tile_max(s_cur);                 // raw score units; every p of tile 0 is <= 1
-    __syncthreads();                               // every wave has read K(0): step 0 stores K(2) over it
-    const float lazy = LAZY_T / c;                 // the reference moves when a tile maximum exceeds it by this much
-
-    int kbuf = 1, vcur = 0, vfree = 2;             // K(j+1) buffer ; V(j) buffer ; V buffer that takes tile j+2
-    for (int j = 0; j < nt; ++j) {
-        const T* Kn = Ks_ + kbuf * KT;
-        const T* Vc = Vt_ + vcur * VT;
-        const bool more2 = j + 2 < nt;
-        kst.load(ksrc, more2 ? (j + 2) * ktb : OOB);
-        vst.load(vsrc, more2 ? (j + 2) * vtb : OOB);
-        // The step as 14 slots, one MFMA each: 6 of S(j+1) = K(j+1) Q^T (the two 32-row halves alternating: independent chains),
-        // then 8 of O^T += V^T(j) P(j). Behind every MFMA run the independent VALU / transcendental ops of ~2.3 elements of
-        // P(j) = exp2(c S(j) - c m_ref) (an MFMA shadows about that much: profiles/r03_microbench_mfma_filler.txt), then the maximum
-        // of S(j+1) and the LDS stores of tile j+2. Slots are fenced by empty volatile asms that every value crossing them passes
-        // through: the accumulators (an MFMA cannot leave its slot), S(j) (no exponential is hoisted), the slot's own p values (none
-        // is sunk). The A-operand fragments are read a whole stage ahead and ride through the fences too: the first version of
-        // this kernel read each one inside its slot and waited on LDS in front of every MFMA (187 vs 161 us at B4 H8 N4096,
-        // profiles/r04_kernel_bench_attn_pipelined_fwd_on.txt).
-        const float mc = m_ref * c;
-        v8 pf[2][2];
-        float pe[32];
-        float mx_n = 0.f;
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        v8 kfr[2][KS], vfr[2][2][DT];
-        #pragma unroll
-        for (int t = 0; t < 2; ++t)
-        #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kfr[t][ks] = as_v8<T>(ld16(Kn + (32 * t + l31) * RS + ks * 16 + hh * 8));
-        asm volatile("" : "+v"(kfr[0][0]), "+v"(kfr[0][1]), "+v"(kfr[0][2]), "+v"(kfr[1][0]), "+v"(kfr[1][1]), "+v"(kfr[1][2]));      // all six K fragments are in flight together; this is the one LDS wait of the step
-        s_nxt[0] = MT<T>::mfma32(kfr[0][0], qf[0], zero16);
-        pe[0] = __builtin_amdgcn_exp2f(s_cur[0][0] * c - mc);
-        pe[1] = __builtin_amdgcn_exp2f(s_cur[0][1] * c - mc);
-        pe[2] = __builtin_amdgcn_exp2f(s_cur[0][2] * c - mc);
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[0]), "+v"(pe[1]), "+v"(pe[2]));
-        s_nxt[1] = MT<T>::mfma32(kfr[1][0], qf[0], zero16);
-        // the V^T fragments of the first 32 keys: consumed four slots from here
-        #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-        #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vfr[0][s2][dt] = tr_afrag<T>(Vc + (32 * dt + l31) * TS, 0, s2, hh);
-        pe[3] = __builtin_amdgcn_exp2f(s_cur[0][3] * c - mc);
-        pe[4] = __builtin_amdgcn_exp2f(s_cur[0][4] * c - mc);
-        pe[5] = __builtin_amdgcn_exp2f(s_cur[0][5] * c - mc);
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[3]), "+v"(pe[4]), "+v"(pe[5]));
-        s_nxt[0] = MT<T>::mfma32(kfr[0][1], qf[1], s_nxt[0]);
-        pe[6] = __builtin_amdgcn_exp2f(s_cur[0][6] * c - mc);
-        pe[7] = __builtin_amdgcn_exp2f(s_cur[0][7] * c - mc);
-        pf[0][0] = v8{(T)pe[0], (T)pe[1], (T)pe[2], (T)pe[3], (T)pe[4], (T)pe[5], (T)pe[6], (T)pe[7]};
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[6]), "+v"(pe[7]));
-        s_nxt[1] = MT<T>::mfma32(kfr[1][1], qf[1], s_nxt[1]);
-        pe[8] = __builtin_amdgcn_exp2f(s_cur[0][8] * c - mc);
-        pe[9] = __builtin_amdgcn_exp2f(s_cur[0][9] * c - mc);
-        pe[10] = __builtin_amdgcn_exp2f(s_cur[0][10] * c - mc);
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[8]), "+v"(pe[9]), "+v"(pe[10]));
-        s_nxt[0] = MT<T>::mfma32(kfr[0][2], qf[2], s_nxt[0]);
-        pe[11] = __builtin_amdgcn_exp2f(s_cur[0][11] * c - mc);
-        pe[12] = __builtin_amdgcn_exp2f(s_cur[0][12] * c - mc);
-        pe[13] = __builtin_amdgcn_exp2f(s_cur[0][13] * c - mc);
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[11]), "+v"(pe[12]), "+v"(pe[13]));
-        s_nxt[1] = MT<T>::mfma32(kfr[1][2], qf[2], s_nxt[1]);
-        pe[14] = __builtin_amdgcn_exp2f(s_cur[0][14] * c - mc);
-        pe[15] = __builtin_amdgcn_exp2f(s_cur[0][15] * c - mc);
-        pf[0][1] = v8{(T)pe[8], (T)pe[9], (T)pe[10], (T)pe[11], (T)pe[12], (T)pe[13], (T)pe[14], (T)pe[15]};
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[14]), "+v"(pe[15]), "+v"(vfr[0][0][0]), "+v"(vfr[0][0][1]), "+v"(vfr[0][1][0]), "+v"(vfr[0][1][1]), "+v"(pf[0][0]), "+v"(pf[0][1]));
-        o[0] = MT<T>::mfma32(vfr[0][0][0], pf[0][0], o[0]);
-        // the V^T fragments of keys 32-63
-        #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-        #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vfr[1][s2][dt] = tr_afrag<T>(Vc + (32 * dt + l31) * TS, 1, s2, hh);
-        pe[16] = __builtin_amdgcn_exp2f(s_cur[1][0] * c - mc);
-        pe[17] = __builtin_amdgcn_exp2f(s_cur[1][1] * c - mc);
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[16]), "+v"(pe[17]));
-        o[1] = MT<T>::mfma32(vfr[0][0][1], pf[0][0], o[1]);
-        pe[18] = __builtin_amdgcn_exp2f(s_cur[1][2] * c - mc);
-        pe[19] = __builtin_amdgcn_exp2f(s_cur[1][3] * c - mc);
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[18]), "+v"(pe[19]));
-        o[0] = MT<T>::mfma32(vfr[0][1][0], pf[0][1], o[0]);
-        pe[20] = __builtin_amdgcn_exp2f(s_cur[1][4] * c - mc);
-        pe[21] = __builtin_amdgcn_exp2f(s_cur[1][5] * c - mc);
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[20]), "+v"(pe[21]));
-        o[1] = MT<T>::mfma32(vfr[0][1][1], pf[0][1], o[1]);
-        pe[22] = __builtin_amdgcn_exp2f(s_cur[1][6] * c - mc);
-        pe[23] = __builtin_amdgcn_exp2f(s_cur[1][7] * c - mc);
-        pf[1][0] = v8{(T)pe[16], (T)pe[17], (T)pe[18], (T)pe[19], (T)pe[20], (T)pe[21], (T)pe[22], (T)pe[23]};
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[22]), "+v"(pe[23]), "+v"(vfr[1][0][0]), "+v"(vfr[1][0][1]), "+v"(vfr[1][1][0]), "+v"(vfr[1][1][1]), "+v"(pf[1][0]));
-        o[0] = MT<T>::mfma32(vfr[1][0][0], pf[1][0], o[0]);
-        pe[24] = __builtin_amdgcn_exp2f(s_cur[1][8] * c - mc);
-        pe[25] = __builtin_amdgcn_exp2f(s_cur[1][9] * c - mc);
-        pe[26] = __builtin_amdgcn_exp2f(s_cur[1][10] * c - mc);
-        pe[27] = __builtin_amdgcn_exp2f(s_cur[1][11] * c - mc);
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[24]), "+v"(pe[25]), "+v"(pe[26]), "+v"(pe[27]));
-        o[1] = MT<T>::mfma32(vfr[1][0][1], pf[1][0], o[1]);
-        pe[28] = __builtin_amdgcn_exp2f(s_cur[1][12] * c - mc);
-        pe[29] = __builtin_amdgcn_exp2f(s_cur[1][13] * c - mc);
-        pe[30] = __builtin_amdgcn_exp2f(s_cur[1][14] * c - mc);
-        pe[31] = __builtin_amdgcn_exp2f(s_cur[1][15] * c - mc);
-        pf[1][1] = v8{(T)pe[24], (T)pe[25], (T)pe[26], (T)pe[27], (T)pe[28], (T)pe[29], (T)pe[30], (T)pe[31]};
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(pe[28]), "+v"(pe[29]), "+v"(pe[30]), "+v"(pe[31]), "+v"(pf[1][1]));
-        o[0] = MT<T>::mfma32(vfr[1][1][0], pf[1][1], o[0]);
-        mx_n = s_nxt[0][0];
-        #pragma unroll
-        for (int r = 0; r < 16; ++r) mx_n = fmaxf(mx_n, s_nxt[0][r]);
-        kst.store(Ks_ + (kbuf ^ 1) * KT, tid);    // K(j) was consumed one step ago
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(mx_n));
-        o[1] = MT<T>::mfma32(vfr[1][1][1], pf[1][1], o[1]);
-        #pragma unroll
-        for (int r = 0; r < 16; ++r) mx_n = fmaxf(mx_n, s_nxt[1][r]);
-        vst.store(Vt_ + vfree * VT, tid);         // the V buffer of tile j-1
-        asm volatile("" : "+v"(s_nxt[0]), "+v"(s_nxt[1]), "+v"(s_cur[0]), "+v"(s_cur[1]), "+v"(o[0]), "+v"(o[1]), "+v"(mx_n));
-        mx_n = fmaxf(mx_n, __shfl_xor(mx_n, 32));
-        __syncthreads();
-#pragma unroll
-        for (int t = 0; t < 2; ++t) s_cur[t] = s_nxt[t];
-        { const int tmp = vcur; vcur = (vcur + 1 == 3) ? 0 : vcur + 1; vfree = tmp; }
-        kbuf ^= 1;
-        if (j + 1 < nt && __any(mx_n > m_ref + lazy)) {   // cold: the reference moves, O^T (with its row sums) follows (the
-                                                           // phantom tile behind the last one, all zeros, must not move it)
-            const float m_new = fmaxf(m_ref, mx_n);
-            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * c);
-            m_ref = m_new;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        }
-    }
-    constexpr int RL = (D % 32) / 8 * 4;
-    static_assert((D % 32) % 8 == 0 && D % 32 != 0, "row D must sit in a register of the hh = 0 lanes");
-    const float lt = __shfl(o[D / 32][RL], l31);
-    const float inv = 1.0f / lt;
-    store_out_rows<T, D>(op + (int64_t)qi * a.o_rs, qi < a.Nq, o, inv, hh);
-    if (a.lse != nullptr && hh == 0 && qi < a.Nq)
-        a.lse[((int64_t)b * a.H + h) * a.Nq + qi] = m_ref * a.scale + __logf(lt);
-}
-
 // ---- regional cross-attention: sum over covering sources of attention / count ---------------------
 // One LDS residency per pass: the K rows and the transposed V of up to NSP sources (context prompt + regions, 65..96
 // keys each: CLIP's 77-token context in three 32-key sub-tiles) are staged together -- every global load of the pass is in
@@ -1457,7 +1220,7 @@ __global__ void attn_bwd_reduce_kernel(const float* __restrict__ part, int nspli
 // with 1-2 elements of softmax work behind every MFMA and an empty volatile asm after each slot that the accumulators and the
 // in-place S / dP vectors pass through (the compiler can neither bunch the MFMAs nor move the exponentials out of their slot).
 // d = 40, no probability columns, no causal mask, whole 64-query tiles: the level-0 self-attention of the UNet; everything else
-// takes attn_bwd_dkdv_kernel. MOS_ATTN_PIPE_DKDV=0 disables it.
+// takes attn_bwd_dkdv_kernel.
 template <typename T, int D>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_pipe_kernel(AttnBwdArgs a) {
     constexpr int NT = 256, NW = 4;
@@ -1783,25 +1546,9 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
     // sequences) they leave CUs idle / unbalanced: fall back to 32 queries per wave when the 256-query grid would
     // not give every CU at least two workgroups.
     const int64_t wg_big = (int64_t)s->H * s->B * ((s->Nq + 4 * QW - 1) / (4 * QW));
-    if constexpr (D == 40) {
-        // MOS_ATTN_PIPE_FWD (default 0; read per call so that tests and same-box A/Bs flip it in one process). Measured, same box
-        // (profiles/r04_kernel_bench_attn_pipe_*.txt): correct, but SLOWER than attn_fwd_kernel -- 185-191 vs 161-164 us at B4 H8
-        // N4096, 215-217 vs 185-186 us at B2 H8 N6144, and 263 us with one wave per SIMD: behind the 14 MFMAs of a tile the
-        // exponentials do not disappear into their shadow the way the isolated microbenchmark suggested (a second wave on the SIMD
-        // helps more than the interleave). Kept for the record and the tests; the dK/dV form of the same idea wins 9 %.
-        const char* pe_ = getenv("MOS_ATTN_PIPE_FWD");
-        const bool pipe = pe_ != nullptr && atoi(pe_) != 0;
-        if (pipe && np == 0 && !s->causal && s->Nkv % KV_TILE == 0 && s->Nkv >= 2 * KV_TILE) {
-            const AttnArgs a = make_args(q, k, v, o, lse, tok, np, pcols, s, 128);
-            size_t plds = (2 * HD<D>::ROW_TILE_ELEMS + 3 * HD<D>::TR_TILE_ELEMS) * sizeof(T);
-            // MOS_ATTN_PIPE_OCC=1: one workgroup per CU (one wave per SIMD), forced through the LDS request: the interleave is
-            // built for a wave that owns its SIMD (MFMA and VALU of different waves serialise, profiles/r03_microbench_*)
-            { const char* oc = getenv("MOS_ATTN_PIPE_OCC"); if (oc != nullptr && atoi(oc) == 1 && plds < 84 * 1024) plds = 84 * 1024; }
-            set_lds(&attn_fwd_pipe_kernel<T, D>, plds);
-            hipLaunchKernelGGL((attn_fwd_pipe_kernel<T, D>), dim3((unsigned)(a.H * a.nqb * a.B)), dim3(256), plds, st, a);
-            return mos_check_launch("attn_fwd_pipe");
-        }
-    }
+    // (a software-pipelined d = 40 forward -- S(j+1) under the exponentials of S(j), lazily moved softmax reference -- was built in
+    //  round 4, measured 185-191 us against 161-164 us for this kernel at B4 H8 N4096, and removed in round 5;
+    //  profiles/r04_kernel_bench_attn_pipe_*.txt)
     if (QW == 64 && wg_big < 512) {
         launch_fwd_qw<T, D, 32>(make_args(q, k, v, o, lse, tok, np, pcols, s, 128), np, lds, st);
     } else {
@@ -1914,15 +1661,11 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
         };
         bool done = false;
         if constexpr (D == 40) {
-            // MOS_ATTN_PIPE_DKDV (default 1): 297.6-304.4 us against 332-334 us for attn_bwd_dkdv_kernel at B4 H8 N4096 on the
-            // same box (profiles/r04_kernel_bench_attn_pipe_*.txt)
-            const char* pe_ = getenv("MOS_ATTN_PIPE_DKDV");
-            const bool pipe = pe_ == nullptr || atoi(pe_) != 0;
-            if (pipe && !pc && !a.causal && s->Nq % KV_TILE == 0 && a.q_per_split % KV_TILE == 0) {
-                size_t plds = lds;
-                { const char* oc = getenv("MOS_ATTN_PIPE_OCC"); if (oc != nullptr && atoi(oc) == 1 && plds < 84 * 1024) plds = 84 * 1024; }
-                set_lds(&attn_bwd_dkdv_pipe_kernel<T, D>, plds);
-                hipLaunchKernelGGL((attn_bwd_dkdv_pipe_kernel<T, D>), grid, dim3(256), plds, st, a);
+            // the slot-interleaved form: 297.6-304.4 us against 332-334 us for attn_bwd_dkdv_kernel at B4 H8 N4096 on the same box
+            // (profiles/r04_kernel_bench_attn_pipe_*.txt); whole query tiles, no probability columns, no causal mask
+            if (!pc && !a.causal && s->Nq % KV_TILE == 0 && a.q_per_split % KV_TILE == 0) {
+                set_lds(&attn_bwd_dkdv_pipe_kernel<T, D>, lds);
+                hipLaunchKernelGGL((attn_bwd_dkdv_pipe_kernel<T, D>), grid, dim3(256), lds, st, a);
                 done = true;
             }
         }

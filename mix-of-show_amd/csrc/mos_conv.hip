@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
 //   K order   : (channel chunk, tap) -- the raster form walks (tap, chunk); same sum, other fp32 association
 //   pipeline  : weight tiles in a ring of 3 (two in flight), halo double-buffered: H(c+1) is issued at tap 0 of chunk c, in front
 //               of that step's weight tile, so the counted wait of tap 1 allows NPW more pieces in flight than the others
-template <typename T, int TH, int BN>
+template <typename T, int TH, int BN, bool UP>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     typedef typename MT<T>::v8 v8;
     constexpr int BM = TH * 16, MI = TH / 2, NJ = BN / 32, WCH = BN * 8 / 256;
@@ -303,7 +303,10 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     const int y0 = (tr / tx_n) * TH, x0 = (tr - (tr / tx_n) * tx_n) * 16;
     const int n0 = n_tile * BN;
 
-    const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((int64_t)a.B * H * Wd * C * (int64_t)sizeof(T)));
+    // UP: the input is read through a nearest 2x upsample -- halo pixel (yy, xx) of the H x Wd image the taps walk is source
+    // pixel (yy >> 1, xx >> 1) of the (H/2) x (Wd/2) tensor; the zero border is the border of the UPSAMPLED image
+    const int Hsrc = UP ? H / 2 : H, Wsrc = UP ? Wd / 2 : Wd;
+    const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((int64_t)a.B * Hsrc * Wsrc * C * (int64_t)sizeof(T)));
     const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * K + K) * (int64_t)sizeof(T)));
     constexpr int OOB = 0x7FFFFF00;
 
@@ -314,7 +317,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
         const int hy = hr / HW18, hx = hr - hy * HW18;
         const int yy = y0 + hy - 1, xx = x0 + hx - 1;
         const int lc = (lane & 7) ^ (hr & 7);
-        hoff[i] = (hr < HR && yy >= 0 && yy < H && xx >= 0 && xx < Wd) ? (((b * H + yy) * Wd + xx) * C + lc * 8) * (int)sizeof(T) : -1;
+        const int ys = UP ? (yy >> 1) : yy, xs = UP ? (xx >> 1) : xx;
+        hoff[i] = (hr < HR && yy >= 0 && yy < H && xx >= 0 && xx < Wd) ? (((b * Hsrc + ys) * Wsrc + xs) * C + lc * 8) * (int)sizeof(T) : -1;
     }
     const int cc8 = ((tid & 7) ^ ((tid >> 3) & 7)) * 8;
 #pragma unroll
@@ -430,19 +434,24 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     }
 }
 
-template <typename T, int TH, int BN>
-int launch_conv_halo(ConvArgs a, hipStream_t st) {
+template <typename T, int TH, int BN, bool UP>
+int launch_conv_halo2(ConvArgs a, hipStream_t st) {
     constexpr int NPW = (((TH + 2) * 18 + 7) / 8 + 3) / 4;
     size_t lds = (size_t)2 * NPW * 32 * CBK * sizeof(T) + (size_t)3 * BN * CBK * sizeof(T);
     const size_t stage = (size_t)TH * 16 * (BN + 8) * sizeof(T);
     if (stage > lds) lds = stage;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TH, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<T, TH, BN, UP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     a.mt = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + 15) / 16);
     a.nt = (a.Cout + BN - 1) / BN;
     const int mt8 = (a.mt + 7) / 8 * 8;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN>), dim3(mt8 * a.nt), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, TH, BN, UP>), dim3(mt8 * a.nt), dim3(256), lds, st, a);
     return mos_check_launch("conv3x3_nhwc(halo)");
+}
+
+template <typename T, int TH, int BN>
+int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
+    return a.up ? launch_conv_halo2<T, TH, BN, true>(a, st) : launch_conv_halo2<T, TH, BN, false>(a, st);
 }
 
 // y = round(sum_z partial[z] + tbias + bias) (+ residual): the epilogue of the unsplit kernel on the summed partials
@@ -480,42 +489,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvArgs 
     st16(reinterpret_cast<T*>(a.Y) + off, from_v8<T>(o));
 }
 
-// split-K plan. Two tilings were measured on the low-resolution levels (profiles/r04_kernel_bench_ff_gn_conv.txt against
-// profiles/r04_kernel_bench_conv_splitk_128wide_tiles.txt, MIOpen in the same tables):
-//   * 64 x 64 tiles (3 workgroups per CU), split where that tiling alone gives <= 320 tiles, ~640 workgroups, >= 6 K tiles each:
-//     batch-4 16x16 67.7 us, 8x8 25.7 us; 512x768 sample 16x24 49.8 us, 8x12 23.1 us (MIOpen: 77.1 / 38.1 / 57.9 / 34.0);
-//   * 128-row x 128-wide tiles (half the L2 -> LDS operand traffic per flop, one workgroup per CU): 76.8 / 30.0 / 60.7 / 22.9 us,
-//     and 224 vs 150 us where it replaced the unsplit kernel at 32x48 -- occupancy beats operand reuse here.
-// The first is the default; MOS_CONV_SPLIT_TILE=128 selects the second (kept for the A/B).
-inline bool conv_splitk_enabled() {          // read per call: tests and same-box A/Bs flip it inside one process
-    const char* e = getenv("MOS_CONV_SPLITK");
-    return e == nullptr || atoi(e) != 0;
-}
-inline bool conv_split_wide() {
-    const char* e = getenv("MOS_CONV_SPLIT_TILE");
-    return e != nullptr && atoi(e) == 128;
-}
-inline int conv_ksplit(int M, int Cout, int Cin, int* kt_per, int* bm) {
+// split-K plan: 64 x 64 tiles (3 workgroups per CU), split where that tiling alone gives <= 320 tiles, ~640 workgroups, >= 6 K
+// tiles each: batch-4 16x16 67.7 us, 8x8 25.7 us; 512x768 sample 16x24 49.8 us, 8x12 23.1 us (MIOpen: 77.1 / 38.1 / 57.9 / 34.0;
+// profiles/r04_kernel_bench_ff_gn_conv.txt). A 128-row x 128-wide tiling (half the L2 -> LDS operand traffic per flop, one
+// workgroup per CU) was measured and lost (76.8 / 30.0 / 60.7 / 22.9 us, profiles/r04_kernel_bench_conv_splitk_128wide_tiles.txt:
+// occupancy beats operand reuse here) -- removed in round 5, like the 256-row tiles of the unsplit form (profiles/r05c1_wide_tiles.txt).
+inline int conv_ksplit(int M, int Cout, int Cin, int* kt_per) {
     const int nk = 9 * (Cin / 64);
-    if (!conv_splitk_enabled() || nk < 36) return 1;
-    int64_t ks;
-    if (conv_split_wide()) {
-        const int64_t t128 = (int64_t)((M + 127) / 128) * ((Cout + 127) / 128);
-        if (t128 >= 384) return 1;
-        *bm = M > 256 ? 128 : 64;
-        const int64_t tiles = (int64_t)((M + *bm - 1) / *bm) * ((Cout + 127) / 128);
-        ks = (640 + tiles - 1) / tiles;
-        if (ks > (int64_t)9 * Cin / (2 * (int64_t)M)) ks = (int64_t)9 * Cin / (2 * (int64_t)M);   // partial bytes <= weight bytes
-        if (ks > 16) ks = 16;
-    } else {
-        *bm = 0;                                  // 64 x 64 tiles
-        const int64_t tiles = (int64_t)((M + 63) / 64) * ((Cout + 63) / 64);
-        const char* mt = getenv("MOS_CONV_SPLIT_MAX_TILES");          // A/B knob: the unsplit tiling is kept above this many tiles
-        const int64_t max_tiles = mt != nullptr ? atoi(mt) : 320;
-        if (tiles > max_tiles) return 1;
-        ks = (640 + tiles - 1) / tiles;
-        if (tiles > 320 && ks < 2) ks = 2;
-    }
+    if (nk < 36) return 1;
+    const int64_t tiles = (int64_t)((M + 63) / 64) * ((Cout + 63) / 64);
+    if (tiles > 320) return 1;
+    int64_t ks = (640 + tiles - 1) / tiles;
     if (ks > nk / 6) ks = nk / 6;               // at least 6 K tiles per workgroup
     if (ks < 2) return 1;
     const int per = (nk + (int)ks - 1) / (int)ks;
@@ -559,42 +543,34 @@ int launch_conv_cfg(const ConvArgs& a, hipStream_t st) {
     return a.up ? launch_conv_cfg2<T, BM, BN, true, NS>(a, st) : launch_conv_cfg2<T, BM, BN, false, NS>(a, st);
 }
 
-// Workgroup count below which the K loop is latency-bound and the DMA ring replaces the double buffer (MOS_RING_MAX_WG=0
-// disables the ring).
-inline int ring_max_wg() {
-    static const int v = [] { const char* e = getenv("MOS_RING_MAX_WG"); return e ? atoi(e) : 640; }();
-    return v;
-}
+// Workgroup count below which the K loop is latency-bound and the DMA ring replaces the double buffer.
+constexpr int RING_MAX_WG = 640;
 
+// Dispatch (round 5, profiles/r05c1_wide_tiles.txt, same box, forward / backward-data in us):
+//   * low-resolution levels (<= 320 tiles of 64 x 64, K >= 36 tiles): split-K raster form;
+//   * maps at least 16 wide and 8 high: the HALO-staged form, 8 x 16 pixels x 64 outputs per workgroup (two workgroups per CU):
+//     B4 320->320 64x64 46/48 -> 38/40, 960->320 133/129 -> 109/104, 640->640 32x32 55/58 -> 43/43, 1920->640 162/101 -> 123/104,
+//     128->128 512x512 416/425 -> 388/354, B2 640->640 32x48 42/46 -> 32/32; the 16 x 16 x 128 tile only where >= 512 input channels
+//     meet >= 256 such tiles (the VAE's 512-channel stages: 324/305 -> 295/281 at 128x128, 82/86 -> 74/77 at 64x64);
+//     8 x 16 x 128 and 16 x 16 x 64 tiles, and 256-row tiles of the raster form, lost everywhere and are gone;
+//   * what is left (maps narrower than 16 pixels that are not split): raster form.
 template <typename T>
 int launch_conv(ConvArgs a, hipStream_t st) {
     char key[112];
-    int kt_per = 0, sbm = 128;
-    const int ks = a.partial != nullptr ? conv_ksplit(a.M, a.Cout, a.Cin, &kt_per, &sbm) : 1;
+    int kt_per = 0;
+    const int ks = a.partial != nullptr ? conv_ksplit(a.M, a.Cout, a.Cin, &kt_per) : 1;
     snprintf(key, sizeof(key), "%s B%d %dx%d Cin%d Cout%d%s%s%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", a.B, a.H, a.Wd,
              a.Cin, a.Cout, a.up ? " up2x" : "", a.tbias ? " +tbias" : "", a.R ? " +res" : "", ks > 1 ? " splitK" : "");
     MosProfScope prof(st, "conv3x3", key, 2.0 * a.M * (double)a.Cout * 9.0 * a.Cin,
                       2.0 * ((double)a.M * a.Cin / (a.up ? 4 : 1) + 9.0 * a.Cin * a.Cout + (double)a.M * a.Cout * (a.R ? 2 : 1)));
     if (ks > 1) {
         a.ksplit = ks; a.kt_per = kt_per;
-        if (sbm == 128) return a.up ? launch_conv_split<T, 128, 128, true>(a, st) : launch_conv_split<T, 128, 128, false>(a, st);
-        if (sbm == 64) return a.up ? launch_conv_split<T, 64, 128, true>(a, st) : launch_conv_split<T, 64, 128, false>(a, st);
         return a.up ? launch_conv_split<T, 64, 64, true>(a, st) : launch_conv_split<T, 64, 64, false>(a, st);
     }
-    if (const char* e = getenv("MOS_CONV_HALO")) {      // branch next/: halo-staged form (not for the upsampling read, not split)
-        const int v = atoi(e);
-        if (v && !a.up && a.Wd >= 16 && a.H >= 8) {
-            if (v == 864) return launch_conv_halo<T, 8, 64>(a, st);
-            if (v == 8128 && a.Cout % 128 == 0) return launch_conv_halo<T, 8, 128>(a, st);
-            if (v == 16128 && a.Cout % 128 == 0 && a.H >= 16) return launch_conv_halo<T, 16, 128>(a, st);
-            if (v == 1664 && a.H >= 16) return launch_conv_halo<T, 16, 64>(a, st);
-        }
-    }
-    if (const char* e = getenv("MOS_CONV_TILE")) {
-        const int v = atoi(e);
-        if (v == 256128 && a.Cout % 128 == 0) return launch_conv_cfg<T, 256, 128, 3>(a, st);
-        if (v == 256256 && a.Cout % 256 == 0) return launch_conv_cfg<T, 256, 256, 2>(a, st);
-        if (v == 25664) return launch_conv_cfg<T, 256, 64, 3>(a, st);
+    if (a.Wd >= 16 && a.H >= 8) {
+        const int64_t t16 = (int64_t)a.B * ((a.H + 15) / 16) * ((a.Wd + 15) / 16) * (a.Cout / 128);
+        if (a.Cin >= 512 && a.Cout % 128 == 0 && a.H >= 16 && t16 >= 256) return launch_conv_halo<T, 16, 128>(a, st);
+        return launch_conv_halo<T, 8, 64>(a, st);
     }
     int bn = (a.Cout % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
@@ -602,7 +578,7 @@ int launch_conv(ConvArgs a, hipStream_t st) {
     if (tiles(bm, bn) < 256 && bn == 128) bn = 64;
     if (bm == 128 && bn == 128) return launch_conv_cfg<T, 128, 128, 2>(a, st);
     if (bm == 128) return launch_conv_cfg<T, 128, 64, 2>(a, st);
-    const bool ring = tiles(bm, bn) <= ring_max_wg();
+    const bool ring = tiles(bm, bn) <= RING_MAX_WG;
     if (bn == 128) return ring ? launch_conv_cfg<T, 64, 128, 3>(a, st) : launch_conv_cfg<T, 64, 128, 2>(a, st);
     return ring ? launch_conv_cfg<T, 64, 64, 4>(a, st) : launch_conv_cfg<T, 64, 64, 2>(a, st);
 }
@@ -613,10 +589,10 @@ extern "C" {
 
 int64_t mos_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 8) return 0;
-    int kt_per = 0, bm = 0;
+    int kt_per = 0;
     const int64_t M = (int64_t)B * H * W;
     if (M > (1 << 20)) return 0;
-    const int ks = conv_ksplit((int)M, Cout, Cin, &kt_per, &bm);
+    const int ks = conv_ksplit((int)M, Cout, Cin, &kt_per);
     return ks > 1 ? (int64_t)ks * M * Cout * (int64_t)sizeof(float) : 0;
 }
 

@@ -323,8 +323,9 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const T* __restrict__ dy
     }
 }
 
-// y[r, :] = softmax(scale * x[r, :]) for half rows of up to 8192 elements; one 256-thread block per row, the row stays
-// in registers (VAE mid-block attention: 4096 x 4096 single-head scores between two library GEMMs).
+// y[r, :] = softmax(scale * x[r, :]) for half rows of up to 32768 elements; one 256-thread block per row, the row stays
+// in registers (VAE mid-block attention: 4096 x 4096 single-head scores between two library GEMMs at 512 x 512; 32768 keys for
+// the 1024 x 2048 images of the reference's regionally_sample.sh: 16 vectors per thread).
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int N, float scale_log2e) {
     typedef typename MT<T>::v8 v8;
@@ -381,7 +382,9 @@ int softmax_rows(const void* x, void* y, int rows, int N, float scale, hipStream
     MosProfScope prof(st, "softmax_rows", key, 5.0 * rows * N, 4.0 * rows * (double)N);
     const float sl = scale * 1.4426950408889634f;
 #define SM_K(NC) hipLaunchKernelGGL((softmax_rows_kernel<T, NC>), dim3(rows), dim3(256), 0, st, (const T*)x, (T*)y, N, sl)
-    switch (nch) { case 1: SM_K(1); break; case 2: SM_K(2); break; case 3: SM_K(3); break; default: SM_K(4); break; }
+    if (nch <= 4) { switch (nch) { case 1: SM_K(1); break; case 2: SM_K(2); break; case 3: SM_K(3); break; default: SM_K(4); break; } }
+    else if (nch <= 8) SM_K(8);
+    else SM_K(16);
 #undef SM_K
     return mos_check_launch("softmax_rows");
 }
@@ -560,7 +563,7 @@ int mos_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int d
 }
 
 int mos_softmax_rows(const void* x, void* y, int rows, int N, float scale, int dtype, void* stream) {
-    MOS_REQUIRE(x && y && rows > 0 && N > 0 && N % 8 == 0 && N <= 8192, "mos_softmax_rows: rows=%d N=%d (N %% 8 == 0, N <= 8192)", rows, N);
+    MOS_REQUIRE(x && y && rows > 0 && N > 0 && N % 8 == 0 && N <= 32768, "mos_softmax_rows: rows=%d N=%d (N %% 8 == 0, N <= 32768)", rows, N);
     if (dtype == MOS_F16) return softmax_rows<f16_t>(x, y, rows, N, scale, (hipStream_t)stream);
     if (dtype == MOS_BF16) return softmax_rows<bf16_t>(x, y, rows, N, scale, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_softmax_rows: dtype %d", dtype);

@@ -535,19 +535,15 @@ int launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
 template <typename T, bool FUSED>
 int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
     if (a.K % GEMM_BK != 0) return launch_gemm_cfg<T, 64, 64, 64, FUSED, true, false, 2>(a, st);
-    if (const char* e = getenv("MOS_GEMM_TILE")) {
-        const int v = atoi(e);
-        if (v == 256128 && a.N % 128 == 0 && a.M >= 2048) return launch_gemm_cfg<T, 256, 128, 64, FUSED, false, true, 3>(a, st);
-        if (v == 25664 && a.M >= 2048) return launch_gemm_cfg<T, 256, 64, 64, FUSED, false, true, 3>(a, st);
-    }
+    // (256-row workgroup tiles -- 256 x 128 and 256 x 64, one wave per SIMD -- were measured in round 5 and lost on every shape:
+    //  M4928 N2304 K768 32 -> 42 us, M4096 N640 K640 13 -> 20 us, M16384 N960 K320 26 -> 26 us; profiles/r05c1_wide_tiles.txt)
     int bn = (a.N % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.N + n - 1) / n); };
     if (tiles(bm, bn) < 384) bm = 64;
     if (tiles(bm, bn) < 256 && bn == 128) bn = 64;
     if (bm == 128 && bn == 128) return launch_gemm_cfg<T, 128, 128, 64, FUSED, false, true, 2>(a, st);
     if (bm == 128) return launch_gemm_cfg<T, 128, 64, 64, FUSED, false, true, 2>(a, st);
-    static const int ring_max_wg = [] { const char* e = getenv("MOS_RING_MAX_WG"); return e ? atoi(e) : 640; }();
-    const bool ring = tiles(bm, bn) <= ring_max_wg;
+    const bool ring = tiles(bm, bn) <= 640;      // grids of <= 640 workgroups: latency-bound K loop, DMA ring instead of the double buffer
     if (ring) {
         if (bn == 128) return launch_gemm_cfg<T, 64, 128, 64, FUSED, false, true, 3>(a, st);
         return launch_gemm_cfg<T, 64, 64, 64, FUSED, false, true, 4>(a, st);

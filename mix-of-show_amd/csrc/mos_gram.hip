@@ -297,88 +297,6 @@ inline int64_t gram_rows_per_chunk(int64_t n, int Cin, int Cout) {
 
 }  // namespace
 
-// ---- L-BFGS history passes (branch next/): what an iteration of the layer solves costs is the traffic over the stored pairs
-// S, Y (25 rows of Cout * Cin fp64 each, 2 x 118 MB for a 768 x 768 layer) -- four passes per iteration, issued as four skinny
-// rocBLAS dgemv calls (k = 25 against n = 589,824). Two streaming kernels do the same four passes as TWO launches at HBM rate:
-//   hist_dots   : out[i] = S[i,:] . g,  out[k + i] = Y[i,:] . g                      (both matrices in one pass, g read once per block)
-//   hist_combine: d[j]   = gamma * (sum_i u[i] Y[i,j] - g[j]) + sum_i v[i] S[i,j]     (the search direction of lbfgs._History.step)
-// Deterministic: fixed column ranges per block, shuffle trees inside a wave, block partials summed in block order.
-constexpr int HD_COLS = 2048;        // columns per block: 32 per lane of a wave; wave w of the 4 owns the rows i % 4 == w
-constexpr int HD_KMAX = 64;          // rows of S plus rows of Y handled per launch (history 25: 50)
-
-template <typename HT> struct HT2;
-template <> struct HT2<double> { typedef double2 type; };
-template <> struct HT2<float> { typedef float2 type; };
-
-// HT = storage type of the history rows: double, or float (rows rounded once when stored, all arithmetic in fp64: half the traffic
-// of the passes; the reference's own L-BFGS keeps its whole state in fp32)
-template <typename HT>
-__global__ __launch_bounds__(256) void hist_dots_kernel(const HT* __restrict__ S, const HT* __restrict__ Y, int64_t ld,
-                                                        const double* __restrict__ g, int k, int64_t n,
-                                                        double* __restrict__ partial) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t c0 = (int64_t)blockIdx.x * HD_COLS;
-    double gv[HD_COLS / 64];
-#pragma unroll
-    for (int t = 0; t < HD_COLS / 128; ++t) {        // lane's columns: c0 + (t * 64 + lane) * 2 + {0, 1}
-        const int64_t c = c0 + (int64_t)(t * 64 + lane) * 2;
-        gv[2 * t] = c < n ? g[c] : 0.0;
-        gv[2 * t + 1] = c + 1 < n ? g[c + 1] : 0.0;
-    }
-    for (int r = wave; r < 2 * k; r += 4) {          // row r < k: S[r]; otherwise Y[r - k]
-        const HT* row = r < k ? S + (int64_t)r * ld : Y + (int64_t)(r - k) * ld;
-        double acc = 0.0;
-#pragma unroll
-        for (int t = 0; t < HD_COLS / 128; ++t) {
-            const int64_t c = c0 + (int64_t)(t * 64 + lane) * 2;
-            double a0 = 0.0, a1 = 0.0;
-            if (c + 1 < n) { const typename HT2<HT>::type v = *reinterpret_cast<const typename HT2<HT>::type*>(row + c); a0 = (double)v.x; a1 = (double)v.y; }
-            else if (c < n) a0 = (double)row[c];
-            acc = fma(a0, gv[2 * t], acc);
-            acc = fma(a1, gv[2 * t + 1], acc);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) partial[(int64_t)blockIdx.x * (2 * k) + r] = acc;
-    }
-}
-
-__global__ void hist_dots_finalize_kernel(const double* __restrict__ partial, int nblk, int k2, double* __restrict__ out) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= k2) return;
-    double acc = 0.0;
-    for (int b = 0; b < nblk; ++b) acc += partial[(int64_t)b * k2 + r];
-    out[r] = acc;
-}
-
-template <typename HT>
-__global__ __launch_bounds__(256) void hist_combine_kernel(const HT* __restrict__ S, const HT* __restrict__ Y, int64_t ld,
-                                                           const double* __restrict__ u, const double* __restrict__ v,
-                                                           const double* __restrict__ g, const double* __restrict__ gamma,
-                                                           int k, int64_t n, double* __restrict__ d) {
-    __shared__ double cu[HD_KMAX], cv[HD_KMAX];
-    if ((int)threadIdx.x < k) { cu[threadIdx.x] = u[threadIdx.x]; cv[threadIdx.x] = v[threadIdx.x]; }
-    __syncthreads();
-    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (c >= n) return;
-    const bool two = c + 1 < n;
-    double y0 = 0.0, y1 = 0.0, s0 = 0.0, s1 = 0.0;
-    for (int i = 0; i < k; ++i) {
-        const HT* yr = Y + (int64_t)i * ld + c;
-        const HT* sr = S + (int64_t)i * ld + c;
-        double ya, yb = 0.0, sa, sb = 0.0;
-        if (two) { const typename HT2<HT>::type a = *reinterpret_cast<const typename HT2<HT>::type*>(yr),
-                                                b = *reinterpret_cast<const typename HT2<HT>::type*>(sr);
-                   ya = (double)a.x; yb = (double)a.y; sa = (double)b.x; sb = (double)b.y; }
-        else { ya = (double)yr[0]; sa = (double)sr[0]; }
-        y0 = fma(cu[i], ya, y0); y1 = fma(cu[i], yb, y1);
-        s0 = fma(cv[i], sa, s0); s1 = fma(cv[i], sb, s1);
-    }
-    const double gm = gamma[0];
-    d[c] = gm * (y0 - g[c]) + s0;
-    if (two) d[c + 1] = gm * (y1 - g[c + 1]) + s1;
-}
-
 extern "C" {
 
 int64_t mos_gram_workspace_bytes(int64_t n, int Cin, int Cout) {
@@ -444,43 +362,6 @@ int mos_lsq_loss_grad_gram(const double* W, const double* G, const double* P, co
     hipLaunchKernelGGL(lsq_loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, (int)(grid.x * grid.y), c,
                        inv, loss);
     return mos_check_launch("lsq_loss_finalize");
-}
-
-int64_t mos_lbfgs_history_workspace_bytes(int k, int64_t n) {
-    if (k <= 0 || n <= 0) return 0;
-    return ((n + HD_COLS - 1) / HD_COLS) * (int64_t)(2 * k) * (int64_t)sizeof(double);
-}
-
-int mos_lbfgs_history_dots(const void* S, const void* Y, int64_t ld, int hist_f32, const double* g, int k, int64_t n, double* out,
-                           void* ws, void* stream) {
-    MOS_REQUIRE(S && Y && g && out && ws, "mos_lbfgs_history_dots: NULL argument");
-    MOS_REQUIRE(k > 0 && 2 * k <= HD_KMAX && n > 0 && ld >= n && ld % 2 == 0, "mos_lbfgs_history_dots: k=%d n=%lld ld=%lld (2k <= %d, even ld)",
-                k, (long long)n, (long long)ld, HD_KMAX);
-    hipStream_t st = (hipStream_t)stream;
-    const int nblk = (int)((n + HD_COLS - 1) / HD_COLS);
-    char key[64];
-    snprintf(key, sizeof(key), "k%d n%lld", k, (long long)n);
-    MosProfScope prof(st, "lbfgs_history_dots", key, 4.0 * k * (double)n, (hist_f32 ? 4.0 : 8.0) * 2.0 * k * (double)n + 8.0 * (double)n);
-    if (hist_f32) hipLaunchKernelGGL(hist_dots_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)S, (const float*)Y, ld, g, k, n, (double*)ws);
-    else hipLaunchKernelGGL(hist_dots_kernel<double>, dim3(nblk), dim3(256), 0, st, (const double*)S, (const double*)Y, ld, g, k, n, (double*)ws);
-    int rc = mos_check_launch("hist_dots");
-    if (rc) return rc;
-    hipLaunchKernelGGL(hist_dots_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nblk, 2 * k, out);
-    return mos_check_launch("hist_dots_finalize");
-}
-
-int mos_lbfgs_history_combine(const void* S, const void* Y, int64_t ld, int hist_f32, const double* u, const double* v, const double* g,
-                              const double* gamma, int k, int64_t n, double* d, void* stream) {
-    MOS_REQUIRE(S && Y && u && v && g && gamma && d, "mos_lbfgs_history_combine: NULL argument");
-    MOS_REQUIRE(k > 0 && k <= HD_KMAX && n > 0 && ld >= n && ld % 2 == 0, "mos_lbfgs_history_combine: k=%d n=%lld ld=%lld", k,
-                (long long)n, (long long)ld);
-    hipStream_t st = (hipStream_t)stream;
-    char key[64];
-    snprintf(key, sizeof(key), "k%d n%lld", k, (long long)n);
-    MosProfScope prof(st, "lbfgs_history_combine", key, 4.0 * k * (double)n, (hist_f32 ? 4.0 : 8.0) * 2.0 * k * (double)n + 16.0 * (double)n);
-    if (hist_f32) hipLaunchKernelGGL(hist_combine_kernel<float>, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, st, (const float*)S, (const float*)Y, ld, u, v, g, gamma, k, n, d);
-    else hipLaunchKernelGGL(hist_combine_kernel<double>, dim3((unsigned)((n + 511) / 512)), dim3(256), 0, st, (const double*)S, (const double*)Y, ld, u, v, g, gamma, k, n, d);
-    return mos_check_launch("hist_combine");
 }
 
 }  // extern "C"

@@ -138,6 +138,8 @@ SIGNATURES = {
     'mos_cross_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
     'mos_region_cross_attn_fwd': (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(AttnShape), ctypes.POINTER(RegionDesc),
                                        _i, _vp]),
+    'mos_attn_probs': (_i, [_vp, _vp, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
+    'mos_attn_pv': (_i, [_vp, _vp, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
     'mos_gram_workspace_bytes': (_i64, [_i64, _i, _i]),
     'mos_gram_accumulate': (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'mos_groupnorm_workspace_bytes': (_i64, [_i, _i, _i, _i]),
@@ -161,9 +163,6 @@ SIGNATURES = {
     'mos_quick_gelu_bwd': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     'mos_lsq_workspace_bytes': (_i64, [_i, _i]),
     'mos_lsq_loss_grad_gram': (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _vp]),
-    'mos_lbfgs_history_workspace_bytes': (_i64, [_i, _i64]),
-    'mos_lbfgs_history_dots': (_i, [_vp, _vp, _i64, _i, _vp, _i, _i64, _vp, _vp, _vp]),
-    'mos_lbfgs_history_combine': (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i64, _vp, _vp]),
 }
 
 _lib = None

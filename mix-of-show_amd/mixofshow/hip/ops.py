@@ -365,6 +365,33 @@ def region_attn_fwd(q, k_src, v_src, heads, scale, boxes, feat_h, feat_w):
     return o
 
 
+def attn_probs(q, k, heads, scale):
+    """The reference's `attn.get_attention_scores(query, key)` (edlora.py:81) on the token-major tensors: q (B,Nq,C), k (B,Nkv,C)
+    views -> softmax(scale q k^T) per head as a dense (B*heads, Nq, Nkv) tensor of q's dtype (index b * heads + h, the
+    reference's head_to_batch_dim order). Nkv <= 96. For controllers that need the full map; inference only."""
+    _dev(q, k)
+    assert not (q.requires_grad or k.requires_grad), 'attn_probs has no backward (controllers with gradients declare token_positions)'
+    B, Nq, C = q.shape
+    probs = torch.empty((B * heads, Nq, k.shape[1]), dtype=q.dtype, device=q.device)
+    s = _shape(q, k, k, q, heads, scale)
+    _lib.check(_lib.load().mos_attn_probs(_p(q), _p(k), _p(probs), ctypes.byref(s), _dt(q), _stream()), 'mos_attn_probs')
+    return probs
+
+
+def attn_pv(probs, v, heads):
+    """torch.bmm(attention_probs, value) + batch_to_head_dim (edlora.py:83-85): probs (B*heads, Nq, Nkv) dense, v (B,Nkv,C) view
+    -> (B, Nq, C)."""
+    _dev(probs, v)
+    B, Nkv, C = v.shape
+    assert probs.dim() == 3 and probs.shape[0] == B * heads and probs.shape[2] == Nkv and probs.dtype == v.dtype
+    probs = probs if probs.is_contiguous() else probs.contiguous()
+    Nq = probs.shape[1]
+    o = torch.empty((B, Nq, C), dtype=v.dtype, device=v.device)
+    s = _shape(o, v, v, o, heads, 1.0)
+    _lib.check(_lib.load().mos_attn_pv(_p(probs), _p(v), _p(o), ctypes.byref(s), _dt(v), _stream()), 'mos_attn_pv')
+    return o
+
+
 # ------------------------------------------------------------------------------------------------
 # gradient-fusion least squares (Gram form)
 # ------------------------------------------------------------------------------------------------
@@ -393,34 +420,6 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
     _lib.check(L.mos_lsq_loss_grad_gram(_p(W), _p(G), _p(P), _p(c), float(n_times_cout), Cout, Cin, _p(loss), _p(grad),
                                         _p(ws), _stream()), 'mos_lsq_loss_grad_gram')
     return loss, grad
-
-
-def lbfgs_hist_dots(S, Y, g, k):
-    """(S[:k] @ g, Y[:k] @ g) in ONE pass over both row-major fp64 matrices (rows of n, row stride S.stride(0))."""
-    _dev(S, Y, g)
-    n = g.numel()
-    assert S.dtype == Y.dtype and S.dtype in (torch.float64, torch.float32) and g.dtype == torch.float64
-    assert S.stride(1) == 1 and Y.stride(1) == 1 and g.is_contiguous()
-    assert S.stride(0) == Y.stride(0) and S.shape[1] == Y.shape[1] == n and 0 < k <= min(S.shape[0], Y.shape[0])
-    out = torch.empty(2 * k, dtype=torch.float64, device=g.device)
-    L = _lib.load()
-    ws = torch.empty((L.mos_lbfgs_history_workspace_bytes(k, n) + 7) // 8, dtype=torch.float64, device=g.device)
-    _lib.check(L.mos_lbfgs_history_dots(_p(S), _p(Y), S.stride(0), int(S.dtype == torch.float32), _p(g), k, n, _p(out), _p(ws), _stream()),
-               'mos_lbfgs_history_dots')
-    return out[:k], out[k:]
-
-
-def lbfgs_hist_combine(S, Y, u, v, g, gamma):
-    """gamma * (Y^T u - g) + S^T v for row-major fp64 S, Y (k rows of n) and device vectors u, v (k), g (n), gamma (1)."""
-    _dev(S, Y, u, v, g, gamma)
-    k, n = S.shape[0], g.numel()
-    assert S.dtype == Y.dtype and S.dtype in (torch.float64, torch.float32) and g.dtype == u.dtype == v.dtype == gamma.dtype == torch.float64
-    assert S.stride(1) == 1 and Y.stride(1) == 1 and S.stride(0) == Y.stride(0) and Y.shape[0] == k and S.shape[1] == Y.shape[1] == n
-    assert u.numel() == v.numel() == k and u.is_contiguous() and v.is_contiguous() and g.is_contiguous() and gamma.numel() == 1
-    d = torch.empty_like(g)
-    _lib.check(_lib.load().mos_lbfgs_history_combine(_p(S), _p(Y), S.stride(0), int(S.dtype == torch.float32), _p(u), _p(v), _p(g), _p(gamma),
-                                                     k, n, _p(d), _stream()), 'mos_lbfgs_history_combine')
-    return d
 
 
 # ------------------------------------------------------------------------------------------------
@@ -600,31 +599,40 @@ def softmax_rows(x, scale, out=None):
 
 def single_head_attention_nograd(q, k, v, scale):
     """softmax(scale q k^T) v for ONE head of large dim (VAE mid-block: d = 512, N = 4096), forward only: scores GEMM,
-    row softmax, values GEMM per batch element on the library kernels (the (N, N) scores are materialised, 34 MB)."""
+    row softmax, values GEMM per batch element on the library kernels (the (N, N) scores are materialised, 34 MB; above 8192
+    queries -- the 1024 x 2048 images of the reference's regionally_sample.sh: N = 32768 -- in blocks of 8192 query rows)."""
     _dev(q, k, v)
     import math
     B, N, d = q.shape
+    Nk = k.shape[1]
+    assert Nk <= 32768 and Nk % 8 == 0, 'single_head_attention_nograd: up to 32768 keys (one softmax row per workgroup)'
     o = torch.empty_like(q)
-    S = torch.empty((N, k.shape[1]), dtype=q.dtype, device=q.device)
+    QB = 8192
+    S = torch.empty((min(N, QB), Nk), dtype=q.dtype, device=q.device)
     # the scores are stored in half between the two GEMMs: q is pre-scaled by the power of two below `scale` (exact in
     # half) so that they are stored at (nearly) their softmax scale -- unscaled d = 512 scores are 22x larger, which
     # costs ~0.1 of a scaled logit in rounding at |logit| ~ 100 and overflows half from |logit| ~ 2900 on
     p2 = 2.0 ** math.floor(math.log2(scale)) if scale > 0 else 1.0
     qs = q * p2
     for i in range(B):
-        linear_fwd(qs[i], k[i], out=S)
-        softmax_rows(S, scale / p2, out=S)
-        linear_fwd(S, v[i].t().contiguous(), out=o[i])
+        vt = v[i].t().contiguous()
+        for r0 in range(0, N, QB):
+            r1 = min(N, r0 + QB)
+            Sb = S[:r1 - r0]
+            linear_fwd(qs[i, r0:r1], k[i], out=Sb)
+            softmax_rows(Sb, scale / p2, out=Sb)
+            linear_fwd(Sb, vt, out=o[i, r0:r1])
     return o
 
 
 # ------------------------------------------------------------------------------------------------
 # 3x3 convolution on channels-last activations (implicit GEMM) — caller-side operator (SURVEY.md 8(f).1)
 # ------------------------------------------------------------------------------------------------
-def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False):
+def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False, split_k=True):
     """x: (B, Cin, H, W) half tensor in channels_last memory format; w_ohwi: (Cout, 3, 3, Cin) contiguous half;
     bias fp32 (Cout,); tbias (B, Cout) half; residual like the output. Returns (B, Cout, H', W') channels_last
-    (H' = 2H with upsample2x)."""
+    (H' = 2H with upsample2x). split_k=False: no workspace is handed over, i.e. the unsplit kernel also on the
+    low-resolution levels (tests)."""
     _dev(x, w_ohwi, bias, tbias, residual)
     B, Cin, Hs, Ws = x.shape
     assert _is_nhwc(x) or (Hs == 1 and Ws == 1) or x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_nhwc needs channels_last'
@@ -640,7 +648,7 @@ def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=Fal
         # (memory-format check, not a stride comparison: the stride of a size-1 dimension -- batch 1, a 1x1 map -- is arbitrary)
         assert residual.shape == y.shape and residual.dtype == x.dtype and residual.is_contiguous(memory_format=torch.channels_last)
     L = _lib.load()
-    nbytes = L.mos_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout)      # > 0: the split-K form of the low-resolution levels
+    nbytes = L.mos_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout) if split_k else 0     # > 0: the split-K form of the low-resolution levels
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device) if nbytes > 0 else None
     _lib.check(L.mos_conv3x3_nhwc_ws(_p(x), _p(w_ohwi), _p(bias), _p(tbias), _p(residual), _p(y), B, H, W, Cin, Cout,
                                      int(bool(upsample2x)), _dt(x), _p(ws), _stream()), 'mos_conv3x3_nhwc_ws')

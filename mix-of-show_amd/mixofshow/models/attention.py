@@ -121,12 +121,15 @@ def project(attn, name, linears, x, cd):
     return y
 
 
-def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_idx=None, region=None):
+def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_idx=None, region=None, edit_probs=None):
     """The whole attention layer on the HIP path: projections (+LoRA), fused attention, out-projection.
 
     hidden_states (B, N, C); encoder_hidden_states (B, M, Cc) or None (self-attention).
     tok_idx: int32 (B, T) key positions whose probabilities are returned (training regulariser).
     region: None or dict(k_src, v_src, boxes, feat_h, feat_w) -> regional mask-and-blend attention.
+    edit_probs: None, or a callable P -> P' for the materialised-probability split of a CROSS layer (the reference's
+    `attention_probs = self.controller(attention_probs, ...)` between softmax and bmm, edlora.py:81-83): P is the dense
+    (B*H, N, M) tensor of mos_attn_probs, P' (the same object, edited in place, or a new tensor) feeds mos_attn_pv.
     Returns (out (B, N, C), pcols (B, H, N, T) fp32 | None)."""
     # (device guard: every primitive in mixofshow.hip.ops raises on non-HIP tensors — there is no fallback)
     cd = F_hip.compute_dtype_for(hidden_states)
@@ -150,6 +153,8 @@ def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_i
             from mixofshow.hip import ops
             o = ops.region_attn_fwd(q, region['k_src'], region['v_src'], attn.heads, attn.scale, region['boxes'],
                                     region['feat_h'], region['feat_w'])
+        elif edit_probs is not None:
+            o = _attention_through_probs(attn, q, e, cd, edit_probs)
         elif _sites(attn.to_k, attn.to_v) is not None:
             kv = project(attn, 'kv', [attn.to_k, attn.to_v], e, cd)
             o, pcols = F_hip.attention_q_kv(q, kv, attn.heads, attn.scale, tok_idx=tok_idx)
@@ -164,15 +169,39 @@ def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_i
     return out, pcols
 
 
+def _attention_through_probs(attn, q, e, cd, edit_probs):
+    """softmax(scale q k^T) as a tensor -> edit_probs -> P' v (mos_attn_probs / mos_attn_pv): the controller boundary of the
+    reference with the full map, for controllers that do not declare the columns they read. Inference only."""
+    from mixofshow.hip import ops
+    if torch.is_grad_enabled() and (q.requires_grad or e.requires_grad):
+        raise NotImplementedError(
+            'materialised attention probabilities have no backward on the HIP path: a controller used in TRAINING must declare '
+            '`token_positions` (mixofshow.utils.ptp_util.AttentionStore does), and receives those probability columns with '
+            'autograd through them')
+    if e.shape[1] > 96:
+        raise NotImplementedError(f'materialised probabilities are built for text keys (<= 96), got {e.shape[1]}')
+    if _sites(attn.to_k, attn.to_v) is not None:
+        kv = project(attn, 'kv', [attn.to_k, attn.to_v], e, cd)
+        C = kv.shape[-1] // 2
+        k, v = kv[..., :C], kv[..., C:]
+    else:
+        k = project(attn, 'k', [attn.to_k], e, cd)
+        v = project(attn, 'v', [attn.to_v], e, cd)
+    probs = ops.attn_probs(q.detach(), k.detach(), attn.heads, attn.scale)
+    edited = edit_probs(probs)
+    probs = probs if edited is None else edited
+    if probs.dtype != v.dtype:
+        probs = probs.to(v.dtype)
+    return ops.attn_pv(probs, v.detach(), attn.heads)
+
+
 def _check_plain(attn):
     assert attn.spatial_norm is None and attn.group_norm is None and not attn.norm_cross, \
         'spatial_norm / group_norm / norm_cross are not part of the SD-1.5 transformer blocks'
-    if attn.upcast_attention or attn.upcast_softmax:
-        # the reference honours these flags (pipeline_regionally_t2iadapter.py:63-73); the fused kernels always keep
-        # scores / softmax statistics in fp32 registers and round P once to the half MFMA operand, which is neither
-        # the un-upcast nor the upcast torch arithmetic bit for bit — refuse rather than silently ignore the request
-        raise NotImplementedError('upcast_attention / upcast_softmax are not selectable on the fused HIP attention '
-                                  '(scores and softmax are always accumulated in fp32); SD-1.5 sets neither')
+    # upcast_attention / upcast_softmax (honoured by the reference, pipeline_regionally_t2iadapter.py:63-73, and by diffusers'
+    # get_attention_scores) ask for fp32 scores / an fp32 softmax with P cast back to the layer dtype. That IS the arithmetic of
+    # the fused kernels (scores and softmax statistics in fp32 registers, P rounded once to the half MFMA operand), so both flags
+    # are accepted and change nothing; with the flags off the kernels are MORE exact than the reference's half scores, not less.
 
 
 class MosAttnProcessor:

@@ -74,14 +74,14 @@ def _select_layer_states(encoder_hidden_states, idx):
     return encoder_hidden_states
 
 
-def _run(attn, hidden_states, encoder_hidden_states, tok_idx=None):
+def _run(attn, hidden_states, encoder_hidden_states, tok_idx=None, edit_probs=None):
     _check_plain(attn)
     residual = hidden_states
     ndim = hidden_states.ndim
     if ndim == 4:
         b, c, h, w = hidden_states.shape
         hidden_states = hidden_states.view(b, c, h * w).transpose(1, 2)
-    out, pcols = fused_attention_layer(attn, hidden_states, encoder_hidden_states, tok_idx=tok_idx)
+    out, pcols = fused_attention_layer(attn, hidden_states, encoder_hidden_states, tok_idx=tok_idx, edit_probs=edit_probs)
     if ndim == 4:
         out = out.transpose(-1, -2).reshape(b, c, h, w)
     if attn.residual_connection:
@@ -107,11 +107,16 @@ class EDLoRA_AttnProcessor:
 class EDLoRA_Control_AttnProcessor:
     """Same, reporting attention probabilities to a controller (reference edlora.py:22-100).
 
-    Controllers that expose `token_positions` (int32 (B, T) key indices, see
-    mixofshow.utils.ptp_util.AttentionStore) receive the (B, H, N, T) probabilities of exactly those
-    columns; a controller without that attribute that returns its input unchanged (the reference's
-    DummyController) receives nothing. Controllers that want the full (B*H, N, 77) map are not
-    supported on the fused path and raise."""
+    Three kinds of controller (the reference knows one: it always materialises the (B*H, N, 77) map, :81-83):
+      * controllers that expose `token_positions` (int32 (B, T) key indices; mixofshow.utils.ptp_util.AttentionStore, the
+        training-time regulariser) receive the (B, H, N, T) probabilities of exactly those columns, produced inside the fused
+        kernel, with autograd through them;
+      * `is_passthrough = True` (the reference's DummyController / EmptyControl): called with None, bookkeeping only;
+      * ANY OTHER controller -- e.g. the reference's own `AttentionStore` / `AttentionControl` objects
+        (mixofshow/utils/ptp_util.py:22-108), prompt-to-prompt editors -- gets the reference's protocol verbatim: the dense
+        (B*H, N, 77) probability tensor (mos_attn_probs), may store it or edit it in place (the eval-mode rule "second half of
+        the CFG batch only", ptp_util.py:45-46, is the controller's own code), and what it returns goes into P.V (mos_attn_pv).
+        Inference only: under autograd this raises (declare `token_positions` for training-time controllers)."""
 
     def __init__(self, cross_attention_idx, place_in_unet, controller, attention_op=None):
         self.cross_attention_idx = cross_attention_idx
@@ -125,15 +130,14 @@ class EDLoRA_Control_AttnProcessor:
         ehs = _select_layer_states(encoder_hidden_states, self.cross_attention_idx)
         ctrl = self.controller
         tok = getattr(ctrl, 'token_positions', None) if is_cross else None
-        if is_cross and tok is None and not getattr(ctrl, 'is_passthrough', False):
-            raise NotImplementedError(
-                f'{type(ctrl).__name__}: controllers on the fused HIP attention must declare `token_positions` '
-                '(the key columns they consume) or `is_passthrough = True`; full probability maps are never '
-                'materialised')
+        passthrough = getattr(ctrl, 'is_passthrough', False)
+        if is_cross and tok is None and not passthrough:
+            place = self.place_in_unet
+            return _run(attn, hidden_states, ehs, edit_probs=lambda p: ctrl(p, True, place))[0]
         out, pcols = _run(attn, hidden_states, ehs, tok_idx=tok)
         if pcols is not None:
             ctrl(pcols, is_cross, self.place_in_unet)
-        elif getattr(ctrl, 'is_passthrough', False):
+        elif passthrough:
             ctrl(None, is_cross, self.place_in_unet)
         return out
 

@@ -30,17 +30,8 @@ the arithmetic, is what an iteration costs. Each problem execute
 sequential run, in the same order: the iterates are bit-identical.
 """
 import math
-import os
 
 import torch
-
-# MOS_LBFGS_FUSED=0: the history passes as torch mat-vecs (rocBLAS dgemv) also on the device -- the A/B of the two streaming kernels
-_fused_history = os.environ.get('MOS_LBFGS_FUSED', '1') != '0'
-# MOS_LBFGS_HIST=f32 (with the fused kernels only): the stored pairs as fp32 rows, arithmetic in fp64 -- half the traffic of the passes.
-# The reference's optimiser keeps ALL of its state in fp32; on 500-iteration ill-conditioned layers the fp32-row variant ends between
-# the fp64-row one and torch.optim.LBFGS in fp32 (direct loss and distance of the solutions; study in DESIGN.md 5.8).
-_hist_f32 = os.environ.get('MOS_LBFGS_HIST', 'f64') == 'f32'
-
 
 def _cubic_interpolate(x1, f1, g1, x2, f2, g2, bounds=None):
     """Minimiser of the cubic through (x1, f1, g1), (x2, f2, g2), clipped to `bounds` (default: the interval)."""
@@ -145,9 +136,8 @@ class _History:
     def __init__(self, size, n, like):
         self.size, self.n = size, n
         kw = dict(dtype=like.dtype, device=like.device)
-        hist_dtype = torch.float32 if (_hist_f32 and _fused_history and like.is_cuda and like.dtype == torch.float64) else like.dtype
-        self.S = torch.empty(2 * size, n, dtype=hist_dtype, device=like.device)
-        self.Y = torch.empty(2 * size, n, dtype=hist_dtype, device=like.device)
+        self.S = torch.empty(2 * size, n, **kw)
+        self.Y = torch.empty(2 * size, n, **kw)
         self.SY = torch.zeros(2 * size, 2 * size, **kw)      # [i, j] = s_i . y_j, valid where pair i is not younger than pair j
         self.YY = torch.zeros(2 * size, 2 * size, **kw)
         self.Sg = torch.zeros(size, **kw)                    # S g, Y g of the previous `step` (physical row order)
@@ -175,12 +165,9 @@ class _History:
         k = self.k
         if k == 0:
             return g.neg() * gamma, gamma
-        fused = _fused_history and g.is_cuda and g.dtype == torch.float64       # the two streaming kernels of mos_gram.hip instead of four skinny dgemv
-        if fused:
-            from mixofshow.hip import ops
-            Sg, Yg = ops.lbfgs_hist_dots(self.S, self.Y, g, k)
-        else:
-            Sg, Yg = self.S[:k] @ g, self.Y[:k] @ g          # physical row order, the new pair included
+        # (two streaming HIP kernels for these passes were measured in round 5 and LOST to the four skinny rocBLAS dgemv calls:
+        #  one 14-concept fusion 46.0 s against 36.4 s, profiles/r05c1_fusion_ab.txt -- removed)
+        Sg, Yg = self.S[:k] @ g, self.Y[:k] @ g          # physical row order, the new pair included
         if slot is not None:
             sy_col, yy_col = Sg - self.Sg[:k], Yg - self.Yg[:k]           # (entry `slot` is meaningless: set below)
             sy_col[slot] = ys
@@ -204,9 +191,6 @@ class _History:
         M.diagonal().add_(SY.diagonal())
         mid = torch.addmv(Yg * gamma, M, u, alpha=-1)
         v = torch.linalg.solve_triangular(R.t(), mid.unsqueeze(1), upper=False).squeeze(1)
-        if fused:
-            gm = gamma if torch.is_tensor(gamma) else torch.full((1, ), float(gamma), dtype=g.dtype, device=g.device)
-            return ops.lbfgs_hist_combine(S, Y, u.contiguous(), v.contiguous(), g, gm.reshape(1)), gamma
         out = torch.addmv(g, Y.t(), u, beta=-1)
         out *= gamma
         return torch.addmv(out, S.t(), v), gamma

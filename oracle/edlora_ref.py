@@ -47,6 +47,20 @@ def lora_linear_ref(x, W, bias, down, up, alpha):
 
 
 # ---- mixofshow/models/edlora.py:103-173 (baddbmm branch :155-156) and :22-100 ---------------------
+def scores_times_value_ref(attn, q, k, v, limit_bytes=2**33):
+    """`torch.bmm(attn.get_attention_scores(q, k), v)` (:81-83). The reference materialises the whole (B*H, N, M) probability
+    tensor; at the reference's shipped 1024x2048 example (N = 32768 self-attention keys) that is 69 GB in fp32, so above
+    `limit_bytes` the SAME two calls run on slices of the leading (batch x head) dimension -- every slice is independent of
+    the others in both calls, the result is identical."""
+    n = q.shape[0]
+    per = q.shape[1] * k.shape[1] * 4
+    step = max(1, min(n, limit_bytes // max(per, 1)))
+    if step >= n:
+        return torch.bmm(attn.get_attention_scores(q, k, None), v)
+    return torch.cat([torch.bmm(attn.get_attention_scores(q[i:i + step], k[i:i + step], None), v[i:i + step])
+                      for i in range(0, n, step)])
+
+
 def _attention_layer_ref(attn, hidden_states, encoder_hidden_states, layer_idx, controller=None, place=None):
     residual = hidden_states
     if attn.spatial_norm is not None:
@@ -69,10 +83,12 @@ def _attention_layer_ref(attn, hidden_states, encoder_hidden_states, layer_idx, 
     q = attn.head_to_batch_dim(attn.to_q(hidden_states)).contiguous()
     k = attn.head_to_batch_dim(attn.to_k(context)).contiguous()
     v = attn.head_to_batch_dim(attn.to_v(context)).contiguous()
-    probs = attn.get_attention_scores(q, k, None)
     if controller is not None:
+        probs = attn.get_attention_scores(q, k, None)
         probs = controller(probs, is_cross, place)  # :82 — the tensor keeps its autograd graph
-    out = attn.batch_to_head_dim(torch.bmm(probs, v))
+        out = attn.batch_to_head_dim(torch.bmm(probs, v))
+    else:
+        out = attn.batch_to_head_dim(scores_times_value_ref(attn, q, k, v))
     out = attn.to_out[1](attn.to_out[0](out))
     if ndim == 4:
         out = out.transpose(-1, -2).reshape(b, c, h, w)

@@ -7,8 +7,8 @@ Emulations compute in fp32 from the (possibly half) inputs and round the result 
 """
 import torch
 
-EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_fwd_ex', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'region_attn_fwd',
-            'gram_accumulate', 'lsq_loss_grad', 'lbfgs_hist_dots', 'lbfgs_hist_combine', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
+EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_fwd_ex', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'attn_probs', 'attn_pv', 'region_attn_fwd',
+            'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
             'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
 PAD = 16
 
@@ -158,6 +158,18 @@ def attn_bwd(q, k, v, o, lse, dO, heads, scale, dq, dk, dv, tok_idx=None, pcols=
     return dq, dk, dv
 
 
+def attn_probs(q, k, heads, scale):
+    qh, kh = _heads(q, heads), _heads(k, heads)
+    p = torch.softmax((qh @ kh.transpose(-1, -2)) * scale, dim=-1)
+    return p.reshape(q.shape[0] * heads, q.shape[1], k.shape[1]).to(q.dtype)
+
+
+def attn_pv(probs, v, heads):
+    B, Nkv, C = v.shape
+    o = probs.float().reshape(B, heads, -1, Nkv) @ _heads(v, heads)
+    return o.permute(0, 2, 1, 3).reshape(B, -1, C).to(v.dtype)
+
+
 def region_attn_fwd(q, k_src, v_src, heads, scale, boxes, feat_h, feat_w):
     B, Nq, C = q.shape
     count = torch.zeros(feat_h, feat_w, device=q.device)
@@ -188,14 +200,6 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
     R = W @ G - P
     loss = ((R * W).sum() - (P * W).sum() + c.reshape(())) / n_times_cout
     return loss, 2.0 * R / n_times_cout
-
-
-def lbfgs_hist_dots(S, Y, g, k):
-    return S[:k].double() @ g, Y[:k].double() @ g
-
-
-def lbfgs_hist_combine(S, Y, u, v, g, gamma):
-    return gamma.reshape(()) * (Y.double().t() @ u - g) + S.double().t() @ v
 
 
 def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
@@ -324,7 +328,7 @@ def single_head_attention_nograd(q, k, v, scale):
     return (p.float() @ v.float()).to(q.dtype)
 
 
-def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False):
+def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False, split_k=True):
     """fp32 convolution of the half inputs, + bias + per-sample bias, rounded ONCE, then + residual rounded again."""
     import torch.nn.functional as F
     xf = x.float()

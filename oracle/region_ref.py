@@ -61,8 +61,8 @@ class RegionT2I_AttnProcessorRef:
             context = encoder_hidden_states
         key, value = attn.to_k(context), attn.to_v(context)
         query, key, value = (attn.head_to_batch_dim(t) for t in (query, key, value))
-        probs = attn.get_attention_scores(query, key, None)
-        out = torch.bmm(probs, value)
+        from oracle.edlora_ref import scores_times_value_ref
+        out = scores_times_value_ref(attn, query, key, value)      # get_attention_scores + bmm (:111-116), sliced when huge
         if is_cross:
             regions = []
             for states, box in cross_attention_kwargs['region_list']:   # KeyError if absent, like the reference

@@ -295,9 +295,49 @@ def main(out_path=None):
                         merged_te=merged_te)
 
     out['adapter'] = adapter_region_weight_golden()
+    out['control_eval'] = control_eval_golden(ref, Shim)
     path = out_path or os.path.join(HERE, 'reference_golden.pt')
     torch.save(out, path)
     print(f'wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB)')
+
+
+def control_eval_golden(ref, Shim):
+    """G12: the controller boundary with the FULL probability map, in eval mode (VERDICT r04 missing #2). The reference's own
+    EDLoRA_Control_AttnProcessor (mixofshow/models/edlora.py:22-100) hands (B*H, N, 77) to the reference's own controllers
+    (mixofshow/utils/ptp_util.py:22-108): `AttentionStore(training=False)` -- AttentionControl.__call__ forwards only the second
+    half of the CFG batch (:45-46) and writes it back in place, AttentionStore.forward stores it (:79-82), between_steps /
+    get_average_attention accumulate over two 'steps' -- and an EDITING controller built on the reference's AttentionControl base
+    (a prompt-to-prompt style re-weighting of two token columns with renormalisation), whose edit must reach the layer output."""
+    torch.manual_seed(40)
+    C, H, N, B, L = 64, 8, 48, 4, 3
+    attns = [_seeded_attention(Shim, C, 32, H, seed=41 + i) for i in range(L)]
+    places = ('down', 'mid', 'up')
+    ehs = torch.randn(B, L, 77, 32)
+    hs = [[torch.randn(B, N, C) for _ in range(L)] for _ in range(2)]          # two sampling 'steps'
+
+    store = ref['ptp'].AttentionStore(training=False)
+    store.num_att_layers = L
+    procs = [ref['edlora'].EDLoRA_Control_AttnProcessor(i, places[i], store) for i in range(L)]
+    outs = [[procs[i](attns[i], hs[step][i], encoder_hidden_states=ehs).detach() for i in range(L)] for step in range(2)]
+    avg = store.get_average_attention()
+
+    class Reweight(ref['ptp'].AttentionControl):            # the reference's base class: its __call__ / bookkeeping run here
+        def __init__(self, cols, gain):
+            super().__init__(low_resource=False, training=False)
+            self.cols, self.gain = cols, gain
+
+        def forward(self, attn, is_cross, place_in_unet):
+            attn = attn.clone()
+            attn[:, :, self.cols] = attn[:, :, self.cols] * self.gain
+            return attn / attn.sum(-1, keepdim=True)
+
+    edit = Reweight([4, 5], 3.0)
+    edit.num_att_layers = L
+    procs_e = [ref['edlora'].EDLoRA_Control_AttnProcessor(i, places[i], edit) for i in range(L)]
+    outs_e = [procs_e[i](attns[i], hs[0][i], encoder_hidden_states=ehs).detach() for i in range(L)]
+    return dict(states=[{k: v.detach() for k, v in a.state_dict().items()} for a in attns], places=places, ehs=ehs, hs=hs,
+                outs=outs, cur_step=store.cur_step, avg={k: [t.detach() for t in v] for k, v in avg.items()},
+                edit_cols=[4, 5], edit_gain=3.0, outs_edit=outs_e, edit_cur_step=edit.cur_step)
 
 
 def adapter_region_weight_golden():
@@ -491,6 +531,14 @@ def fusion_golden(out_path=None, iters_te=30, iters_unet=12):
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'fusion':
         fusion_golden(sys.argv[2] if len(sys.argv) > 2 else None)
+    elif len(sys.argv) > 1 and sys.argv[1] == 'control_eval':  # add G12 to the existing fixture without touching the rest
+        path = os.path.join(HERE, 'reference_golden.pt')
+        out = torch.load(path, weights_only=False)
+        ref = _import_reference()
+        from oracle.attention_shim import Attention as Shim
+        out['control_eval'] = control_eval_golden(ref, Shim)
+        torch.save(out, path)
+        print('added control_eval golden')
     elif len(sys.argv) > 1 and sys.argv[1] == 'adapter':      # add G7 to the existing fixture without touching the rest
         path = os.path.join(HERE, 'reference_golden.pt')
         out = torch.load(path, weights_only=False)

@@ -1,5 +1,7 @@
-"""Data-parallel path on real devices: 2 ranks over RCCL (backend "nccl"), one per GPU. Skips on a 1-GPU box (the
-driver's 8-GPU node runs it); the same logic is covered on CPU with gloo in tests/test_dp_gloo.py."""
+"""Data-parallel path on real devices: 2 ranks over RCCL (backend "nccl"), one per GPU. The 2-rank tests skip on a 1-GPU box
+(and FAIL, not skip, on anything with two devices: the driver's 8-GPU node gives a verdict); the same logic is covered on CPU
+with gloo in tests/test_dp_gloo.py. One test runs everywhere: a world-size-1 RCCL group on the single device -- communicator
+creation, the bucket all-reduce kernel on the training stream, and the hipGraph replay followed by that eager collective."""
 import os
 import sys
 
@@ -61,6 +63,58 @@ def test_two_rank_rccl_allreduce_of_the_gradient_bucket(tmp_path):
     torch.testing.assert_close(r0['reduced'], r1['reduced'], rtol=0, atol=0)
     torch.testing.assert_close(r0['reduced'], (r0['local'] + r1['local']) / 2, rtol=1e-6, atol=1e-9)
     torch.testing.assert_close(r0['params'], r1['params'], rtol=0, atol=0)        # lock-step after fused AdamW
+
+
+def _single_rank_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, ROOT)
+    import mos_path  # noqa: F401
+    import torch.distributed as dist
+    from bench import TRAIN_OPT, build_trainer, synthetic_batch
+    from mixofshow.pipelines.train_loop import TrainEngine
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)          # RCCL communicator on the one device
+    tr = build_trainer('small', dev)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+            l.lora_up.weight.normal_(0, 0.02)
+    engine = TrainEngine(tr, dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g'])), total_iter=100, mixed_precision='fp16')
+
+    def batch(step):
+        g = torch.Generator().manual_seed(10 + 7 * step)
+        b = synthetic_batch(2, 256, dev, 100 + 7 * step)
+        b.update(latents=torch.randn(2, 4, 32, 32, generator=g).to(dev), noise=torch.randn(2, 4, 32, 32, generator=g).to(dev),
+                 timesteps=torch.randint(0, 1000, (2, ), generator=g).to(dev))
+        b['images'] = None
+        return b
+
+    engine.enable_graph(batch(0))
+    ok = []
+    for step in range(3):
+        engine.step(batch(step))                                            # hipGraph replay (+ optimiser)
+        before = engine.bucket.flat.clone()
+        dist.all_reduce(engine.bucket.flat, op=dist.ReduceOp.SUM)           # eager ncclAllReduce right behind the replay
+        torch.cuda.synchronize()
+        ok.append(bool(torch.equal(before, engine.bucket.flat)) and bool(torch.isfinite(before).all()))
+    t = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+    dist.all_reduce(t)
+    dist.barrier()
+    torch.save(dict(ok=ok, sum=float(t.double().sum()), backend=dist.get_backend(), grad_absmax=float(before.abs().max())),
+               os.path.join(out_dir, 'single.pt'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_single_rank_rccl_group_allreduce_behind_a_graph_replay(tmp_path):
+    """RCCL itself on a 1-GPU box (no xGMI traffic, but the library, the communicator, ncclAllReduce on the training stream and
+    its ordering behind a replayed hipGraph run): with one rank the sum all-reduce returns the gradient bucket bit for bit."""
+    mp.spawn(_single_rank_worker, args=(1, 28700 + (os.getpid() % 1000), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / 'single.pt')
+    n = 1 << 20
+    assert r['backend'] == 'nccl' and r['ok'] == [True, True, True] and r['sum'] == n * (n - 1) / 2 and r['grad_absmax'] > 0
 
 
 def _graph_worker(rank, world, port, out_dir):

@@ -87,7 +87,8 @@ def _install_cast(unet, dtype):
 
 
 @torch.no_grad()
-def _denoise_loop(pipe, prompt_embeds, latents0, cak=None, forced=None, steps=50, guidance_scale=7.5, residuals=None):
+def _denoise_loop(pipe, prompt_embeds, latents0, cak=None, forced=None, steps=50, guidance_scale=7.5, residuals=None,
+                  max_steps=None):
     """The sampling loop of the reference pipelines (pipeline_edlora.py:271-301 / pipeline_regionally_t2iadapter.py:
     548-580) written out so that every step's (input latent, raw UNet epsilon, post-scheduler latent) can be
     recorded and the input latent can be teacher-forced. Returns a list of (x_in, eps_raw, x_out)."""
@@ -96,6 +97,8 @@ def _denoise_loop(pipe, prompt_embeds, latents0, cak=None, forced=None, steps=50
     lat = latents0.to(prompt_embeds.dtype) * sched.init_noise_sigma
     rec = []
     for i, t in enumerate(sched.timesteps):
+        if max_steps is not None and i >= max_steps:       # only the first steps of the `steps`-step schedule
+            break
         if forced is not None:
             lat = forced[i]
         x = sched.scale_model_input(torch.cat([lat] * 2), t)
@@ -217,16 +220,16 @@ def _edlora_setup(dtype):
     return pipe, emb, None, latents
 
 
-def _regional_setup(preset, dtype=torch.float16):
+def _regional_setup(preset, dtype=torch.float16, H=512, W=768):
     from bench import regional_prompt
     from mixofshow.pipelines.pipeline_regionally_t2iadapter import RegionallyT2IAdapterPipeline
-    H, W = 512, 768
     pipe = RegionallyT2IAdapterPipeline.from_pretrained(f'synthetic://{preset}?seed=0', torch_dtype=dtype).to(DEV)
     cfg = _concept_cfg(pipe.tokenizer, pipe.text_encoder,
                        ['<potter1>', '<potter2>', '<hermione1>', '<hermione2>', '<thanos1>', '<thanos2>'])
     pipe.set_new_concept_cfg(cfg)
     prompt, neg = regional_prompt(H, W)
-    prompt[0][1].append(('a castle', neg, [100 / H, 150 / W, 400 / H, 300 / W]))   # overlaps regions 1 and 2
+    if (H, W) == (512, 768):        # (the shipped 1024x2048 example runs as shipped: three regions)
+        prompt[0][1].append(('a castle', neg, [100 / H, 150 / W, 400 / H, 300 / W]))   # overlaps regions 1 and 2
     emb, region_list = pipe._encode_region_prompt(prompt, cfg, DEV, 1, True, [neg], height=H, width=W)
     cak = {'region_list': region_list, 'height': H, 'width': W}
     latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14)).to(DEV)
@@ -293,7 +296,7 @@ def _peak_attention_logits(pipe, emb, latents, cak, target):
     return before, after
 
 
-def _hot_path_error(name, setup, regional, residuals_fn=None, steps=50, peak_logits=None):
+def _hot_path_error(name, setup, regional, residuals_fn=None, steps=50, peak_logits=None, max_steps=None):
     """fp32 pipeline: the only half-precision arithmetic is the attention layers. HIP vs exact at 1e-3, every step.
     residuals_fn(pipe) -> adapter states fed as `down_block_additional_residuals` to every UNet call (both paths).
     peak_logits: the "trained-model" fixture -- every attention layer's scores scaled to that maximum.
@@ -306,15 +309,15 @@ def _hot_path_error(name, setup, regional, residuals_fn=None, steps=50, peak_log
         lb, la = _peak_attention_logits(pipe, emb, latents, cak, peak_logits)
         print(f'[parity] {name}: attention logits peaked: largest |logit| {lb:.1f} -> {la:.1f} (every layer at {peak_logits})')
         assert 0.8 * peak_logits <= la <= 1.2 * peak_logits
-    rec_free = _denoise_loop(pipe, emb, latents, cak=cak, residuals=res, steps=steps)
+    rec_free = _denoise_loop(pipe, emb, latents, cak=cak, residuals=res, steps=steps, max_steps=max_steps)
     _sensitivity(name, pipe, emb, latents, cak=cak)
     _install_oracle(pipe, regional)
-    rec_exact = _denoise_loop(pipe, emb, latents, cak=cak, residuals=res, steps=steps)       # oracle, exact fp32 attention
+    rec_exact = _denoise_loop(pipe, emb, latents, cak=cak, residuals=res, steps=steps, max_steps=max_steps)       # oracle, exact fp32 attention
     forced = [r[0] for r in rec_exact]
     _install_cast(pipe.unet, torch.float16)
-    rec_ref16 = _denoise_loop(pipe, emb, latents, cak=cak, forced=forced, residuals=res, steps=steps)   # reference fp16 attention arithmetic
+    rec_ref16 = _denoise_loop(pipe, emb, latents, cak=cak, forced=forced, residuals=res, steps=steps, max_steps=max_steps)   # reference fp16 attention arithmetic
     _restore_hip(pipe, hip_procs)
-    rec_hip = _denoise_loop(pipe, emb, latents, cak=cak, forced=forced, residuals=res, steps=steps)
+    rec_hip = _denoise_loop(pipe, emb, latents, cak=cak, forced=forced, residuals=res, steps=steps, max_steps=max_steps)
     he, hx, hr = _per_step(rec_hip, rec_exact)
     re_, rx, rr = _per_step(rec_ref16, rec_exact)
     de, dx, dr = _per_step(rec_hip, rec_ref16)                                 # HIP against the reference arithmetic, directly
@@ -438,6 +441,16 @@ def test_regional_sd15_hot_path_error_teacher_forced():
     _hot_path_error('regional sd15 512x768', lambda dt: _regional_setup('sd15', dt), True)
 
 
+def test_regional_sd15_shipped_example_1024x2048_teacher_forced():
+    """VERDICT r04 missing #3: the reference's own shipped regional example (regionally_sample.sh:52-90: 1024 x 2048, the three
+    boxes unscaled, seed 14) -- latent 128 x 256, N = 32768 queries AND self-attention keys at level 0, 8192 / 2048 / 512 below:
+    grid limits, 32-bit offsets and the region kernel's box table at 5.3x the largest size of the other tests. First 6 steps of
+    the 50-step schedule, teacher-forced, fp32 pipeline (attention layers only in half), HIP vs exact attention (the oracle's
+    probability tensors are built in (batch x head) slices: 69 GB otherwise) and vs the reference's fp16 arithmetic."""
+    _hot_path_error('regional sd15 1024x2048 (regionally_sample.sh)', lambda dt: _regional_setup('sd15', dt, 1024, 2048), True,
+                    max_steps=6)
+
+
 def test_regional_sd15_with_adapter_states_hot_path_error_teacher_forced():
     """SURVEY 8(f).2 on the device (reference pipeline_regionally_t2iadapter.py:474-546, :565): the reference cannot sample
     without an adapter input. Seeded synthetic 4-level adapter features go through the product's region-weight rule ON
@@ -474,6 +487,46 @@ def test_edlora_sd15_hot_path_error_peaked_logits():
 def test_regional_sd15_hot_path_error_peaked_logits():
     _hot_path_error('regional sd15 512x768, logits peaked at 30', lambda dt: _regional_setup('sd15', dt), True, steps=12,
                     peak_logits=30.0)
+
+
+@torch.no_grad()
+def test_reference_style_attention_store_gets_full_maps_on_the_hip_path():
+    """VERDICT r04 missing #2, on the device at SD-1.5 size: a controller that follows the reference's protocol and declares no
+    token positions -- `AttentionStore(training=False)` as prompt-to-prompt uses it (reference ptp_util.py:37-53,79-98) -- is handed
+    the dense (B*H, N, 77) probabilities of all 16 cross-attention layers (mos_attn_probs), keeps the conditional half, and the
+    layer output continues from what it returned (mos_attn_pv). Against the oracle's full-map store on exact fp32 attention:
+    the 16 averaged maps after two UNet calls, and epsilon."""
+    from mixofshow.models.edlora import revise_edlora_unet_attention_controller_forward
+    from mixofshow.utils.ptp_util import AttentionStore
+    from oracle import edlora_ref as R
+    pipe, emb, _, latents = _edlora_setup(torch.float32)
+    store = AttentionStore(training=False)
+    revise_edlora_unet_attention_controller_forward(pipe.unet, store)
+    assert store.num_att_layers == 16 and store.token_positions is None
+    x = torch.cat([latents] * 2)
+    ts = [torch.tensor(t, device=DEV) for t in (801, 401)]
+    eps_hip = [pipe.unet(x, t, encoder_hidden_states=emb).sample.float() for t in ts]
+    assert store.cur_step == 2
+    maps_hip = store.get_average_attention()
+    ref = R.AttentionStoreRef(training=False)
+    for m in pipe.unet.modules():
+        if m.__class__.__name__ == 'Attention':
+            m.set_processor(R.PlainAttnProcessorRef())
+    R.install_ref_processors(pipe.unet, controller=ref, control=True)
+    ref.num_att_layers = 16
+    eps_ref = [pipe.unet(x, t, encoder_hidden_states=emb).sample.float() for t in ts]
+    maps_ref = ref.get_average_attention()
+    worst = 0.0
+    n = 0
+    for k, lst in maps_ref.items():
+        assert len(maps_hip[k]) == len(lst)
+        for a, b in zip(maps_hip[k], lst):
+            assert a.shape == b.shape and a.shape[0] == 8 and a.shape[2] == 77          # conditional half: 1 sample x 8 heads
+            worst = max(worst, (a.float() - b.float()).abs().max().item())
+            n += 1
+    de = max(_absmax(a - b) / max(1.0, _absmax(b)) for a, b in zip(eps_hip, eps_ref))
+    print(f'[parity] full-map controller on the HIP path: {n} stored maps, worst |dP| = {worst:.3e}; epsilon vs exact {de:.3e}')
+    assert n == 16 and worst <= 1e-3 and de <= TOL
 
 
 def test_edlora_sd15_fp16_pipeline_inside_reference_band():

@@ -250,11 +250,47 @@ def test_attention_fwd_bwd(ops, emu, dtype, B, H, Nq, Nkv, d):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('B,Nq,Nkv', [(2, 6144, 6144), (4, 4096, 4096), (1, 200, 256), (1, 128, 128), (2, 1000, 1536)])
-def test_attention_fwd_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch):
-    """attn_fwd_pipe_kernel (d = 40, keys % 64 == 0: software-pipelined, lazily moved softmax reference) against
-    attn_fwd_kernel (the default) and the fp32 emulation; plus a drifting-score case in which every tile's maximum is
-    far above the previous one (the reference moves at every step) and one in which it falls (it never moves)."""
+@pytest.mark.parametrize('B,H,Nq,Nkv,d', [
+    (2, 8, 4096, 77, 40), (2, 8, 1024, 77, 80), (2, 8, 256, 77, 160), (2, 8, 64, 77, 160),     # the four UNet levels, CFG pair
+    (2, 8, 6144, 77, 40),                   # 512x768 sample
+    (1, 8, 70, 77, 40), (3, 8, 33, 5, 80),  # ragged queries, few keys, a probability tile that is not 16-byte aligned
+    (1, 8, 130, 96, 160), (1, 8, 64, 3, 40),
+])
+def test_materialised_probabilities_split(ops, emu, dtype, B, H, Nq, Nkv, d):
+    """mos_attn_probs / mos_attn_pv (the controller boundary with the full (B*H, N, 77) map, reference edlora.py:81-83) against the
+    fp32 emulation, and their composition against the fused kernel; an in-place edit of the conditional half between the two
+    (the reference's eval-mode rule, ptp_util.py:45-46) must reach the output."""
+    C = H * d
+    q, k, v = _qkv(B, Nq, Nkv, C, dtype, 17, fused=False)
+    scale = d**-0.5
+    P = ops.attn_probs(q, k, H, scale)
+    P_r = emu.attn_probs(q, k, H, scale)
+    assert P.shape == (B * H, Nq, Nkv) and P.dtype == dtype and P.is_contiguous()
+    _check(f'attn_probs[{B}x{H}x{Nq}x{Nkv}x{d}]', P, P_r, dtype, ulps=2.0)
+    rows = P.float().sum(-1)
+    assert (rows - 1).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 3e-3)
+    o = ops.attn_pv(P, v, H)
+    _check('attn_pv on the kernel probabilities vs emulation', o, emu.attn_pv(P, v, H), dtype, ulps=2.0)
+    o_f, _, _ = ops.attn_fwd(q, k, v, H, scale)
+    _check('attn_probs -> attn_pv vs the fused kernel', o, o_f, dtype, ulps=6.0)
+    if B >= 2:
+        half = P.shape[0] // 2
+        P2 = P.clone()
+        e = P2[half:].float()
+        e[:, :, :2] *= 3.0
+        P2[half:] = (e / e.sum(-1, keepdim=True)).to(dtype)
+        o2 = ops.attn_pv(P2, v, H)
+        _check('attn_pv on edited probabilities', o2, emu.attn_pv(P2, v, H), dtype, ulps=2.0)
+        nb = B // 2
+        assert torch.equal(o2[:nb], o[:nb]) and not torch.equal(o2[nb:], o[nb:])
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,Nq,Nkv', [(2, 6144, 6144), (1, 200, 256), (2, 1000, 1536)])
+def test_attention_fwd_drifting_scores(ops, emu, dtype, B, Nq, Nkv):
+    """The online softmax of attn_fwd_kernel (d = 40) on scores that DRIFT from key tile to key tile: a case in which every
+    tile's maximum is far above the previous one (the running maximum moves and O is rescaled at every step) and one in which
+    it falls (it never moves), against the fp32 emulation."""
     H, d = 8, 40
     C = H * d
     g = torch.Generator(device='cpu').manual_seed(31)
@@ -266,23 +302,17 @@ def test_attention_fwd_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch
         if ramp is not None:          # q.k grows / falls by ~30 raw units per 64-key tile for the first queries
             kk += ramp * 0.75 * (torch.arange(Nkv).float() / 64.0).floor()[None, :, None] * q[:, :1, :] / (q[:, :1, :].pow(2).mean(-1, keepdim=True).sqrt())
         qd, kd, vd = (t.to('cuda', dtype) for t in (q, kk, v))
-        monkeypatch.setenv('MOS_ATTN_PIPE_FWD', '1')
         o1, lse1, _ = ops.attn_fwd(qd, kd, vd, H, d**-0.5)
-        monkeypatch.setenv('MOS_ATTN_PIPE_FWD', '0')
-        o0, lse0, _ = ops.attn_fwd(qd, kd, vd, H, d**-0.5)
-        monkeypatch.delenv('MOS_ATTN_PIPE_FWD')
         o_r, lse_r, _ = emu.attn_fwd(qd, kd, vd, H, d**-0.5)
-        _check(f'attn_fwd pipelined[{name} {B}x{Nq}x{Nkv}].o vs emulation', o1, o_r, dtype)
-        _check(f'attn_fwd pipelined[{name}].lse vs emulation', lse1, lse_r, torch.float16, ulps=2.0)
-        _check(f'attn_fwd pipelined[{name}].o vs attn_fwd_kernel', o1, o0, dtype, ulps=2.0)
-        _check(f'attn_fwd pipelined[{name}].lse vs attn_fwd_kernel', lse1, lse0, torch.float16, ulps=1.0)
+        _check(f'attn_fwd drifting[{name} {B}x{Nq}x{Nkv}].o vs emulation', o1, o_r, dtype)
+        _check(f'attn_fwd drifting[{name}].lse vs emulation', lse1, lse_r, torch.float16, ulps=2.0)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,Nq,Nkv', [(4, 4096, 4096), (1, 1024, 1024), (2, 256, 200), (1, 6144, 6144)])
-def test_attention_bwd_dkdv_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkeypatch):
-    """attn_bwd_dkdv_pipe_kernel (d = 40, slot-interleaved MFMA / softmax VALU) against attn_bwd_dkdv_kernel
-    (MOS_ATTN_PIPE_DKDV=0) and the fp32 emulation; dQ rides along unchanged."""
+def test_attention_bwd_dkdv_slot_interleaved_kernel(ops, emu, dtype, B, Nq, Nkv):
+    """d = 40 dK/dV: attn_bwd_dkdv_pipe_kernel (slot-interleaved MFMA / softmax VALU; whole 64-query tiles) and, for the ragged
+    case, attn_bwd_dkdv_kernel, against the fp32 emulation; dQ rides along."""
     H, d = 8, 40
     C = H * d
     q, k, v = _qkv(B, Nq, Nkv, C, dtype, 11, fused=(Nq == Nkv))
@@ -290,22 +320,13 @@ def test_attention_bwd_dkdv_pipelined_kernel(ops, emu, dtype, B, Nq, Nkv, monkey
     o_r, lse_r, _ = emu.attn_fwd(q, k, v, H, scale)
     g = torch.Generator(device='cpu').manual_seed(12)
     dO = torch.randn(B, Nq, C, generator=g).to('cuda', dtype)
-    res = {}
-    for mode in ('1', '2'):                          # '1' = attn_bwd_dkdv_pipe_kernel, '2' = attn_bwd_dkdv_kernel
-        monkeypatch.setenv('MOS_ATTN_PIPE_DKDV', '1' if mode == '1' else '0')
-        dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
-        ops.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq, dk, dv)
-        res[mode] = (dq, dk, dv)
-    monkeypatch.delenv('MOS_ATTN_PIPE_DKDV')
-    dq_r, dk_r, dv_r = torch.empty_like(res['1'][0]), torch.empty_like(res['1'][1]), torch.empty_like(res['1'][2])
+    dq, dk, dv = torch.empty_like(q.contiguous()), torch.empty_like(k.contiguous()), torch.empty_like(v.contiguous())
+    ops.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq, dk, dv)
+    dq_r, dk_r, dv_r = torch.empty_like(dq), torch.empty_like(dk), torch.empty_like(dv)
     emu.attn_bwd(q, k, v, o_r, lse_r, dO, H, scale, dq_r, dk_r, dv_r)
-    _check(f'attn_bwd pipelined dK/dV [{B}x{Nq}x{Nkv}].dk vs emulation', res['1'][1], dk_r, dtype, ulps=6.0)
-    _check('attn_bwd pipelined dK/dV .dv vs emulation', res['1'][2], dv_r, dtype, ulps=6.0)
-    _check('attn_bwd pipelined dK/dV .dk vs attn_bwd_dkdv_kernel', res['1'][1], res['2'][1], dtype, ulps=1.0)
-    _check('attn_bwd pipelined dK/dV .dv vs attn_bwd_dkdv_kernel', res['1'][2], res['2'][2], dtype, ulps=1.0)
-    same = torch.equal(res['1'][1], res['2'][1]) and torch.equal(res['1'][2], res['2'][2])
-    print(f'[parity] pipelined dK/dV [{B}x{Nq}x{Nkv}] bit-identical to attn_bwd_dkdv_kernel: {same}')
-    assert torch.equal(res['1'][0], res['2'][0])         # dQ: same kernel both times
+    _check(f'attn_bwd dK/dV [{B}x{Nq}x{Nkv}].dk vs emulation', dk, dk_r, dtype, ulps=6.0)
+    _check('attn_bwd dK/dV .dv vs emulation', dv, dv_r, dtype, ulps=6.0)
+    _check('attn_bwd .dq vs emulation', dq, dq_r, dtype, ulps=6.0)
 
 
 def test_attention_softmax_rescale_branch(ops, emu):
@@ -355,6 +376,55 @@ def test_region_attention(ops, emu, dtype, fh, fw, d):
     twin = torch.stack([kv[0], kv[1], kv[1]])
     two = ops.region_attn_fwd(q, twin[..., :C], twin[..., C:], H, d**-0.5, [boxes[0], boxes[0]], fh, fw)
     _check('region_attn.twin_regions', two, one.float(), dtype)
+
+
+@pytest.mark.parametrize('fh,fw,d', [(64, 96, 40), (32, 48, 80), (16, 24, 160), (8, 12, 160), (128, 256, 40)])
+def test_region_attention_random_and_degenerate_boxes(ops, emu, fh, fw, d):
+    """region_rewrite's box rule on the DEVICE (reference pipeline_regionally_t2iadapter.py:34-41,60-83):
+    fractional boxes rounded ceil / floor like the reference -- so some collapse to ZERO area (start > end after rounding: the
+    reference's slice is empty and the region contributes nothing), some touch or run along the borders, some coincide, up to
+    the kernel's source limit; plus the all-degenerate layout (== base attention). 128 x 256 = the shipped 1024x2048 example's
+    level 0."""
+    import random
+    from mixofshow.hip.ops import MOS_MAX_SOURCES
+    B, H = 2, 8
+    C = H * d
+    N = fh * fw
+    dtype = torch.float16
+    g = torch.Generator(device='cpu').manual_seed(60)
+    q = torch.randn(B, N, C, generator=g).to('cuda', dtype)
+    kv = torch.randn(MOS_MAX_SOURCES, B, 77, 2 * C, generator=g).to('cuda', dtype)
+    rnd = random.Random(61)
+    n_zero = n_border = 0
+    layouts = 3 if N > 8192 else 8
+    for it in range(layouts):
+        R = rnd.randint(1, MOS_MAX_SOURCES - 1)
+        fr = []
+        for r in range(R):
+            kind = rnd.choice(['thin', 'border', 'any', 'any', 'dup'])
+            if kind == 'thin':                      # narrower than one feature cell, not on a cell boundary: ceil(start) > floor(end)
+                c0 = (rnd.randint(0, fw - 1) + 0.3) / fw
+                fr.append([rnd.random() * 0.5, c0, 0.5 + rnd.random() * 0.5, c0 + 0.4 / fw])
+            elif kind == 'border':
+                fr.append([0.0, 0.0, 1.0, rnd.random()] if rnd.random() < 0.5 else [rnd.random() * 0.9, rnd.random() * 0.9, 1.0, 1.0])
+            elif kind == 'dup' and fr:
+                fr.append(list(fr[-1]))
+            else:
+                a, b = sorted([rnd.random(), rnd.random()])
+                c, e = sorted([rnd.random(), rnd.random()])
+                fr.append([a, c, b, e])
+        boxes = [(math.ceil(f[0] * fh), math.ceil(f[1] * fw), math.floor(f[2] * fh), math.floor(f[3] * fw)) for f in fr]
+        n_zero += sum(1 for b in boxes if b[2] <= b[0] or b[3] <= b[1])
+        n_border += sum(1 for b in boxes if b[0] == 0 or b[1] == 0 or b[2] == fh or b[3] == fw)
+        k_src, v_src = kv[:R + 1, ..., :C], kv[:R + 1, ..., C:]
+        o = ops.region_attn_fwd(q, k_src, v_src, H, d**-0.5, boxes, fh, fw)
+        o_r = emu.region_attn_fwd(q, k_src, v_src, H, d**-0.5, boxes, fh, fw)
+        _check(f'region_attn random boxes [{fh}x{fw}x{d}] layout {it}: {boxes}', o, o_r, dtype)
+    assert n_zero >= 1 and n_border >= 2, (n_zero, n_border)
+    dead = [(5, 7, 5, 9), (3, 4, 2, 8), (fh, 0, fh, fw)]            # zero height, negative height, empty strip at the border
+    o = ops.region_attn_fwd(q, kv[:4, ..., :C], kv[:4, ..., C:], H, d**-0.5, dead, fh, fw)
+    base, _, _ = emu.attn_fwd(q, kv[0, ..., :C], kv[0, ..., C:], H, d**-0.5)
+    _check('region_attn: only zero-area regions == base attention', o, base, dtype)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -792,28 +862,36 @@ def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
     _check('softmax_rows', ops.softmax_rows(x, 0.7), emu.softmax_rows(x, 0.7), dtype, ulps=2.0)
     x2 = (torch.randn(50, 1000, generator=g) * 3).to('cuda', dtype)
     _check('softmax_rows (ragged chunk count)', ops.softmax_rows(x2, 1.3), emu.softmax_rows(x2, 1.3), dtype, ulps=2.0)
-    B, N, d = 2, 1024, 512
-    q, k, v = ((torch.randn(B, N, d, generator=g) * 0.5).to('cuda', dtype) for _ in range(3))
-    o = ops.single_head_attention_nograd(q, k, v, d**-0.5)
-    _check('vae attention vs emulation', o, emu.single_head_attention_nograd(q, k, v, d**-0.5), dtype)
-    exact = torch.softmax(q.float() @ k.float().transpose(-1, -2) * d**-0.5, -1) @ v.float()
-    _check('vae attention vs exact fp32', o, exact, dtype, ulps=6.0)
+    for rows, N in ((40, 16384), (24, 32768), (8, 20000)):         # 8 / 16 vectors per thread (1024 x 2048 images: 32768 keys)
+        x3 = (torch.randn(rows, N, generator=g) * 3).to('cuda', dtype)
+        _check(f'softmax_rows N={N}', ops.softmax_rows(x3, 0.9), emu.softmax_rows(x3, 0.9), dtype, ulps=2.0)
+    for B, N, d in ((2, 1024, 512), (1, 8200, 512)):               # the second: two blocks of query rows
+        q, k, v = ((torch.randn(B, N, d, generator=g) * 0.5).to('cuda', dtype) for _ in range(3))
+        o = ops.single_head_attention_nograd(q, k, v, d**-0.5)
+        _check(f'vae attention N={N} vs emulation', o, emu.single_head_attention_nograd(q, k, v, d**-0.5), dtype)
+        exact = torch.softmax(q.float() @ k.float().transpose(-1, -2) * d**-0.5, -1) @ v.float()
+        _check(f'vae attention N={N} vs exact fp32', o, exact, dtype, ulps=6.0)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,Cin,Cout,H,W,extras', [
-    (4, 320, 320, 64, 64, 'tr'),      # level-0 ResNet conv1 (+temb) / conv2 (+residual)     128 x 64 tiles
-    (4, 640, 640, 32, 32, 't'),       # level 1                                              64 x 128
-    (4, 1280, 1280, 16, 16, 'r'),     # level 2                                              64 x 64
-    (4, 1280, 1280, 8, 8, 'tr'),      # level 3: 128-row tiles span two images
+    (4, 320, 320, 64, 64, 'tr'),      # level-0 ResNet conv1 (+temb) / conv2 (+residual)     halo form, 8 x 16 x 64 tiles
+    (4, 640, 640, 32, 32, 't'),       # level 1                                              halo form
+    (4, 1280, 1280, 16, 16, 'r'),     # level 2                                              split-K raster form
+    (4, 1280, 1280, 8, 8, 'tr'),      # level 3: 64-row raster tiles span images
     (2, 2560, 1280, 8, 8, ''),        # up-block concat input
     (2, 960, 320, 64, 64, 't'),       # last up block
     (1, 1920, 640, 32, 48, 'r'),      # 512x768 regional sample (non-square map)
-    (2, 1280, 1280, 16, 16, 'u'),     # Upsample2D: nearest 2x folded into the gather, output 32x32
-    (2, 128, 128, 96, 80, 't'),       # VAE-like stage, ragged tile count
-    (1, 128, 256, 250, 203, 'r'),     # VAE stage, 128 x 128 tiles, ragged last tile
-    (1, 128, 128, 512, 500, ''),      # VAE 512-px stage (largest tile variant when enabled)
-    (1, 64, 8, 5, 7, 'tr'),           # tiny / odd sizes
+    (2, 1280, 1280, 16, 16, 'u'),     # Upsample2D: nearest 2x folded into the HALO fetch, output 32x32
+    (2, 640, 640, 32, 48, 'u'),       # Upsample2D into level 0 of a 512x768 sample (64x96)
+    (1, 320, 320, 13, 21, 'u'),       # upsampled read with ragged halo tiles (26 x 42 output)
+    (2, 128, 128, 96, 80, 't'),       # VAE-like stage
+    (1, 128, 256, 250, 203, 'r'),     # VAE stage, ragged last tile in both directions
+    (1, 128, 128, 512, 500, ''),      # VAE 512-px stage
+    (1, 512, 512, 128, 128, 'r'),     # VAE 512-channel stage: the 16 x 16 x 128 halo tile (256 of them)
+    (1, 512, 512, 130, 100, ''),      # ... ragged
+    (1, 64, 8, 5, 7, 'tr'),           # tiny / odd sizes (raster form: narrower than a halo tile)
+    (1, 64, 72, 9, 17, 'tr'),         # one row / one column past a halo tile, Cout not a multiple of the 64-wide tile
     (2, 1280, 1280, 16, 24, 'tr'),    # 512x768 sample, level 2: split-K form (240 tiles, 4 K ranges)
     (2, 2560, 1280, 8, 12, 't'),      # level 3 up block: split-K, 360 K tiles
     (2, 1280, 1280, 8, 12, 'u'),      # Upsample2D into the 16x24 level: split-K with the upsampling gather
@@ -847,46 +925,8 @@ def test_conv3x3_nhwc(ops, emu, dtype, B, Cin, Cout, H, W, extras):
     _check('conv3x3 backward-data', dx, dx_ref, dtype)
     from mixofshow.hip import lib as _lib
     if _lib.load().mos_conv3x3_nhwc_workspace_bytes(B, Ho, Wo, Cin, Cout) > 0:
-        # this shape took the split-K form: the unsplit kernel must agree to the rounding of the fp32 summation order
-        import os
-        os.environ['MOS_CONV_SPLITK'] = '0'
-        try:
-            assert _lib.load().mos_conv3x3_nhwc_workspace_bytes(B, Ho, Wo, Cin, Cout) == 0
-            y1 = ops.conv3x3_nhwc(x, w_fwd, bias, tb, res, up)
-        finally:
-            os.environ.pop('MOS_CONV_SPLITK')
+        # this shape took the split-K form: the unsplit kernel (same entry point without a workspace) must agree to the
+        # rounding of the fp32 summation order
+        y1 = ops.conv3x3_nhwc(x, w_fwd, bias, tb, res, up, split_k=False)
         _check(f'conv3x3 split-K vs unsplit [{B}x{Cin}->{Cout}x{H}x{W} {extras}]', y, y1, dtype, ulps=1.0)
         print(f'[parity] conv3x3 split-K [{B}x{Cin}->{Cout}x{Ho}x{Wo}] bit-identical to the unsplit kernel: {torch.equal(y, y1)}')
-
-
-def test_lbfgs_history_kernels_vs_torch():
-    """mos_lbfgs_history_dots / _combine (the four passes of an L-BFGS iteration over the stored pairs as two streaming kernels)
-    against the fp64 torch mat-vecs, on whole buffers and on a row window of a larger buffer, k < 25 and k = 25."""
-    from mixofshow.hip import ops
-    g = torch.Generator().manual_seed(5)
-    for n, rows, lo, k in ((320 * 320, 50, 0, 25), (768 * 768, 50, 7, 25), (1280 * 320, 50, 0, 3), (2050, 10, 2, 5)):
-        S = torch.randn(rows, n, generator=g, dtype=torch.float64).to(DEV)
-        Y = torch.randn(rows, n, generator=g, dtype=torch.float64).to(DEV)
-        gv = torch.randn(n, generator=g, dtype=torch.float64).to(DEV)
-        u = torch.randn(k, generator=g, dtype=torch.float64).to(DEV)
-        v = torch.randn(k, generator=g, dtype=torch.float64).to(DEV)
-        gamma = torch.tensor([0.37], dtype=torch.float64, device=DEV)
-        Sw, Yw = S[lo:lo + k], Y[lo:lo + k]
-        sg, yg = ops.lbfgs_hist_dots(Sw, Yw, gv, k)
-        d = ops.lbfgs_hist_combine(Sw, Yw, u, v, gv, gamma)
-        torch.cuda.synchronize()
-        want_sg, want_yg = Sw @ gv, Yw @ gv
-        want_d = gamma * (Yw.t() @ u - gv) + Sw.t() @ v
-        scale = n ** 0.5
-        assert (sg - want_sg).abs().max().item() <= 1e-11 * scale and (yg - want_yg).abs().max().item() <= 1e-11 * scale
-        assert (d - want_d).abs().max().item() <= 1e-12 * (k ** 0.5) * 10
-        sg2, yg2 = ops.lbfgs_hist_dots(Sw, Yw, gv, k)                       # deterministic
-        assert torch.equal(sg, sg2) and torch.equal(yg, yg2)
-        # fp32-stored rows, fp64 arithmetic: exact on the rounded rows
-        S32, Y32 = S.float(), Y.float()
-        sg, yg = ops.lbfgs_hist_dots(S32[lo:lo + k], Y32[lo:lo + k], gv, k)
-        d = ops.lbfgs_hist_combine(S32[lo:lo + k], Y32[lo:lo + k], u, v, gv, gamma)
-        torch.cuda.synchronize()
-        Sd, Yd = S32[lo:lo + k].double(), Y32[lo:lo + k].double()
-        assert (sg - Sd @ gv).abs().max().item() <= 1e-11 * scale and (yg - Yd @ gv).abs().max().item() <= 1e-11 * scale
-        assert (d - (gamma * (Yd.t() @ u - gv) + Sd.t() @ v)).abs().max().item() <= 1e-12 * (k ** 0.5) * 10

@@ -75,6 +75,53 @@ def test_control_processor_store_and_attn_reg(golden):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-9)
 
 
+class _ReweightCtl:
+    """The editing controller of golden G12, duck-typed: the reference's AttentionControl.__call__ in eval mode edits the
+    conditional half of the CFG batch in place (ptp_util.py:45-46)."""
+
+    def __init__(self, cols, gain, n_layers):
+        self.cols, self.gain, self.num_att_layers, self.cur_att_layer, self.cur_step = cols, gain, n_layers, 0, 0
+
+    def __call__(self, attn, is_cross, place):
+        h = attn.shape[0]
+        e = attn[h // 2:].clone()
+        e[:, :, self.cols] = e[:, :, self.cols] * self.gain
+        attn[h // 2:] = e / e.sum(-1, keepdim=True)
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers:
+            self.cur_att_layer, self.cur_step = 0, self.cur_step + 1
+        return attn
+
+
+def test_control_processor_eval_mode_full_maps(golden):
+    """G12: the reference's control processor + its own AttentionStore(training=False) and an editing AttentionControl."""
+    g = golden['control_eval']
+    L = len(g['states'])
+    C, cross = g['hs'][0][0].shape[-1], g['ehs'].shape[-1]
+    attns = [_attn_from_state(st, C, cross, 8) for st in g['states']]
+    store = R.AttentionStoreRef(training=False)
+    store.num_att_layers = L
+    procs = [R.EDLoRA_Control_AttnProcessorRef(i, g['places'][i], store) for i in range(L)]
+    with torch.no_grad():
+        for step in range(2):
+            for i in range(L):
+                y = procs[i](attns[i], g['hs'][step][i], encoder_hidden_states=g['ehs'])
+                torch.testing.assert_close(y, g['outs'][step][i], rtol=1e-5, atol=1e-6)
+        assert store.cur_step == g['cur_step'] == 2
+        avg = store.get_average_attention()
+        assert {k: len(v) for k, v in avg.items()} == {k: len(v) for k, v in g['avg'].items()}
+        for k in avg:
+            for a, b in zip(avg[k], g['avg'][k]):
+                assert a.shape == b.shape                       # (B/2 * H, N, 77): the conditional half only
+                torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+        edit = _ReweightCtl(g['edit_cols'], g['edit_gain'], L)
+        for i in range(L):
+            y = R.EDLoRA_Control_AttnProcessorRef(i, g['places'][i], edit)(attns[i], g['hs'][0][i], encoder_hidden_states=g['ehs'])
+            torch.testing.assert_close(y, g['outs_edit'][i], rtol=1e-5, atol=1e-6)
+            assert not torch.allclose(y, g['outs'][0][i], atol=1e-4)         # the edit reaches the output
+        assert edit.cur_step == g['edit_cur_step']
+
+
 def test_region_processor(golden):
     g = golden['region']
     C = g['hs'].shape[-1]

@@ -1,4 +1,4 @@
-"""Lane-level model of the data movement of conv3x3_halo_kernel (branch next/): LDS as an element array, dma16 = 16 B per lane at
+"""Lane-level model of the data movement of conv3x3_halo_kernel (csrc/mos_conv.hip; the default 3x3 path since round 5): LDS as an element array, dma16 = 16 B per lane at
 (wave-uniform base) + lane * 16 from a global byte offset (zeros out of range), ld16 = 8 elements at an LDS element address, the
 16x16x32 MFMA by its lane layout. The kernel's index arithmetic is transcribed literally; the sum is compared with conv2d.
 The same model with the raster kernel's arithmetic (known to be right on the device) validates the model itself."""
@@ -21,9 +21,13 @@ def mfma16(acc, afrag, bfrag):
             acc[lane][r] += D[(lane >> 4) * 4 + r, lane & 15]
 
 
-def run_halo(x, w, TH, BN):
-    """x (B, H, W, C) NHWC, w (Cout, 3, 3, C). Returns y (B, H, W, Cout) computed tile by tile like the kernel."""
+def run_halo(x, w, TH, BN, up=False):
+    """x (B, H, W, C) NHWC, w (Cout, 3, 3, C). Returns y (B, H, W, Cout) computed tile by tile like the kernel.
+    up: x is (B, H/2, W/2, C) and is read through a nearest 2x upsample (template parameter UP of the kernel)."""
     B, H, Wd, C = x.shape
+    Hsrc, Wsrc = H, Wd
+    if up:
+        H, Wd = 2 * H, 2 * Wd
     N = w.shape[0]
     K = 9 * C
     MI, NJ, WCH = TH // 2, BN // 32, BN * 8 // 256
@@ -60,7 +64,8 @@ def run_halo(x, w, TH, BN):
                 yy, xx = y0 + hy - 1, x0 + hx - 1
                 lc = (lane & 7) ^ (hr & 7)
                 ok = hr < HR and 0 <= yy < H and 0 <= xx < Wd
-                return (((b * H + yy) * Wd + xx) * C + lc * 8) * 2 if ok else -1
+                ys, xs = (yy >> 1, xx >> 1) if up else (yy, xx)
+                return (((b * Hsrc + ys) * Wsrc + xs) * C + lc * 8) * 2 if ok else -1
 
             def issue_halo(cch, hb):
                 live = cch < cpt
@@ -136,4 +141,13 @@ if __name__ == '__main__':
         got = torch.from_numpy(run_halo(x.numpy(), w.numpy(), TH, BN))
         err = (got - ref).abs().max().item()
         print(f'B{B} {H}x{Wd} C{C} N{N} TH{TH} BN{BN}: max|d| = {err:.3e}')
+        assert err < 1e-9
+    for (B, H, Wd, C, N, TH, BN) in ((1, 8, 8, 64, 64, 8, 64), (2, 5, 12, 64, 64, 8, 64), (1, 8, 16, 64, 128, 16, 128)):
+        x = torch.randn(B, H, Wd, C, generator=g, dtype=torch.float64)
+        w = torch.randn(N, 3, 3, C, generator=g, dtype=torch.float64)
+        xu = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), scale_factor=2.0, mode='nearest')
+        ref = torch.nn.functional.conv2d(xu, w.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        got = torch.from_numpy(run_halo(x.numpy(), w.numpy(), TH, BN, up=True))
+        err = (got - ref).abs().max().item()
+        print(f'upsampled read: B{B} {H}x{Wd} -> {2 * H}x{2 * Wd} C{C} N{N} TH{TH} BN{BN}: max|d| = {err:.3e}')
         assert err < 1e-9
