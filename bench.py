@@ -243,14 +243,13 @@ ATTENTION_PATH_KERNELS = ('attn_', 'region_attn', 'gemm_nt', 'lora_')
 
 
 def _tuning_switches():
-    """The host-side kernel-dispatch switches in effect (defaults unless overridden in the environment)."""
+    """The host-side dispatch switches in effect (defaults unless overridden in the environment; the LIBRARY reads no
+    environment variable since round 5)."""
     from mixofshow.hip import functional as F_hip
-    return dict(conv3x3_min_pixels=F_hip._conv_min_pixels, ring_max_wg=int(os.environ.get('MOS_RING_MAX_WG', -1)),
+    return dict(conv3x3_min_pixels=F_hip._conv_min_pixels,
                 fuse_add_layernorm=bool(F_hip._fuse_add_ln), fuse_groupnorm_skip_grad=bool(F_hip._fuse_gn_res),
-                groupnorm_finalize=os.environ.get('MOS_GN_FINALIZE', '1') != '0',
                 batched_time_projections=os.environ.get('MOS_BATCH_TEMB', '1') != '0',
-                groupnorm_column_kernel=int(os.environ.get('MOS_GN_FUSED', 1)), conv_splitk=os.environ.get('MOS_CONV_SPLITK', '1') != '0',
-                ff_geglu_epilogue=bool(F_hip._ff_geglu), ff2_residual_epilogue=bool(F_hip._ff2_own))
+                ff2_residual_epilogue=bool(F_hip._ff2_own))
 
 
 def attention_path_aggregate(gflop_per_unit, units, recs, per):

@@ -163,10 +163,17 @@ def _solve_layers_impl(accs, original_state_dict, iters, tag):
     # Lock-step solve (MOS_FUSION_BATCH, default on for a HIP device; 0 = the worker-thread form below): the layers advance
     # together, ONE host read-back per round answers the pending requests of all of them (mixofshow.utils.lbfgs.minimize_many)
     # -- bit-identical iterates per layer, no thread contention for the interpreter. Groups are cut so that the L-BFGS
-    # histories of a group (4 x 25 rows of Cout*Cin fp64 per layer) stay within MOS_FUSION_BATCH_GB (default 24 GB).
+    # histories of a group (4 x 25 rows of Cout*Cin fp64 per layer) stay within a budget derived from the free device memory.
     lockstep = os.environ.get('MOS_FUSION_BATCH', '1')               # ('force': also on the CPU -- the tests' way in)
     if (lockstep == 'force' or (dev.type == 'cuda' and lockstep != '0')) and len(names) >= 2:
-        budget = float(os.environ.get('MOS_FUSION_BATCH_GB', 24)) * 2**30
+        # budget of the doubled fp64 histories of one group: MOS_FUSION_BATCH_GB if set, otherwise a third of the device memory
+        # that is FREE right now (the Gram statistics, trial points and the resident model come on top: ADVICE r04), at most 24 GB
+        if 'MOS_FUSION_BATCH_GB' in os.environ:
+            budget = float(os.environ['MOS_FUSION_BATCH_GB']) * 2**30
+        elif dev.type == 'cuda':
+            budget = min(24.0 * 2**30, torch.cuda.mem_get_info(dev)[0] / 3.0)
+        else:
+            budget = 24.0 * 2**30
         groups, cur, used = [], [], 0.0
         for name in names:
             need = 4.0 * 25 * accs[name].cout * accs[name].cin * 8        # S and Y, each kept twice (lbfgs._History)
@@ -282,8 +289,10 @@ class _Recorder:
             acc.add(x, y)
             return
         xs, ys = self.pending.setdefault(weight_name, ([], []))
-        xs.append(GramAccumulator._rows(x, acc.cin))
-        ys.append(GramAccumulator._rows(y, acc.cout))
+        # contiguous COPIES, not views: a queued slice of the fused q/k/v GEMM output would pin the whole 3C-wide buffer until
+        # the flush, and the statistics must not depend on nothing downstream writing into the activation
+        xs.append(GramAccumulator._rows(x, acc.cin).clone(memory_format=torch.contiguous_format))
+        ys.append(GramAccumulator._rows(y, acc.cout).clone(memory_format=torch.contiguous_format))
         if sum(t.shape[0] for t in xs) >= self.batch_rows:
             self._flush_one(weight_name)
 

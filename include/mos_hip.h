@@ -111,15 +111,10 @@ int mos_lora_linear_fused_fwd(const void* x, int64_t ldx, const void* W, int64_t
  * `hidden_states = attn(...) + hidden_states; hidden_states = ff(norm3(hidden_states)) + hidden_states`):
  *   residual != NULL : y = round(x.W^T (+ LoRA) + bias) + residual[M, Nout]   -- the rounding points of "GEMM, then an add
  *                      kernel" (bit-identical to that pair), without the add launch and its 3 passes over the activation
- *   geglu            : W (and bias) hold the GEGLU projection's rows INTERLEAVED in blocks of 16: rows 32q..32q+15 = value rows
- *                      16q..16q+15, rows 32q+16..32q+31 = gate rows 16q..16q+15 (packed once by the caller; the weight is
- *                      frozen). y is [M, N/2] = value * gelu(gate) (exact erf GELU), same arithmetic as the GEMM followed
- *                      by mos_geglu_fwd: the (M, N) pre-activation never goes to HBM. N % 32 == 0; not combined with residual.
  * A16 / Bp16 NULL: plain GEMM; otherwise the fused LoRA form of mos_lora_linear_fused_fwd (t_out as there). */
 typedef struct {
     const void* residual;     /* [M, Nout] in `dtype`, or NULL */
     int64_t ldr;              /* its row stride in elements */
-    int geglu;                /* 0 / 1 */
 } mos_gemm_epilogue;
 int mos_lora_linear_fwd_ex(const void* x, int64_t ldx, const void* W, int64_t ldw,
                            const void* A16, const void* Bp16, const float* bias,
@@ -320,8 +315,10 @@ int mos_groupnorm_silu_bwd(const void* dy, const void* x, const float* gamma, co
  * attention path and of MIOpen's fp16 NHWC implicit-GEMM convolutions, so a UNet kept in channels_last needs no
  * NCHW<->NHWC transposes around convolutions and no permute copies around the transformer blocks. C % 8 == 0,
  * C <= 4096, G <= 64. ws: mos_groupnorm_nhwc_workspace_bytes() bytes (per-slice partial sums + the per-group constants
- * one block per image folds them into; environment MOS_GN_FINALIZE=0: every apply block folds the partials itself, the
- * round-2 scheme, same results). */
+ * one block per image folds them into). `silu` is a flag word: bit 0 = SiLU after the norm; bit 1 (MOS_GN_FORCE_SLICES) =
+ * take the three-launch slice form even where the one-launch column kernel applies (parity tests and A/B runs: there is no
+ * environment switch and no other process-global state behind these entry points). */
+#define MOS_GN_FORCE_SLICES 2
 int64_t mos_groupnorm_nhwc_workspace_bytes(int B, int C, int HW, int G);
 int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                 void* ws, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);

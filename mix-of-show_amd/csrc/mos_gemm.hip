@@ -47,12 +47,11 @@ struct GemmArgs {
     void* Y; void* Tout;
     int64_t ldx, ldw, ldy;
     int M, N, K, mt, nt;
-    // epilogue variants (mos_lora_linear_fwd_ex): R = residual [M, Nout] added to the ROUNDED result (the rounding points of
-    // "GEMM, then an add kernel"); geglu = W rows interleaved value|gate in blocks of 16: Y [M, N/2] = value * gelu(gate)
-    const void* R; int64_t ldr; int geglu;
+    // epilogue variant (mos_lora_linear_fwd_ex): R = residual [M, N] added to the ROUNDED result (the rounding points of
+    // "GEMM, then an add kernel"). (A GEGLU epilogue -- value * gelu(gate) from interleaved weight rows -- was built in round 4,
+    // measured no faster than hipBLASLt + the geglu kernel at the sampling sizes, and removed in round 5.)
+    const void* R; int64_t ldr;
 };
-
-__device__ __forceinline__ float gemm_gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
 
 // Y[M,N] = X[M,K].W[N,K]^T (+ t.Baug^T) (+ bias), t = X.Adown^T computed in the same K loop (FUSED) or read from Taug.
 //   * Tiles are fetched with buffer loads whose descriptors end at the last valid row: rows past M / N read as zeros in
@@ -314,26 +313,6 @@ __global__ __launch_bounds__(256) void gemm_lora_kernel(const GemmArgs a) {
     __syncthreads();
     T* Y = reinterpret_cast<T*>(a.Y);
     constexpr int OCH = BM * (BN / 8) / 256;
-    if (a.geglu) {
-        // the staged tile holds the ROUNDED pre-activations in the interleaved column order [16 value | 16 gate] ...: output
-        // chunk (row, oc) of the BM x BN/2 result pairs the value chunk at 32 * (oc / 16) + oc % 16 with the gate chunk 16
-        // columns further (same arithmetic as the GEMM followed by geglu_fwd_kernel: half operands, fp32 product, one rounding)
-        constexpr int GCH = (BM * (BN / 16) + 255) / 256;
-#pragma unroll
-        for (int i = 0; i < GCH; ++i) {
-            const int c = tid + 256 * i;
-            const int row = c / (BN / 16), oc = (c % (BN / 16)) * 8;
-            const int vc = 32 * (oc >> 4) + (oc & 15);
-            if (c < BM * (BN / 16) && m0 + row < M && n0 + vc < N) {     // N % 32 == 0 (host check): a 32-block is entirely in or out
-                const v8 vv = as_v8<T>(ld16(Cs + row * CS + vc)), gv = as_v8<T>(ld16(Cs + row * CS + vc + 16));
-                v8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (T)((float)vv[e] * gemm_gelu_f((float)gv[e]));
-                st16(Y + (int64_t)(m0 + row) * a.ldy + (n0 >> 1) + oc, from_v8<T>(o));
-            }
-        }
-        return;
-    }
     const T* Rr = reinterpret_cast<const T*>(a.R);
 #pragma unroll
     for (int i = 0; i < OCH; ++i) {
@@ -562,18 +541,18 @@ int launch_gemm_t(const GemmArgs& a, hipStream_t st) {
 template <typename T>
 int launch_gemm(const void* X, int64_t ldx, const void* W, int64_t ldw, const void* t, const void* adown, const void* Bp,
                 const float* bias, void* Y, int64_t ldy, void* tout, int M, int N, int K, hipStream_t st,
-                const void* residual = nullptr, int64_t ldr = 0, int geglu = 0) {
+                const void* residual = nullptr, int64_t ldr = 0) {
     char key[112];
     const bool lora = (t != nullptr) || (adown != nullptr);
-    snprintf(key, sizeof(key), "%s M%d N%d K%d%s%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", M, N, K,
-             adown ? " +lora(fused)" : (t ? " +lora" : ""), geglu ? " +geglu" : "", residual ? " +res" : "");
-    const double nout = geglu ? 0.5 * N : (double)N;
+    snprintf(key, sizeof(key), "%s M%d N%d K%d%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", M, N, K,
+             adown ? " +lora(fused)" : (t ? " +lora" : ""), residual ? " +res" : "");
+    const double nout = (double)N;
     MosProfScope prof(st, "gemm_nt", key, 2.0 * M * (double)N * (K + (lora ? 16 : 0)) + (adown ? 2.0 * M * 16.0 * K : 0.0),
                       2.0 * ((double)M * K + (double)N * K + (double)M * nout * (residual ? 2.0 : 1.0)));
     GemmArgs a;
     a.X = X; a.W = W; a.Taug = t; a.Adown = adown; a.Baug = Bp; a.bias = bias; a.Y = Y; a.Tout = tout;
     a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.M = M; a.N = N; a.K = K; a.mt = a.nt = 0;
-    a.R = residual; a.ldr = ldr; a.geglu = geglu;
+    a.R = residual; a.ldr = ldr;
     return adown ? launch_gemm_t<T, true>(a, st) : launch_gemm_t<T, false>(a, st);
 }
 
@@ -1010,20 +989,16 @@ int mos_lora_linear_fwd_ex(const void* x, int64_t ldx, const void* W, int64_t ld
                            const mos_gemm_epilogue* epi, void* stream) {
     MOS_REQUIRE(x && W && y && epi, "mos_lora_linear_fwd_ex: NULL argument");
     MOS_REQUIRE((A16 == nullptr) == (Bp16 == nullptr), "mos_lora_linear_fwd_ex: A16 and Bp16 must both be set or both NULL");
-    const int geglu = epi->geglu ? 1 : 0;
-    const int nout = geglu ? N / 2 : N;
-    int rc = gemm_dims_ok("mos_lora_linear_fwd_ex", M, N, K, ldx, ldw, geglu ? 2 * ldy : ldy);
+    const int nout = N;
+    int rc = gemm_dims_ok("mos_lora_linear_fwd_ex", M, N, K, ldx, ldw, ldy);
     if (rc) return rc;
-    MOS_REQUIRE(!geglu || (N % 32 == 0 && ldy % 8 == 0 && ldy >= nout),
-                "mos_lora_linear_fwd_ex: geglu needs N %% 32 == 0 and ldy %% 8 == 0 (N=%d ldy=%lld)", N, (long long)ldy);
-    MOS_REQUIRE(!(geglu && epi->residual), "mos_lora_linear_fwd_ex: the GEGLU epilogue takes no residual");
     MOS_REQUIRE(epi->residual == nullptr || (epi->ldr % 8 == 0 && epi->ldr >= nout),
                 "mos_lora_linear_fwd_ex: residual row stride %lld (need %% 8 == 0, >= %d)", (long long)epi->ldr, nout);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MOS_F16)
-        return launch_gemm<f16_t>(x, ldx, W, ldw, nullptr, A16, Bp16, bias, y, ldy, t_out, M, N, K, st, epi->residual, epi->ldr, geglu);
+        return launch_gemm<f16_t>(x, ldx, W, ldw, nullptr, A16, Bp16, bias, y, ldy, t_out, M, N, K, st, epi->residual, epi->ldr);
     if (dtype == MOS_BF16)
-        return launch_gemm<bf16_t>(x, ldx, W, ldw, nullptr, A16, Bp16, bias, y, ldy, t_out, M, N, K, st, epi->residual, epi->ldr, geglu);
+        return launch_gemm<bf16_t>(x, ldx, W, ldw, nullptr, A16, Bp16, bias, y, ldy, t_out, M, N, K, st, epi->residual, epi->ldr);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_lora_linear_fwd_ex: dtype %d", dtype);
 }
 

@@ -133,68 +133,11 @@ __global__ void gram_reduce_kernel(const float* __restrict__ partial, int nchunk
     else G[(int64_t)(i - Cout) * Cin + j] += s;
 }
 
-// R = W.G - P (fp64, 64x64 tile / block, 4x4 per thread); grad = 2R/nm ; block partial of sum((R - P) o W)
-__global__ __launch_bounds__(256) void lsq_grad_kernel(const double* __restrict__ W, const double* __restrict__ G,
-                                                       const double* __restrict__ P, double inv_nm, int Cout, int Cin,
-                                                       double* __restrict__ grad, double* __restrict__ blk_partial) {
-    __shared__ double Ws[16][64 + 1];
-    __shared__ double Gs[16][64 + 1];
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
-    double acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k0 = 0; k0 < Cin; k0 += 16) {
-        __syncthreads();
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int kk = e & 15, ii = e >> 4;  // W tile: rows i (64) x k (16), k contiguous in memory
-            const int gi = i0 + ii, gk = k0 + kk;
-            Ws[kk][ii] = (gi < Cout && gk < Cin) ? W[(int64_t)gi * Cin + gk] : 0.0;
-            const int jj = e & 63, k2 = e >> 6;  // G tile: rows k (16) x cols j (64), j contiguous
-            const int gj = j0 + jj, gk2 = k0 + k2;
-            Gs[k2][jj] = (gj < Cin && gk2 < Cin) ? G[(int64_t)gk2 * Cin + gj] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            double a[4], b[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { a[q] = Ws[kk][ty * 4 + q]; b[q] = Gs[kk][tx * 4 + q]; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) acc[q][p] += a[q] * b[p];
-        }
-    }
-    double part = 0.0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int gi = i0 + ty * 4 + q, gj = j0 + tx * 4 + p;
-            if (gi < Cout && gj < Cin) {
-                const int64_t o = (int64_t)gi * Cin + gj;
-                const double pv = P[o], w = W[o];
-                const double r = acc[q][p] - pv;
-                grad[o] = 2.0 * r * inv_nm;
-                part += (r - pv) * w;
-            }
-        }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
-    if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    if (tid == 0) blk_partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-}
-
-// The same product on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: D[i][j] += sum_k A[i][k] B[k][j], lane l supplies
+// R = W.G - P (fp64, 64 x 64 tile per block); grad = 2R/nm ; block partial of sum((R - P) o W).
+// On the fp64 matrix cores (v_mfma_f64_16x16x4_f64: D[i][j] += sum_k A[i][k] B[k][j], lane l supplies
 // A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; D: lane l holds rows (l >> 4) + 4 * reg, column l & 15 -- NOT the f32
-// row map). 64 x 64 block tile, 4 waves of 32 x 32 (2 x 2 MFMA tiles), W and G staged through LDS in 16-deep K slabs exactly
-// like the VALU kernel above. The L-BFGS closure of gradient fusion is this kernel ~45 k times per 14-concept job (VALU form:
+// row map). 64 x 64 block tile, 4 waves of 32 x 32 (2 x 2 MFMA tiles), W and G staged through LDS in 16-deep K slabs (the fp64
+// VALU form of rounds 1-3, 4 x 4 outputs per thread, was kept as an A/B switch until round 5 and is gone). The L-BFGS closure of gradient fusion is this kernel ~45 k times per 14-concept job (VALU form:
 // 235 us per call at 768 x 768, 3.9 TFLOP/s); the fp64 MFMA peak is ~79 TFLOP/s.
 typedef __attribute__((ext_vector_type(4))) double f64x4;
 __global__ __launch_bounds__(256) void lsq_grad_mfma_kernel(const double* __restrict__ W, const double* __restrict__ G,
@@ -352,11 +295,7 @@ int mos_lsq_loss_grad_gram(const double* W, const double* G, const double* P, co
     char key[64];
     snprintf(key, sizeof(key), "Cout%d Cin%d", Cout, Cin);
     MosProfScope prof(st, "lsq_loss_grad", key, 2.0 * Cout * (double)Cin * Cin, 8.0 * (3.0 * Cout * Cin + (double)Cin * Cin));
-    const char* e = getenv("MOS_LSQ_MFMA");       // 0: the fp64 VALU form of rounds 1-3 (A/B, tests)
-    if (e != nullptr && atoi(e) == 0)
-        hipLaunchKernelGGL(lsq_grad_kernel, grid, dim3(256), 0, st, W, G, P, inv, Cout, Cin, grad, (double*)ws);
-    else
-        hipLaunchKernelGGL(lsq_grad_mfma_kernel, grid, dim3(256), 0, st, W, G, P, inv, Cout, Cin, grad, (double*)ws);
+    hipLaunchKernelGGL(lsq_grad_mfma_kernel, grid, dim3(256), 0, st, W, G, P, inv, Cout, Cin, grad, (double*)ws);
     int rc = mos_check_launch("lsq_grad");
     if (rc) return rc;
     hipLaunchKernelGGL(lsq_loss_finalize_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, (int)(grid.x * grid.y), c,

@@ -350,10 +350,10 @@ __global__ __launch_bounds__(256) void gn_nhwc_reduce_kernel(GnNhwcArgs a) {
 
 // DS (backward): out = half(dx) + ds -- the gradient of a residual connection that bypasses this norm, added where autograd
 // would otherwise launch a separate accumulation kernel (same rounding points: dx rounded to T, then the half add)
-// FIN: the per-group constants were combined once per image by gn_nhwc_finalize_kernel (a.partial + fin_off); otherwise every
-// block combines the nsplit slice partials itself (the original scheme: at the UNet's sizes that prologue -- up to 128 x G x 2
-// partials per block -- moves more L2 traffic per block than the block's own slice of the activation).
-template <typename T, int VT, bool BWD, bool SILU, bool DS = false, bool FIN = false>
+// The per-group constants were combined once per image by gn_nhwc_finalize_kernel (a.partial + fin_off). (Rounds 1-2 let every
+// apply block combine the nsplit slice partials itself: at the UNet's sizes that prologue -- up to 128 x G x 2 partials per block
+// -- moved more L2 traffic per block than the block's own slice of the activation; removed in round 5.)
+template <typename T, int VT, bool BWD, bool SILU, bool DS = false>
 __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     static_assert(BWD || !DS, "the bypass gradient exists in backward only");
     typedef typename MT<T>::v8 v8;
@@ -362,51 +362,12 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     const int r = tid / a.TP, tp = tid - r * a.TP;
     const int b = blockIdx.x, sp = blockIdx.y;
     const int p0 = sp * a.ppb, p1 = min(p0 + a.ppb, a.HW);
-    // second-stage combine of the nsplit slice partials, by ALL threads (a single thread per group walking nsplit
-    // dependent loads cost 40 us at nsplit = 128): coalesced loads, double accumulation in LDS
-    __shared__ double acc_s[128];
-    if constexpr (FIN) {
-        if (tid < a.G) {
-            const float* fin = a.partial + (int64_t)a.B * a.nsplit * a.G * 2 + ((int64_t)b * a.G + tid) * 2;
-            u_s[tid] = fin[0]; w_s[tid] = fin[1];
-            if (BWD) { m_s[tid] = a.stats[(b * a.G + tid) * 2]; r_s[tid] = a.stats[(b * a.G + tid) * 2 + 1]; }
-        }
-        __syncthreads();
-    } else {
-    for (int i = tid; i < 2 * a.G; i += blockDim.x) acc_s[i] = 0.0;
-    __syncthreads();
-    {
-        const int tot = a.nsplit * a.G * 2;
-        const float* pb = a.partial + (int64_t)b * tot;
-        for (int e0 = tid; e0 < tot; e0 += 8 * blockDim.x) {
-            float pv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int e = e0 + q * blockDim.x; pv[q] = e < tot ? pb[e] : 0.f; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = e0 + q * blockDim.x;
-                if (e < tot) atomicAdd(&acc_s[e % (2 * a.G)], (double)pv[q]);
-            }
-        }
-    }
-    __syncthreads();
     if (tid < a.G) {
-        const double t0 = acc_s[tid * 2], t1 = acc_s[tid * 2 + 1];
-        const double n = (double)a.cpg * a.HW;
-        if (!BWD) {
-            const double m = t0 / n;
-            double var = t1 / n - m * m;
-            if (var < 0.0) var = 0.0;
-            const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-            u_s[tid] = mean; w_s[tid] = rstd;
-            if (sp == 0 && a.stats != nullptr) { a.stats[(b * a.G + tid) * 2] = mean; a.stats[(b * a.G + tid) * 2 + 1] = rstd; }
-        } else {
-            u_s[tid] = (float)(t0 / n); w_s[tid] = (float)(t1 / n);
-            m_s[tid] = a.stats[(b * a.G + tid) * 2]; r_s[tid] = a.stats[(b * a.G + tid) * 2 + 1];
-        }
+        const float* fin = a.partial + (int64_t)a.B * a.nsplit * a.G * 2 + ((int64_t)b * a.G + tid) * 2;
+        u_s[tid] = fin[0]; w_s[tid] = fin[1];
+        if (BWD) { m_s[tid] = a.stats[(b * a.G + tid) * 2]; r_s[tid] = a.stats[(b * a.G + tid) * 2 + 1]; }
     }
     __syncthreads();
-    }   // !FIN
     // per-channel constants of this thread's vectors
     float c0[VT][8], c1[VT][8], c2[VT][8], c3[VT][8], c4[VT][8], c5[VT][8];
 #pragma unroll
@@ -523,11 +484,6 @@ __global__ __launch_bounds__(256) void gn_nhwc_finalize_kernel(GnNhwcArgs a) {
     }
 }
 
-bool gn_finalize_enabled() {
-    static const bool v = [] { const char* e = getenv("MOS_GN_FINALIZE"); return e == nullptr || atoi(e) != 0; }();
-    return v;
-}
-
 bool gn_nhwc_plan(GnNhwcArgs& a) {
     a.V = a.C / 8;
     const int vt = (a.V + 255) / 256;
@@ -564,50 +520,25 @@ int gn_nhwc_run(GnNhwcArgs a, int silu, hipStream_t st) {
     }
     int rc = mos_check_launch("gn_nhwc_reduce");
     if (rc) return rc;
-    if (gn_finalize_enabled()) {
-        {
-            MosProfScope prof(st, BWD ? "groupnorm_bwd_finalize" : "groupnorm_finalize", key, 2.0 * a.B * a.nsplit * a.G,
-                              8.0 * a.B * a.nsplit * a.G);
-            hipLaunchKernelGGL((gn_nhwc_finalize_kernel<BWD>), dim3(a.B), dim3(256), 0, st, a);
-        }
-        rc = mos_check_launch("gn_nhwc_finalize");
-        if (rc) return rc;
-        MosProfScope prof(st, BWD ? "groupnorm_bwd_apply" : "groupnorm_apply", key, (BWD ? 14.0 : 8.0) * n, (BWD ? 6.0 : 4.0) * n);
-#define GN_APPLY_FIN(VTN, S, D) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, VTN, BWD, S, D, true>), grid, block, 0, st, a)
-        bool has_ds = false;
-        if constexpr (BWD) has_ds = a.ds != nullptr;
-        if constexpr (BWD) {
-            if (has_ds) {
-                if (vt == 1) { if (silu) GN_APPLY_FIN(1, true, true); else GN_APPLY_FIN(1, false, true); }
-                else { if (silu) GN_APPLY_FIN(2, true, true); else GN_APPLY_FIN(2, false, true); }
-                return mos_check_launch("gn_nhwc_apply");
-            }
-        }
-        if (vt == 1) { if (silu) GN_APPLY_FIN(1, true, false); else GN_APPLY_FIN(1, false, false); }
-        else { if (silu) GN_APPLY_FIN(2, true, false); else GN_APPLY_FIN(2, false, false); }
-#undef GN_APPLY_FIN
-        return mos_check_launch("gn_nhwc_apply");
+    {
+        MosProfScope prof(st, BWD ? "groupnorm_bwd_finalize" : "groupnorm_finalize", key, 2.0 * a.B * a.nsplit * a.G,
+                          8.0 * a.B * a.nsplit * a.G);
+        hipLaunchKernelGGL((gn_nhwc_finalize_kernel<BWD>), dim3(a.B), dim3(256), 0, st, a);
     }
+    rc = mos_check_launch("gn_nhwc_finalize");
+    if (rc) return rc;
     MosProfScope prof(st, BWD ? "groupnorm_bwd_apply" : "groupnorm_apply", key, (BWD ? 14.0 : 8.0) * n, (BWD ? 6.0 : 4.0) * n);
+#define GN_APPLY(VTN, S, D) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, VTN, BWD, S, D>), grid, block, 0, st, a)
     if constexpr (BWD) {
         if (a.ds != nullptr) {
-            if (vt == 1) {
-                if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, true, true, true>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, true, false, true>), grid, block, 0, st, a);
-            } else {
-                if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 2, true, true, true>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 2, true, false, true>), grid, block, 0, st, a);
-            }
+            if (vt == 1) { if (silu) GN_APPLY(1, true, true); else GN_APPLY(1, false, true); }
+            else { if (silu) GN_APPLY(2, true, true); else GN_APPLY(2, false, true); }
             return mos_check_launch("gn_nhwc_apply");
         }
     }
-    if (vt == 1) {
-        if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, BWD, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 1, BWD, false>), grid, block, 0, st, a);
-    } else {
-        if (silu) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 2, BWD, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, 2, BWD, false>), grid, block, 0, st, a);
-    }
+    if (vt == 1) { if (silu) GN_APPLY(1, true, false); else GN_APPLY(1, false, false); }
+    else { if (silu) GN_APPLY(2, true, false); else GN_APPLY(2, false, false); }
+#undef GN_APPLY
     return mos_check_launch("gn_nhwc_apply");
 }
 
@@ -631,7 +562,7 @@ int gn_nhwc_check(const void* x, const void* out, const float* gamma, const floa
 // 1920 -- runs of 80 .. 240 contiguous bytes per pixel). Its slab (<= 128 KB for every 32x32-and-smaller map of the UNet, and
 // for the 32x48 level of a 512x768 sample) stays in REGISTERS (K <= 16 vectors per thread at 510 threads), so the statistics
 // are the exact two-pass form (mean, then sum (x - mean)^2), and the tensor is read once and written once by one launch.
-// Slabs that do not fit (64x64 maps) can run the same kernel in streaming form (K = 0: one-pass sums, second read from L2).
+// Slabs that do not fit (64x64 maps) take the slice kernels (a streaming form of this kernel lost: 62 vs 21 us at level 0).
 // Workgroups are renumbered so that neighbouring columns (which share 128-byte lines) run on the same XCD / L2.
 struct GnColArgs {
     const void* x; const void* dy; const void* ds; void* out;
@@ -677,8 +608,7 @@ template <typename T, int K, bool BWD, bool SILU, bool DS>
 __global__ __launch_bounds__(GN_COL_T) void gn_col_kernel(GnColArgs a) {
     static_assert(BWD || !DS, "the bypass gradient exists in backward only");
     typedef typename MT<T>::v8 v8;
-    constexpr bool RES = K > 0;                    // slab resident in registers
-    constexpr int KR = RES ? K : 1;
+    static_assert(K > 0, "the slab of a column is register-resident (a streaming form was measured in round 4 and lost)");
     __shared__ float red[GN_COL_T / 64][2 * GN_COL_NG];
     __shared__ double totd[2 * GN_COL_NG];
     const int tid = threadIdx.x;
@@ -703,80 +633,44 @@ __global__ __launch_bounds__(GN_COL_T) void gn_col_kernel(GnColArgs a) {
     T* ob = (T*)a.out + img + cbase;
     const double ninv = 1.0 / ((double)a.cpg * (double)a.HW);
 
-    u32x4 xr[KR];
-    [[maybe_unused]] u32x4 dr[KR];
-    if constexpr (RES) {
+    u32x4 xr[K];
+    [[maybe_unused]] u32x4 dr[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const int p = row + k * a.RP;
-            const bool ok = active && p < a.HW;
-            xr[k] = ok ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
-            if constexpr (BWD) dr[k] = ok ? ld16(db + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
-        }
+    for (int k = 0; k < K; ++k) {
+        const int p = row + k * a.RP;
+        const bool ok = active && p < a.HW;
+        xr[k] = ok ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
+        if constexpr (BWD) dr[k] = ok ? ld16(db + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
     }
 
     float m0 = 0.f, r0 = 0.f, m1 = 0.f, r1 = 0.f;   // mean / rstd of gl0 and gl0 + 1
     if constexpr (!BWD) {
-        if constexpr (RES) {
-            // exact two-pass statistics from the registers
-            float a0 = 0.f, a1 = 0.f;
+        // exact two-pass statistics from the registers
+        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const v8 xv = as_v8<T>(xr[k]);     // (rows past HW are zeros: they add nothing)
+        for (int k = 0; k < K; ++k) {
+            const v8 xv = as_v8<T>(xr[k]);     // (rows past HW are zeros: they add nothing)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { const float f = (float)xv[i]; if (i < nb) a0 += f; else a1 += f; }
-            }
-            gn_col_block_sum(a0, 0.f, a1, 0.f, gl0, red, totd, nwaves);
-            m0 = (float)(totd[2 * gl0] * ninv);
-            m1 = two ? (float)(totd[2 * (gl0 + 1)] * ninv) : 0.f;
-            float q0 = 0.f, q1 = 0.f;
+            for (int i = 0; i < 8; ++i) { const float f = (float)xv[i]; if (i < nb) a0 += f; else a1 += f; }
+        }
+        gn_col_block_sum(a0, 0.f, a1, 0.f, gl0, red, totd, nwaves);
+        m0 = (float)(totd[2 * gl0] * ninv);
+        m1 = two ? (float)(totd[2 * (gl0 + 1)] * ninv) : 0.f;
+        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (!(active && row + k * a.RP < a.HW)) continue;
-                const v8 xv = as_v8<T>(xr[k]);
+        for (int k = 0; k < K; ++k) {
+            if (!(active && row + k * a.RP < a.HW)) continue;
+            const v8 xv = as_v8<T>(xr[k]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float d = (float)xv[i] - (i < nb ? m0 : m1);
-                    if (i < nb) q0 += d * d; else q1 += d * d;
-                }
-            }
-            gn_col_block_sum(q0, 0.f, q1, 0.f, gl0, red, totd, nwaves);
-            r0 = (float)(1.0 / sqrt(totd[2 * gl0] * ninv + (double)a.eps));
-            r1 = two ? (float)(1.0 / sqrt(totd[2 * (gl0 + 1)] * ninv + (double)a.eps)) : 0.f;
-        } else {
-            float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
-            constexpr int U = 4;
-            for (int k0 = 0; k0 < a.npass; k0 += U) {
-                u32x4 t[U];
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int p = row + (k0 + q) * a.RP;
-                    t[q] = (active && p < a.HW) ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
-                }
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const v8 xv = as_v8<T>(t[q]);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float f = (float)xv[i];
-                        if (i < nb) { a0 += f; q0 += f * f; } else { a1 += f; q1 += f * f; }
-                    }
-                }
-            }
-            gn_col_block_sum(a0, q0, a1, q1, gl0, red, totd, nwaves);
-            {
-                const double mm = totd[2 * gl0] * ninv;
-                double var = totd[2 * gl0 + 1] * ninv - mm * mm;
-                if (var < 0.0) var = 0.0;
-                m0 = (float)mm; r0 = (float)(1.0 / sqrt(var + (double)a.eps));
-            }
-            if (two) {
-                const double mm = totd[2 * (gl0 + 1)] * ninv;
-                double var = totd[2 * (gl0 + 1) + 1] * ninv - mm * mm;
-                if (var < 0.0) var = 0.0;
-                m1 = (float)mm; r1 = (float)(1.0 / sqrt(var + (double)a.eps));
+            for (int i = 0; i < 8; ++i) {
+                const float d = (float)xv[i] - (i < nb ? m0 : m1);
+                if (i < nb) q0 += d * d; else q1 += d * d;
             }
         }
+        gn_col_block_sum(q0, 0.f, q1, 0.f, gl0, red, totd, nwaves);
+        r0 = (float)(1.0 / sqrt(totd[2 * gl0] * ninv + (double)a.eps));
+        r1 = two ? (float)(1.0 / sqrt(totd[2 * (gl0 + 1)] * ninv + (double)a.eps)) : 0.f;
+    
         if (a.stats != nullptr && active && row == 0) {   // one writer per group: the thread whose vector starts the group
             if (vec * 8 == gl0 * a.cpg) { a.stats[gidx0 * 2] = m0; a.stats[gidx0 * 2 + 1] = r0; }
             if (two) { a.stats[(gidx0 + 1) * 2] = m1; a.stats[(gidx0 + 1) * 2 + 1] = r1; }
@@ -798,28 +692,12 @@ __global__ __launch_bounds__(GN_COL_T) void gn_col_kernel(GnColArgs a) {
             }
             st16(ob + (int64_t)p * a.C, from_v8<T>(o));
         };
-        if constexpr (RES) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int p = row + k * a.RP;
-                if (active && p < a.HW) apply(xr[k], p);
-            }
-        } else {
-            constexpr int U = 4;
-            for (int k0 = 0; k0 < a.npass; k0 += U) {
-                u32x4 t[U];
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int p = row + (k0 + q) * a.RP;
-                    t[q] = (active && p < a.HW) ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
-                }
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int p = row + (k0 + q) * a.RP;
-                    if (active && p < a.HW) apply(t[q], p);
-                }
-            }
+        for (int k = 0; k < K; ++k) {
+            const int p = row + k * a.RP;
+            if (active && p < a.HW) apply(xr[k], p);
         }
+    
     } else {
         m0 = a.stats[gidx0 * 2]; r0 = a.stats[gidx0 * 2 + 1];
         if (two) { m1 = a.stats[(gidx0 + 1) * 2]; r1 = a.stats[(gidx0 + 1) * 2 + 1]; }
@@ -847,26 +725,10 @@ __global__ __launch_bounds__(GN_COL_T) void gn_col_kernel(GnColArgs a) {
                 if (i < nb) { a0 += gg[i]; b0 += gg[i] * xh[i]; } else { a1 += gg[i]; b1 += gg[i] * xh[i]; }
             }
         };
-        if constexpr (RES) {
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-                if (active && row + k * a.RP < a.HW) accumulate(xr[k], dr[k]);
-        } else {
-            constexpr int U = 2;
-            for (int k0 = 0; k0 < a.npass; k0 += U) {
-                u32x4 tx[U], td[U];
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int p = row + (k0 + q) * a.RP;
-                    const bool ok = active && p < a.HW;
-                    tx[q] = ok ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
-                    td[q] = ok ? ld16(db + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
-                }
-#pragma unroll
-                for (int q = 0; q < U; ++q)
-                    if (active && row + (k0 + q) * a.RP < a.HW) accumulate(tx[q], td[q]);
-            }
-        }
+        for (int k = 0; k < K; ++k)
+            if (active && row + k * a.RP < a.HW) accumulate(xr[k], dr[k]);
+    
         gn_col_block_sum(a0, b0, a1, b1, gl0, red, totd, nwaves);
         const float mg0 = (float)(totd[2 * gl0] * ninv), mx0 = (float)(totd[2 * gl0 + 1] * ninv);
         const float mg1 = two ? (float)(totd[2 * (gl0 + 1)] * ninv) : 0.f, mx1 = two ? (float)(totd[2 * (gl0 + 1) + 1] * ninv) : 0.f;
@@ -884,46 +746,19 @@ __global__ __launch_bounds__(GN_COL_T) void gn_col_kernel(GnColArgs a) {
             }
             st16(ob + (int64_t)p * a.C, from_v8<T>(o));
         };
-        if constexpr (RES) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const int p = row + k * a.RP;
-                if (active && p < a.HW) apply(xr[k], dr[k], p);
-            }
-        } else {
-            constexpr int U = 2;
-            for (int k0 = 0; k0 < a.npass; k0 += U) {
-                u32x4 tx[U], td[U];
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int p = row + (k0 + q) * a.RP;
-                    const bool ok = active && p < a.HW;
-                    tx[q] = ok ? ld16(xb + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
-                    td[q] = ok ? ld16(db + (int64_t)p * a.C) : u32x4{0, 0, 0, 0};
-                }
-#pragma unroll
-                for (int q = 0; q < U; ++q) {
-                    const int p = row + (k0 + q) * a.RP;
-                    if (active && p < a.HW) apply(tx[q], td[q], p);
-                }
-            }
+        for (int k = 0; k < K; ++k) {
+            const int p = row + k * a.RP;
+            if (active && p < a.HW) apply(xr[k], dr[k], p);
         }
+    
     }
-}
-
-// MOS_GN_FUSED: 0 = slice kernels only (round 3), 1 = column kernel where the slab is register-resident (default),
-// 2 = column kernel (streaming form) also for larger maps. Read per call: tests and A/B runs flip it inside one process.
-int gn_fused_mode() {
-    const char* e = getenv("MOS_GN_FUSED");
-    return e == nullptr ? 1 : atoi(e);
 }
 
 int gn_gcd(int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; }
 
-// true: `c` is filled in and the column kernel takes this call (resident = slab fits K vectors per thread)
-bool gn_col_plan(const GnNhwcArgs& a, GnColArgs& c, bool& resident) {
-    const int mode = gn_fused_mode();
-    if (mode <= 0) return false;
+// true: `c` is filled in and the column kernel takes this call (the slab fits GN_COL_K vectors per thread)
+bool gn_col_plan(const GnNhwcArgs& a, GnColArgs& c) {
     const int cpg = a.C / a.G;
     const int cu = cpg / gn_gcd(cpg, 8) * 8;        // lcm(cpg, 8): whole groups AND whole 16-byte vectors
     if (cpg < 8 || cu < 32 || cu > 128 || a.C % cu != 0 || cu / cpg > GN_COL_NG) return false;   // (cpg >= 8: a vector spans <= 2 groups)
@@ -936,43 +771,41 @@ bool gn_col_plan(const GnNhwcArgs& a, GnColArgs& c, bool& resident) {
     c.S = threads / c.NV * c.NV;
     c.RP = c.S / c.NV;
     c.npass = (a.HW + c.RP - 1) / c.RP;
-    resident = c.npass <= GN_COL_K;
-    if (!resident && mode < 2) return false;
+    if (c.npass > GN_COL_K) return false;       // larger slabs (level 0, VAE): the slice kernels
     c.x = a.x; c.dy = a.dy; c.ds = a.ds; c.out = a.out; c.gamma = a.gamma; c.beta = a.beta; c.stats = a.stats;
     return true;
 }
 
 template <typename T, bool BWD>
-int gn_col_run(const GnColArgs& c, bool resident, int silu, hipStream_t st) {
+int gn_col_run(const GnColArgs& c, int silu, hipStream_t st) {
     const int threads = (c.S + 63) / 64 * 64;
     const dim3 grid(c.units * c.B), block(threads);
     char key[96];
-    snprintf(key, sizeof(key), "nhwc B%d C%d HW%d%s%s", c.B, c.C, c.HW, silu ? " +silu" : "", resident ? "" : " streaming");
+    snprintf(key, sizeof(key), "nhwc B%d C%d HW%d%s", c.B, c.C, c.HW, silu ? " +silu" : "");
     const double n = (double)c.B * c.C * c.HW;
     const bool has_ds = BWD && c.ds != nullptr;
     MosProfScope prof(st, BWD ? "groupnorm_bwd_fused" : "groupnorm_fused", key, (BWD ? 26.0 : 11.0) * n,
                       (BWD ? (has_ds ? 8.0 : 6.0) : 4.0) * n);
-#define GN_COL(KK, S_, D_) hipLaunchKernelGGL((gn_col_kernel<T, KK, BWD, S_, D_>), grid, block, 0, st, c)
+#define GN_COL(S_, D_) hipLaunchKernelGGL((gn_col_kernel<T, GN_COL_K, BWD, S_, D_>), grid, block, 0, st, c)
     if constexpr (BWD) {
         if (has_ds) {
-            if (resident) { if (silu) GN_COL(GN_COL_K, true, true); else GN_COL(GN_COL_K, false, true); }
-            else { if (silu) GN_COL(0, true, true); else GN_COL(0, false, true); }
+            if (silu) GN_COL(true, true); else GN_COL(false, true);
             return mos_check_launch("gn_col");
         }
     }
-    if (resident) { if (silu) GN_COL(GN_COL_K, true, false); else GN_COL(GN_COL_K, false, false); }
-    else { if (silu) GN_COL(0, true, false); else GN_COL(0, false, false); }
+    if (silu) GN_COL(true, false); else GN_COL(false, false);
 #undef GN_COL
     return mos_check_launch("gn_col");
 }
 
+// flags: bit 0 = SiLU, bit 1 (MOS_GN_FORCE_SLICES) = the three-launch slice form even where the column kernel applies (tests / A-B)
 template <bool BWD>
-int gn_nhwc_dispatch(GnNhwcArgs& a, int silu, int dtype, hipStream_t st, const char* who) {
+int gn_nhwc_dispatch(GnNhwcArgs& a, int flags, int dtype, hipStream_t st, const char* who) {
+    const int silu = flags & 1;
     GnColArgs c = {};
-    bool resident = false;
-    if (gn_col_plan(a, c, resident)) {
-        if (dtype == MOS_F16) return gn_col_run<f16_t, BWD>(c, resident, silu, st);
-        if (dtype == MOS_BF16) return gn_col_run<bf16_t, BWD>(c, resident, silu, st);
+    if (!(flags & MOS_GN_FORCE_SLICES) && gn_col_plan(a, c)) {
+        if (dtype == MOS_F16) return gn_col_run<f16_t, BWD>(c, silu, st);
+        if (dtype == MOS_BF16) return gn_col_run<bf16_t, BWD>(c, silu, st);
         return mos_set_error(MOS_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
     }
     if (dtype == MOS_F16) return gn_nhwc_run<f16_t, BWD>(a, silu, st);

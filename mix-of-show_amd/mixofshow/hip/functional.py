@@ -477,14 +477,12 @@ def lora_linear(x, W16, Wt16, bias32, sites, residual=None):
 # ---- feed-forward of the transformer block (diffusers FeedForward: GEGLU projection, Linear) on the library's GEMM ---------
 # Switches, defaults from the same-box measurements of round 4 (profiles/r04_kernel_bench_ff_gn_conv.txt,
 # profiles/r04_ab_same_box_{train,regional}_switches.txt):
-#   MOS_FF_GEGLU (default 0): FF1 as the library's GEMM with the GEGLU epilogue when sampling. Measured: equal to hipBLASLt +
-#     geglu kernel at level 0 (51.5 vs 50.6 us), slower at the wide levels (N = 5120 / 10240: 38 vs 33, 52 vs 34 us; regional
-#     sample 508.8 vs 504.8 ms) -- kept as an option, off.
+#   (FF1 with a GEGLU epilogue in the library's GEMM was an option of round 4: equal to hipBLASLt + the geglu kernel at level 0,
+#    slower at the wide levels; removed in round 5.)
 #   MOS_FF2_OWN (default 1): FF2 as the library's GEMM with the residual add in its epilogue where it wins: K = 4C <= 1280
 #     (level 0: 19.4 vs 24.4 us sampling, 24.8 vs 25.7 training) and K <= 2560 up to 3072 rows (22.9 vs 25.7 us); the wide
 #     levels stay on hipBLASLt + add (33.5 vs 27.3 us at 768 x 5120 -> 1280).
 #   MOS_GEMM_RESIDUAL (default 1): the 1x1 proj_out's residual in the GEMM epilogue (bit-identical to GEMM + add).
-_ff_geglu = _os.environ.get('MOS_FF_GEGLU', '0') != '0'
 _ff2_own = _os.environ.get('MOS_FF2_OWN', '1') != '0'
 _gemm_residual = _os.environ.get('MOS_GEMM_RESIDUAL', '1') != '0'
 
@@ -511,7 +509,8 @@ def linear_residual(linear, x, residual):
     dt = _half_path(x) if (_ff2_own and _plain_linear(linear)) else None
     K, rows = linear.in_features, x.numel() // max(1, x.shape[-1])
     wins = K <= 1280 or (K <= 2560 and rows <= 3072)         # measured crossover against hipBLASLt + add, see above
-    if dt is None or not wins or K % 8 or linear.out_features % 8 or residual.shape[:-1] != x.shape[:-1]:
+    if (dt is None or not wins or K % 8 or linear.out_features % 8 or residual.shape[:-1] != x.shape[:-1]
+            or residual.dtype != dt):        # (a residual stream of another dtype keeps `linear(x) + residual`'s promotion)
         return linear(x) + residual
     cache = linear.__dict__.get('_mos_cache')
     if cache is None:
@@ -524,26 +523,9 @@ def linear_residual(linear, x, residual):
 
 
 def linear_geglu(proj, x):
-    """`geglu(proj(x))` (diffusers GEGLU). Sampling (no gradient wanted) on the HIP path: ONE GEMM whose epilogue forms
-    value * gelu(gate) from the interleaved weight rows -- the (rows, 8C) pre-activation is never written. Training keeps the
-    pre-activation (the backward of GEGLU needs it): torch's GEMM + the geglu kernel."""
-    dt = _half_path(x) if (_ff_geglu and _plain_linear(proj)) else None
-    if (dt is None or (torch.is_grad_enabled() and x.requires_grad) or proj.in_features % 8 or proj.out_features % 32):
-        return geglu(proj(x))
-    ent = proj.__dict__.get('_mos_geglu')
-    w, b = proj.weight, proj.bias
-    key = (w.data_ptr(), w._version, w.dtype, dt, None if b is None else (b.data_ptr(), b._version))
-    if ent is None or ent[0] != key:
-        Wi, bi = ops.geglu_interleave(w.detach().to(dt), None if b is None else b.detach().float())
-        ent = (key, Wi, bi)
-        object.__setattr__(proj, '_mos_geglu', ent)
-    x2 = x.reshape(-1, x.shape[-1])
-    if x2.dtype != dt:
-        x2 = x2.to(dt)
-    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
-        x2 = x2.contiguous()
-    y = ops.linear_fwd_ex(x2, ent[1], None, None, ent[2], geglu=True)[0]
-    return y.view(*x.shape[:-1], y.shape[-1])
+    """`geglu(proj(x))` (diffusers GEGLU): the projection GEMM (hipBLASLt through torch: measured faster than the library's GEMM
+    at these widths) + ONE fused kernel each way for value * gelu(gate) (the backward needs the pre-activation)."""
+    return geglu(proj(x))
 
 
 class _Attention(torch.autograd.Function):

@@ -70,7 +70,7 @@ class LoraFinalRec(ctypes.Structure):          # mos_lora_final_rec
 
 
 class GemmEpilogue(ctypes.Structure):          # mos_gemm_epilogue
-    _fields_ = [('residual', ctypes.c_void_p), ('ldr', ctypes.c_int64), ('geglu', ctypes.c_int)]
+    _fields_ = [('residual', ctypes.c_void_p), ('ldr', ctypes.c_int64)]
 
 
 class AttnShape(ctypes.Structure):
@@ -169,7 +169,6 @@ _lib = None
 _lock = threading.Lock()
 
 
-RING_MAX_WG_DEFAULT = 640
 
 
 def load():
@@ -185,9 +184,6 @@ def load():
                 f'libmos_hip.so not found at {LIB_PATH}. Build it with `bash mix-of-show_amd/csrc/build.sh` '
                 '(or `python -c "import __graft_entry__ as g; g.build()"`). mixofshow has no CPU/PyTorch fallback '
                 'for its kernel-backed ops.')
-        # Host-side tuning defaults of the kernels' own switches (read by the library with getenv at first launch):
-        # MOS_RING_MAX_WG = workgroup count up to which the GEMM / conv K loops run as an LDS-DMA ring (0 = never).
-        os.environ.setdefault('MOS_RING_MAX_WG', str(RING_MAX_WG_DEFAULT))
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch

@@ -218,34 +218,21 @@ def linear_fwd(x, W, t=None, Bp16=None, bias=None, out=None):
     return y
 
 
-def geglu_interleave(W, bias=None):
-    """The GEGLU projection's rows (and bias) in the order the GEGLU epilogue of linear_fwd_ex consumes: blocks of 16 value
-    rows followed by the 16 gate rows of the same output features (include/mos_hip.h mos_gemm_epilogue). W (2F, K)."""
-    F2 = W.shape[0]
-    assert F2 % 32 == 0
-    F = F2 // 2
-    idx = torch.arange(F, device=W.device).view(F // 16, 1, 16)
-    perm = torch.cat([idx, idx + F], dim=1).reshape(-1)           # [16 value | 16 gate] per block
-    return W[perm].contiguous(), (None if bias is None else bias[perm].contiguous())
-
-
-def linear_fwd_ex(x, W, A16=None, Bp16=None, bias=None, residual=None, geglu=False, need_t=False):
-    """mos_lora_linear_fwd_ex: y = x . W^T (+ (x . A16^T) . Bp16^T) (+ bias) with an epilogue variant:
-    residual (M, Nout): added to the rounded result (== GEMM followed by a half add, one launch);
-    geglu: W / bias interleaved by geglu_interleave, y (M, N/2) = value * gelu(gate). Returns (y, t | None)."""
+def linear_fwd_ex(x, W, A16=None, Bp16=None, bias=None, residual=None, need_t=False):
+    """mos_lora_linear_fwd_ex: y = x . W^T (+ (x . A16^T) . Bp16^T) (+ bias) with the residual epilogue:
+    residual (M, N): added to the rounded result (== GEMM followed by a half add, one launch). Returns (y, t | None)."""
     _dev(x, W, A16, Bp16, bias, residual)
     M, K = x.shape
     N = W.shape[0]
-    nout = N // 2 if geglu else N
     assert W.shape[1] == K and W.dtype == x.dtype and (A16 is None) == (Bp16 is None)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.is_contiguous()
     epi = _lib.GemmEpilogue()
-    epi.residual, epi.ldr, epi.geglu = None, 0, int(bool(geglu))
+    epi.residual, epi.ldr = None, 0
     if residual is not None:
-        assert residual.shape == (M, nout) and residual.dtype == x.dtype
+        assert residual.shape == (M, N) and residual.dtype == x.dtype
         epi.residual, epi.ldr = residual.data_ptr(), _rows(residual)
-    y = torch.empty((M, nout), dtype=x.dtype, device=x.device)
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device)
     t = torch.empty((M, MOS_LORA_PAD), dtype=x.dtype, device=x.device) if (need_t and A16 is not None) else None
     L = _lib.load()
     _lib.check(L.mos_lora_linear_fwd_ex(_p(x), _rows(x), _p(W), _rows(W), _p(A16), _p(Bp16), _p(bias), _p(y), _rows(y), _p(t),
@@ -434,9 +421,10 @@ def _is_nhwc(x):
     return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
 
 
-def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
+def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False):
     """x (B, C, *spatial) half, contiguous (NCHW) or channels_last (NHWC); gamma/beta fp32.
-    Returns (y like x, same memory format; stats (B*G, 2) fp32)."""
+    Returns (y like x, same memory format; stats (B*G, 2) fp32). force_slices (channels_last): the three-launch slice kernels
+    also where the one-launch column kernel applies (MOS_GN_FORCE_SLICES; parity tests, A/B)."""
     _dev(x, gamma, beta)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
@@ -446,7 +434,7 @@ def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
     if _is_nhwc(x):
         ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
         _lib.check(L.mos_groupnorm_silu_fwd_nhwc(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, C, HW, groups,
-                                                 float(eps), int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_fwd_nhwc')
+                                                 float(eps), int(bool(silu)) | (2 if force_slices else 0), _dt(x), _stream()), 'mos_groupnorm_silu_fwd_nhwc')
         return y, stats
     assert x.is_contiguous(), 'groupnorm_silu_fwd needs a contiguous (NCHW) or channels_last (NHWC) tensor'
     ws = torch.empty((L.mos_groupnorm_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
@@ -455,7 +443,7 @@ def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
     return y, stats
 
 
-def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None):
+def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None, force_slices=False):
     """dy must have x's memory format. ds (channels_last x only): gradient of a skip path around the norm, same format and
     dtype as x; the result is round(GN_bwd(dy)) + ds in one kernel."""
     _dev(dy, x, gamma, beta, stats, ds)
@@ -469,11 +457,11 @@ def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None):
         if ds is not None:
             assert _same_layout(ds, x) and ds.dtype == x.dtype
             _lib.check(L.mos_groupnorm_silu_bwd_nhwc_res(_p(dy), _p(ds), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws),
-                                                         B, C, HW, groups, int(bool(silu)), _dt(x), _stream()),
+                                                         B, C, HW, groups, int(bool(silu)) | (2 if force_slices else 0), _dt(x), _stream()),
                        'mos_groupnorm_silu_bwd_nhwc_res')
             return dx
         _lib.check(L.mos_groupnorm_silu_bwd_nhwc(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, C, HW,
-                                                 groups, int(bool(silu)), _dt(x), _stream()), 'mos_groupnorm_silu_bwd_nhwc')
+                                                 groups, int(bool(silu)) | (2 if force_slices else 0), _dt(x), _stream()), 'mos_groupnorm_silu_bwd_nhwc')
         return dx
     assert x.is_contiguous() and dy.is_contiguous() and ds is None, 'the bypass gradient is fused for channels_last only'
     ws = torch.empty((L.mos_groupnorm_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)

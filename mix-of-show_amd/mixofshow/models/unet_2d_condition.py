@@ -104,8 +104,8 @@ class _TimeProjections:
                  or p._forward_pre_hooks) and type(p) is nn.Linear for p in (b.time_emb_proj for b in self.blocks))
 
     def __call__(self, act):
-        key = tuple((b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.bias._version,
-                     b.time_emb_proj.weight.dtype) for b in self.blocks)
+        key = tuple((b.time_emb_proj.weight.data_ptr(), b.time_emb_proj.weight._version, b.time_emb_proj.weight.dtype,
+                     b.time_emb_proj.bias.data_ptr(), b.time_emb_proj.bias._version, b.time_emb_proj.bias.dtype) for b in self.blocks)
         if key != self.key:
             by_width = {}
             for b in self.blocks:

@@ -200,6 +200,12 @@ class StableDiffusionPipeline:
             prompt_embeds = torch.cat([n, prompt_embeds])
         return prompt_embeds[:, 0] if layer_num == 1 else prompt_embeds
 
+    def clear_sampling_graphs(self):
+        """Release the captured UNet graphs kept across calls (their memory pools stay pinned otherwise, e.g. between the
+        validation calls of a training run)."""
+        from mixofshow.utils import hipgraph as hipgraph_util
+        return hipgraph_util.clear_sampling_graphs(self)
+
     @torch.no_grad()
     def __call__(self, prompt=None, height=None, width=None, num_inference_steps=50, guidance_scale=7.5,
                  negative_prompt=None, num_images_per_prompt=1, eta=0.0, generator=None, latents=None,

@@ -271,6 +271,12 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
             out.append(w * f)
         return out
 
+    def clear_sampling_graphs(self):
+        """Release the captured UNet graphs kept across calls (their memory pools stay pinned otherwise, e.g. between the
+        validation calls of a training run)."""
+        from mixofshow.utils import hipgraph as hipgraph_util
+        return hipgraph_util.clear_sampling_graphs(self)
+
     @torch.no_grad()
     def __call__(self, prompt=None, keypose_adapter_input=None, keypose_adaptor_weight=1.0,
                  region_keypose_adaptor_weight='', sketch_adapter_input=None, sketch_adaptor_weight=1.0,

@@ -35,7 +35,20 @@ def model_epoch(module):
     h = 0
     for t in list(module.parameters()) + list(module.buffers()):
         h = (h * 1000003 + hash((t.data_ptr(), t._version, t.dtype))) & 0xFFFFFFFFFFFFFFFF
-    return h
+    # the derived copies are also keyed by COMPUTE dtype (functional.WeightCache / _ConvWeights): the same weights sampled under
+    # another autocast dtype re-allocate them, and a graph captured before would replay against freed addresses
+    ac = (torch.is_autocast_enabled('cuda'), torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else None)
+    return (h * 1000003 + hash(ac)) & 0xFFFFFFFFFFFFFFFF
+
+
+def clear_sampling_graphs(pipe):
+    """Drop the captured UNet graphs a sampling pipeline keeps across calls (and with them their private memory pools): call
+    when validation ends and training resumes, or before changing weights out of band."""
+    graphs = pipe.__dict__.get('_sampling_graphs')
+    n = len(graphs) if graphs else 0
+    if graphs:
+        graphs.clear()
+    return n
 
 
 def graphs_usable(device):

@@ -52,18 +52,12 @@ def linear_fused_fwd(x, W, A16, Bp16, bias=None, need_t=True):
     return linear_fwd(x, W, t, Bp16, bias), (t if need_t else None)
 
 
-def linear_fwd_ex(x, W, A16=None, Bp16=None, bias=None, residual=None, geglu=False, need_t=False):
-    """mos_lora_linear_fwd_ex: the GEMM rounded to the half type, then the epilogue on the rounded values (geglu on the
-    interleaved [16 value | 16 gate] column blocks; residual added last, rounded again)."""
+def linear_fwd_ex(x, W, A16=None, Bp16=None, bias=None, residual=None, need_t=False):
+    """mos_lora_linear_fwd_ex: the GEMM rounded to the half type, then the residual added to the rounded values, rounded again."""
     t = None
     if A16 is not None:
         t = (x.float() @ A16.float().t()).to(x.dtype)
     y = linear_fwd(x, W, t, Bp16, bias)
-    if geglu:
-        assert residual is None, 'the GEGLU epilogue takes no residual'
-        M, N = y.shape
-        blk = y.view(M, N // 32, 2, 16).float()
-        y = (blk[:, :, 0] * torch.nn.functional.gelu(blk[:, :, 1])).reshape(M, N // 2).to(x.dtype)
     if residual is not None:
         y = (y.float() + residual.float()).to(x.dtype)
     return y, (t if need_t else None)
@@ -202,7 +196,7 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
     return loss, 2.0 * R / n_times_cout
 
 
-def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
+def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False):
     import torch.nn.functional as F
     cd = torch.float64 if x.dtype == torch.float64 else torch.float32
     xf = x.to(cd)
@@ -217,7 +211,7 @@ def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu):
     return y.to(x.dtype), stats
 
 
-def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None):
+def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None, force_slices=False):
     """Closed-form GroupNorm(+SiLU) input gradient from the saved (mean, rstd); checked against autograd in
     tests/test_host_cpu.py."""
     B, C = x.shape[0], x.shape[1]

@@ -562,29 +562,6 @@ def test_gemm_residual_epilogue(ops, emu, dtype, M, N, K, lora):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-@pytest.mark.parametrize('M,C', [(12288, 320), (8192, 320), (3072, 640), (768, 1280), (192, 1280), (100, 64)])
-def test_gemm_geglu_epilogue(ops, emu, dtype, M, C):
-    """mos_lora_linear_fwd_ex(geglu) on the interleaved GEGLU projection (C -> 8C): bit-identical to the GEMM on the original
-    weight followed by mos_geglu_fwd (same arithmetic: rounded pre-activations, fp32 product, one rounding)."""
-    g = torch.Generator(device='cpu').manual_seed(13)
-    x = torch.randn(M, C, generator=g).to('cuda', dtype)
-    W = (torch.randn(8 * C, C, generator=g) * C ** -0.5).to('cuda', dtype)
-    b = (torch.randn(8 * C, generator=g) * 0.1).cuda()
-    Wi, bi = ops.geglu_interleave(W, b)
-    y, _ = ops.linear_fwd_ex(x, Wi, None, None, bi, geglu=True)
-    assert y.shape == (M, 4 * C)
-    want = ops.geglu_fwd(ops.linear_fwd(x, W, None, None, b))
-    exact = torch.equal(y, want)
-    print(f'[parity] gemm+geglu[{M}x{8 * C}x{C}] bit-identical to GEMM + geglu kernel: {exact}')
-    if not exact:          # (the two GEMMs tile N differently only if their grids differ: same kernel, same K order -> expected exact)
-        _check('gemm+geglu vs GEMM + geglu kernel', y, want, dtype, ulps=1.0)
-    _check('gemm+geglu vs emulation', y, emu.linear_fwd_ex(x, Wi, None, None, bi, geglu=True)[0], dtype, ulps=2.0)
-    from mixofshow.hip.lib import MosHipError
-    with pytest.raises(MosHipError, match='no residual'):
-        ops.linear_fwd_ex(x, Wi, None, None, bi, residual=torch.zeros_like(y), geglu=True)
-
-
-@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('silu', [True, False])
 @pytest.mark.parametrize('B,C,H,W', [
     (4, 640, 32, 32), (2, 640, 32, 48),      # 40-channel columns, two groups each (resident: 1024 / 1536 pixels)
@@ -592,13 +569,13 @@ def test_gemm_geglu_epilogue(ops, emu, dtype, M, C):
     (2, 1280, 16, 24), (4, 1280, 8, 8),      # one group per column
     (2, 2560, 8, 12), (4, 2560, 16, 16),     # 80-channel columns
     (2, 1920, 16, 24), (4, 960, 16, 16),     # 120-channel columns: 2 / 4 groups, 15 vectors per pixel
-    (2, 1920, 32, 48), (2, 960, 32, 48),     # 120-channel columns too large for registers: slice kernels in mode 1
-    (4, 320, 64, 64), (2, 320, 64, 96),      # level 0: streaming column form in mode 2 only
+    (2, 1920, 32, 48), (2, 960, 32, 48),     # 120-channel columns too large for registers: slice kernels
+    (4, 320, 64, 64), (2, 320, 64, 96),      # level 0: slice kernels either way
     (1, 640, 5, 8),                          # fewer vectors than one wave
 ])
-def test_groupnorm_column_kernel(ops, emu, dtype, silu, B, C, H, W, monkeypatch):
-    """The one-launch column kernel (MOS_GN_FUSED=1: register-resident slabs; =2: also the streaming form) against the
-    slice kernels of round 3 (=0) and the fp32 emulation: forward, statistics, input gradient, gradient + bypass."""
+def test_groupnorm_column_kernel(ops, emu, dtype, silu, B, C, H, W):
+    """The one-launch column kernel (register-resident slabs; the library's choice wherever a slab fits) against the three-launch
+    slice kernels (MOS_GN_FORCE_SLICES) and the fp32 emulation: forward, statistics, input gradient, gradient + bypass."""
     g = torch.Generator(device='cpu').manual_seed(8)
     cl = torch.channels_last
     x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to('cuda', dtype).contiguous(memory_format=cl)
@@ -612,22 +589,20 @@ def test_groupnorm_column_kernel(ops, emu, dtype, silu, B, C, H, W, monkeypatch)
     out = torch.nn.functional.silu(out) if silu else out
     (dx_ref, ) = torch.autograd.grad(out, xf, dy.float().contiguous())
     res = {}
-    for mode in ('0', '1', '2'):
-        monkeypatch.setenv('MOS_GN_FUSED', mode)
-        y, stats = ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, silu)
-        dx = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats_ref, 32, silu)
-        dxs = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats_ref, 32, silu, ds=ds)
+    for mode, slices in (('slices', True), ('auto', False)):
+        y, stats = ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, silu, force_slices=slices)
+        dx = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats_ref, 32, silu, force_slices=slices)
+        dxs = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats_ref, 32, silu, ds=ds, force_slices=slices)
         assert y.stride() == x.stride() and dx.stride() == x.stride()
-        _check(f'groupnorm[mode {mode}].y[{B}x{C}x{H}x{W}]', y, y_ref, dtype, ulps=2.0)
-        _check(f'groupnorm[mode {mode}].stats', stats, stats_ref, torch.float16, ulps=0.05)
-        _check(f'groupnorm[mode {mode}].dx', dx, dx_ref, dtype, ulps=3.0)
-        _check(f'groupnorm[mode {mode}].dx+ds', dxs, dx.float() + ds.float(), dtype, ulps=1.0)
+        _check(f'groupnorm[{mode}].y[{B}x{C}x{H}x{W}]', y, y_ref, dtype, ulps=2.0)
+        _check(f'groupnorm[{mode}].stats', stats, stats_ref, torch.float16, ulps=0.05)
+        _check(f'groupnorm[{mode}].dx', dx, dx_ref, dtype, ulps=3.0)
+        _check(f'groupnorm[{mode}].dx+ds', dxs, dx.float() + ds.float(), dtype, ulps=1.0)
         res[mode] = (y, stats, dx)
-    for mode in ('1', '2'):
-        same = torch.equal(res[mode][0], res['0'][0]) and torch.equal(res[mode][2], res['0'][2])
-        print(f'[parity] groupnorm column kernel mode {mode} [{B}x{C}x{H}x{W} silu={silu}] bit-identical to the slice kernels: {same}')
-        _check(f'groupnorm mode {mode} vs slice kernels: y', res[mode][0], res['0'][0], dtype, ulps=1.0)
-        _check(f'groupnorm mode {mode} vs slice kernels: dx', res[mode][2], res['0'][2], dtype, ulps=1.0)
+    same = torch.equal(res['auto'][0], res['slices'][0]) and torch.equal(res['auto'][2], res['slices'][2])
+    print(f'[parity] groupnorm library choice [{B}x{C}x{H}x{W} silu={silu}] bit-identical to the slice kernels: {same}')
+    _check('groupnorm library choice vs slice kernels: y', res['auto'][0], res['slices'][0], dtype, ulps=1.0)
+    _check('groupnorm library choice vs slice kernels: dx', res['auto'][2], res['slices'][2], dtype, ulps=1.0)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)

@@ -58,7 +58,43 @@ def test_test_cli_on_saved_checkpoint(emulated_hip, tmp_path):
     p = tmp_path / 'test.yml'
     with open(p, 'w') as f:
         yaml.safe_dump(opt, f)
+    opt['val']['compose_visualize'] = True
+    with open(p, 'w') as f:
+        yaml.safe_dump(opt, f)
     test_edlora.test(str(tmp_path), argparse.Namespace(opt=str(p)))
-    out = tmp_path / 'results' / 'cli_cpu_test' / 'visualization' / 'validation_0.7'
+    # the reference's layout (test_edlora.py:44): <visualization>/<dataset name>/<current_iter>/<prompt>---G_x_S_y---<i>---<iter>.png
+    out = tmp_path / 'results' / 'cli_cpu_test' / 'visualization' / opt['datasets']['val_vis']['name'] / 'validation_0.7'
     pngs = [f for f in os.listdir(out) if f.endswith('.png')]
     assert len(pngs) == 1 and '<potter1>' in pngs[0]       # 1 prompt x 1 sample, <TOK> replaced in the file name
+    assert pngs[0].endswith('---G_7.5_S_2---1---validation_0.7.png')
+    # compose_visualize (reference utils/util.py:279-313): caption tile + the sample, one row per prompt, saved beside the folder
+    grid = out.parent / 'G_7.5_S_2---validation_0.7.jpg'
+    assert grid.exists()
+    from PIL import Image
+    w, h = Image.open(grid).size
+    assert (w, h) == (2 * (64 + 2) + 2, 64 + 2 + 2)        # make_grid: 2 tiles of 64 px (8x8 latent), 2-pixel padding
+
+
+def test_compose_visualize_grid_layout(tmp_path):
+    """Two prompts x two samples -> 2 rows of [caption | sample | sample]; mixed sample args are refused (reference assert)."""
+    import numpy as np
+    import pytest
+    from PIL import Image
+    import mos_path  # noqa: F401
+    from mixofshow.utils.util import compose_visualize, make_grid
+    d = tmp_path / 'val' / 'iter1'
+    d.mkdir(parents=True)
+    for pi, prompt in enumerate(('a_cat', 'a_dog')):
+        for i in (1, 2):
+            Image.fromarray(np.full((32, 48, 3), 40 * (2 * pi + i), dtype=np.uint8)).save(d / f'{prompt}---G_7.5_S_50---{i}---iter1.png')
+    out = compose_visualize(str(d))
+    assert out.endswith('G_7.5_S_50---iter1.jpg')
+    img = np.asarray(Image.open(out).convert('RGB')).astype(int)
+    assert img.shape == (2 * 34 + 2, 3 * 50 + 2, 3)
+    assert abs(img[2 + 16, 2 + 50 + 24].mean() - 40) <= 3 and abs(img[2 + 34 + 16, 2 + 100 + 24].mean() - 160) <= 3
+    assert img[0].max() <= 8                                # padding rows are black
+    g = make_grid([torch.ones(3, 4, 4)] * 5, nrow=2)
+    assert g.shape == (3, 3 * 6 + 2, 2 * 6 + 2)
+    Image.fromarray(np.zeros((32, 48, 3), dtype=np.uint8)).save(d / 'a_cat---G_3_S_50---3---iter1.png')
+    with pytest.raises(AssertionError, match='same sample args'):
+        compose_visualize(str(d))

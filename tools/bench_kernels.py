@@ -136,8 +136,8 @@ def _timed(fn, iters):
 
 def ff_reference(levels, dtype, iters):
     """Feed-forward of the transformer block (rows x C -> 8C -GEGLU-> 4C -> C, + residual) per UNet level: torch's GEMMs
-    (hipBLASLt) + geglu kernel + add, against the library's GEMM with the GEGLU / residual epilogues."""
-    print(f"{'FF rows C':18s} {'FF1 blas':>9s} {'+geglu':>8s} {'FF1 mos+geglu epi':>18s} {'FF2 blas':>9s} {'+add':>7s} {'FF2 mos+res epi':>16s} {'FF2 mos':>8s}")
+    (hipBLASLt) + geglu kernel + add, against the library's GEMM with the residual epilogue."""
+    print(f"{'FF rows C':18s} {'FF1 blas':>9s} {'+geglu':>8s} {'FF2 blas':>9s} {'+add':>7s} {'FF2 mos+res epi':>16s} {'FF2 mos':>8s}")
     with torch.no_grad():
         for rows, C in levels:
             x = torch.randn(rows, C, device='cuda', dtype=dtype)
@@ -146,25 +146,23 @@ def ff_reference(levels, dtype, iters):
             W2 = torch.randn(C, 4 * C, device='cuda', dtype=dtype) / math.sqrt(4 * C)
             b2 = torch.randn(C, device='cuda', dtype=dtype) * 0.1
             res = torch.randn(rows, C, device='cuda', dtype=dtype)
-            W1i, b1i = ops.geglu_interleave(W1, b1.float())
             b2f = b2.float()
             h = torch.nn.functional.linear(x, W1, b1)
             a = ops.geglu_fwd(h)
             t_f1 = _timed(lambda: torch.nn.functional.linear(x, W1, b1), iters)
             t_g = _timed(lambda: ops.geglu_fwd(h), iters)
-            t_f1m = _timed(lambda: ops.linear_fwd_ex(x, W1i, None, None, b1i, geglu=True), iters)
             t_f2 = _timed(lambda: torch.nn.functional.linear(a, W2, b2), iters)
             y = torch.nn.functional.linear(a, W2, b2)
             t_add = _timed(lambda: y + res, iters)
             t_f2m = _timed(lambda: ops.linear_fwd_ex(a, W2, None, None, b2f, residual=res), iters)
             t_f2p = _timed(lambda: ops.linear_fwd(a, W2, None, None, b2f), iters)
-            print(f"{f'{rows} {C}':18s} {t_f1:9.1f} {t_g:8.1f} {t_f1m:18.1f} {t_f2:9.1f} {t_add:7.1f} {t_f2m:16.1f} {t_f2p:8.1f}")
+            print(f"{f'{rows} {C}':18s} {t_f1:9.1f} {t_g:8.1f} {t_f2:9.1f} {t_add:7.1f} {t_f2m:16.1f} {t_f2p:8.1f}")
 
 
 def gn_reference(shapes, dtype, iters):
-    """GroupNorm(+SiLU) on channels_last maps: slice kernels (MOS_GN_FUSED=0: 3 launches) vs the one-launch column kernel
-    (=1 register-resident only, =2 also streaming), forward and backward, us per call."""
-    print(f"{'GroupNorm B C HxW':24s} {'fwd m0':>8s} {'fwd m1':>8s} {'fwd m2':>8s} {'bwd m0':>8s} {'bwd m1':>8s} {'bwd m2':>8s} {'MB':>7s}")
+    """GroupNorm(+SiLU) on channels_last maps: slice kernels (MOS_GN_FORCE_SLICES: 3 launches) vs the library's choice (the
+    one-launch column kernel where the slab is register-resident), forward and backward, us per call."""
+    print(f"{'GroupNorm B C HxW':24s} {'fwd slices':>10s} {'fwd auto':>9s} {'bwd slices':>10s} {'bwd auto':>9s} {'MB':>7s}")
     for B, C, H, W in shapes:
         x = torch.randn(B, C, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
         dy = torch.randn(B, C, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
@@ -172,14 +170,12 @@ def gn_reference(shapes, dtype, iters):
         _, stats = ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, True)
         row = []
         for kind in ('fwd', 'bwd'):
-            for mode in ('0', '1', '2'):
-                os.environ['MOS_GN_FUSED'] = mode
+            for slices in (True, False):
                 if kind == 'fwd':
-                    row.append(_timed(lambda: ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, True), iters))
+                    row.append(_timed(lambda: ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, True, force_slices=slices), iters))
                 else:
-                    row.append(_timed(lambda: ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, True), iters))
-        os.environ.pop('MOS_GN_FUSED', None)
-        print(f"{f'B{B} C{C} {H}x{W}':24s} " + ' '.join(f'{v:8.1f}' for v in row) + f' {x.numel() * 2 / 1e6:7.2f}')
+                    row.append(_timed(lambda: ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, True, force_slices=slices), iters))
+        print(f"{f'B{B} C{C} {H}x{W}':24s} " + ' '.join(f'{v:9.1f}' for v in row) + f' {x.numel() * 2 / 1e6:7.2f}')
 
 
 def region_case(fh, fw, d, dtype, iters):

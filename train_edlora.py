@@ -117,7 +117,7 @@ def save_and_validation(opt, trainer, global_step, logger, rank):
             pipe, cfg = convert_edlora(pipe, torch.load(save_path, weights_only=False), enable_edlora=enable_edlora,
                                        alpha=lora_alpha)
             pipe.set_new_concept_cfg(cfg)
-            visual_validation(pipe, loader, f'Iters-{global_step}_Alpha-{lora_alpha}', opt, rank)
+            visual_validation(None, pipe, loader, f'Iters-{global_step}_Alpha-{lora_alpha}', opt)     # reference :187
             del pipe
 
 
