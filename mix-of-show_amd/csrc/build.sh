@@ -2,7 +2,7 @@
 # Build libmos_hip.so for gfx950 (MI355X). Cross-compiles without a GPU.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-# MOS_OUT / MOS_BUILD_DIR / MOS_ATTN_SRC / MOS_ATTN_FLAGS: kernel-variant builds for same-box A/B runs (load with MOS_HIP_LIB=...)
+# MOS_OUT / MOS_BUILD_DIR / MOS_ATTN_SRC / MOS_ATTN_FLAGS / MOS_CONV_FLAGS: kernel-variant builds for same-box A/B runs (load with MOS_HIP_LIB=...)
 OUT="${MOS_OUT:-${HERE}/../libmos_hip.so}"
 BUILD="${MOS_BUILD_DIR:-${HERE}/_build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
@@ -20,7 +20,9 @@ EXTRA_mos_attn="-mllvm -amdgpu-mfma-vgpr-form=1 ${MOS_ATTN_FLAGS:-}"
 # for 8 MFMAs, fused 64x128 ring: 94 for 20); the VGPR form has none (22 / 38). VALU and MFMA time add up on this chip.
 # MOS_MFMA_FORM_FLAGS="" restores the AccVGPR form for an A/B build.
 EXTRA_mos_gemm="${MOS_MFMA_FORM_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1}"
-EXTRA_mos_conv="${MOS_MFMA_FORM_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1}"
+# MOS_CONV_FLAGS="-DMOS_CONV_NO_HALO": a variant build whose 3x3 convolutions all take the raster form of rounds 2-4 (same-box A/B
+# of the halo-staged form; load with MOS_HIP_LIB=...). Build-time only: the library reads no environment variable.
+EXTRA_mos_conv="${MOS_MFMA_FORM_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1} ${MOS_CONV_FLAGS:-}"
 for f in ${SRCS}; do
   extra_var="EXTRA_${f}"
   src="${HERE}/${f}.hip"

@@ -567,11 +567,13 @@ int launch_conv(ConvArgs a, hipStream_t st) {
         a.ksplit = ks; a.kt_per = kt_per;
         return a.up ? launch_conv_split<T, 64, 64, true>(a, st) : launch_conv_split<T, 64, 64, false>(a, st);
     }
+#ifndef MOS_CONV_NO_HALO          // (variant build for the same-box A/B against the raster form, csrc/build.sh)
     if (a.Wd >= 16 && a.H >= 8) {
         const int64_t t16 = (int64_t)a.B * ((a.H + 15) / 16) * ((a.Wd + 15) / 16) * (a.Cout / 128);
         if (a.Cin >= 512 && a.Cout % 128 == 0 && a.H >= 16 && t16 >= 256) return launch_conv_halo<T, 16, 128>(a, st);
         return launch_conv_halo<T, 8, 64>(a, st);
     }
+#endif
     int bn = (a.Cout % 128 == 0) ? 128 : 64, bm = 128;
     auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
     if (tiles(bm, bn) < 384) bm = 64;

@@ -344,10 +344,20 @@ def _hot_path_error(name, setup, regional, residuals_fn=None, steps=50, peak_log
                    **_abs_figures(rec_free[-1:], rec_exact[-1:], 'free_running_final_hip_vs_exact'))
     assert xmax <= 8.0, f'{name}: calibrated synthetic latents should stay O(1), got {xmax}'
     if peak_logits is not None:
-        # yardstick = the reference's own fp16 attention arithmetic on the same peaked scores (see the docstring)
+        # yardstick = the reference's own fp16 attention arithmetic on the same peaked scores (see the docstring); the peaked
+        # sampler is less contractive, so the FREE-running error is read against the reference arithmetic run freely too
+        # (first run of round 5: HIP 1.74e-3 after 12 free steps against 4.7e-4 per teacher-forced step)
+        _install_oracle(pipe, regional)
+        _install_cast(pipe.unet, torch.float16)
+        rec_free16 = _denoise_loop(pipe, emb, latents, cak=cak, residuals=res, steps=steps, max_steps=max_steps)
+        _restore_hip(pipe, hip_procs)
+        _, fl16 = _latent_rms(rec_free16, rec_exact)
+        print(f'[parity] {name}: free-running final-latent RMS error, HIP {fl:.3e} / reference fp16 arithmetic {fl16:.3e}')
+        _record_parity(name + ' | free-running yardstick', latent_rms_free_running_final_hip_vs_exact=fl,
+                       latent_rms_free_running_final_ref_fp16_vs_exact=fl16)
         assert he <= 1.25 * re_ + 1e-4, f'{name}: epsilon {he:.3e} vs reference fp16 arithmetic {re_:.3e} (both against exact)'
         assert hw <= 1.25 * rw + 1e-4 and hx <= 1.25 * rx + 1e-4, f'{name}: latent {hw:.3e} / {hx:.3e} vs {rw:.3e} / {rx:.3e}'
-        assert fl <= max(TOL, 2.0 * rw), f'{name}: free-running final-latent RMS error {fl:.3e}'
+        assert fl <= max(TOL, 1.5 * fl16 + 1e-4), f'{name}: free-running final-latent RMS error {fl:.3e} (reference arithmetic {fl16:.3e})'
         return
     # epsilon = what the hot path produces: north_star's 1e-3, every step -- against exact attention AND against the
     # reference's own fp16 attention arithmetic
@@ -526,7 +536,9 @@ def test_reference_style_attention_store_gets_full_maps_on_the_hip_path():
             n += 1
     de = max(_absmax(a - b) / max(1.0, _absmax(b)) for a, b in zip(eps_hip, eps_ref))
     print(f'[parity] full-map controller on the HIP path: {n} stored maps, worst |dP| = {worst:.3e}; epsilon vs exact {de:.3e}')
-    assert n == 16 and worst <= 1e-3 and de <= TOL
+    # probabilities in [0, 1] stored in half (ulp 4.9e-4 at the top) from half q / k projections, averaged in half, against the
+    # exact fp32 maps: 1.3e-3 measured; epsilon (4e-5) is what continues from the returned map
+    assert n == 16 and worst <= 3e-3 and de <= TOL
 
 
 def test_edlora_sd15_fp16_pipeline_inside_reference_band():
@@ -912,8 +924,9 @@ def test_update_quasi_newton_vs_reference_golden(golden):
         print(f'[parity] lbfgs[{name}]: loss0={l_0:.4e} ref={l_ref:.6e} hip={l_got:.6e} rel_dW_err={rel_w:.3e}')
         # same optimiser on the same objective: the loss reached must match the reference's, and the update
         # direction W - W0 must agree (fp32-vs-fp64 line-search noise only)
+        # (measured rounds 3-5: rel_dW_err <= 2.5e-5 on all four problems)
         assert l_got <= l_ref * (1 + 2e-2) + 1e-12
-        assert rel_w < 5e-2
+        assert rel_w < 1e-3
 
 
 def test_gradient_fusion_end_to_end(tmp_path):
@@ -956,18 +969,27 @@ def test_fusion_feature_collection_and_fused_weights_vs_oracle_gpu(tmp_path, mon
     fusion_parity_report(res, 2e-3, solve_layers=2)
 
 
-def test_fusion_one_sd15_level0_layer_over_14_concepts_vs_oracle(tmp_path, monkeypatch):
-    """configs[3] at ITS scale (reference gradient_fusion.py:627-747): ONE level-0 spatial layer of the SD-1.5
-    UNet (320 -> 320, the output projection of the last self-attention: its input is what the HIP attention kernel wrote)
-    accumulated over 14 synthetic concepts x 20 recorded DPM-Solver steps x 4096 tokens = 1,146,880 rows. The product
-    streams them into fp64 Gram statistics through the feature tap of the fused projection; the oracle runs the reference
-    procedure (forward hook on the nn.Linear, features stored on the host, oracle processors) on the same model and seeds.
-    Compared: n, G = X^T X, P = Y^T X, c = sum Y^2."""
+def test_fusion_three_sd15_layers_over_14_concepts_vs_oracle(tmp_path, monkeypatch):
+    """configs[3] at ITS scale (reference gradient_fusion.py:627-747): THREE spatial layers of the
+    SD-1.5 UNet -- self-attention output projections (their input is what the HIP attention kernel wrote) at level 0
+    (320 -> 320, the last block), level 1 (640 -> 640) and level 2 (1280 -> 1280) -- accumulated
+    over 14 synthetic concepts x 20 recorded DPM-Solver steps x 4096 / 1024 / 256 tokens = 1,146,880 / 286,720 / 71,680 rows.
+    The product streams them into fp64 Gram statistics through the feature taps of the fused projections; the oracle runs the
+    reference procedure (forward hooks on the nn.Linear modules, features STORED, oracle processors) on the same model and seeds.
+    Compared per layer: n, G = X^T X, P = Y^T X, c = sum Y^2, and the FUSED WEIGHT -- the product's Gram-form fp64 L-BFGS on its
+    streamed statistics against the reference's own solver (torch.optim.LBFGS on the chunked fp32 closure over the stored
+    features, update_quasi_newton :38-96), 50 iterations as fuse.sh sets for the UNet."""
     import gradient_fusion as gf
     from bench import synthetic_edlora_checkpoints
+    from mixofshow.utils.lsq import lbfgs_on_gram
     from oracle import edlora_ref as R
     from oracle import fusion_ref as FR
-    layer = 'up_blocks.3.attentions.2.transformer_blocks.0.attn1.to_out.0'
+    # (one projection KIND: the reference hooks every module of the kinds that occur in the LoRA keys, :640-660, and the oracle
+    #  stores their features on the host -- 16 modules for one kind, as in round 4)
+    layers = ['up_blocks.3.attentions.2.transformer_blocks.0.attn1.to_out.0',
+              'down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_out.0',
+              'down_blocks.2.attentions.1.transformer_blocks.0.attn1.to_out.0']
+    rows = {layers[0]: 4096, layers[1]: 1024, layers[2]: 256}
     n_concepts = 14
     cfg = synthetic_edlora_checkpoints('sd15', n_concepts, str(tmp_path))
     pipe, _, sched = gf.init_stable_diffusion('synthetic://sd15?seed=0', DEV)
@@ -975,41 +997,55 @@ def test_fusion_one_sd15_level0_layer_over_14_concepts_vs_oracle(tmp_path, monke
         p.requires_grad = False
     emb, te, kv, sp, concepts = gf.parse_new_concepts(cfg)
     _, ncfg = gf.merge_new_concepts_(emb, concepts, pipe.tokenizer, pipe.text_encoder)
-    sp = [{k: v for k, v in d.items() if k.startswith(layer + '.lora_')} for d in sp]
-    assert all(len(d) == 2 for d in sp)
+    sp = [{k: v for k, v in d.items() if any(k.startswith(l + '.lora_') for l in layers)} for d in sp]
+    assert all(len(d) == 2 * len(layers) for d in sp)
     captured = {}
     monkeypatch.setattr(gf, '_solve_layers', lambda accs, sd, iters, tag: captured.setdefault(tag, accs) and {})
     u0 = {k: v.detach().clone() for k, v in pipe.unet.state_dict().items()}
     torch.manual_seed(77)                     # decode_to_latents draws from the global CPU generator (reference :601)
     gf.merge_spatial_attention(concepts, 1, ncfg, pipe.tokenizer, pipe.text_encoder, pipe.unet, sp, sched, DEV)
-    acc = captured['spatial'][layer + '.weight']
+    accs = captured['spatial']
     assert all(torch.equal(v, u0[k]) for k, v in pipe.unet.state_dict().items()), 'original weights not restored'
     # the reference procedure on the same modules: every projection a real nn.Linear call, features kept on the host
     for m in pipe.unet.modules():
         if m.__class__.__name__ == 'Attention':
             m.set_processor(R.PlainAttnProcessorRef())
     torch.manual_seed(77)
-    X, Y, _ = FR.merge_spatial_attention_ref(concepts, 1, ncfg, pipe.tokenizer, pipe.text_encoder, pipe.unet, sp, sched, DEV,
-                                             R.bind_concept_prompt_ref, return_features=True)
-    X, Y = X[layer + '.weight'], Y[layer + '.weight']
-    n = n_concepts * 20 * 4096
-    assert acc.n == n == X.shape[0] == 1146880 and X.shape[1] == Y.shape[1] == 320
-    G = torch.zeros(320, 320, dtype=torch.float64, device=DEV)
-    P = torch.zeros(320, 320, dtype=torch.float64, device=DEV)
-    c = torch.zeros((), dtype=torch.float64, device=DEV)
-    for s0 in range(0, n, 131072):
-        x, y = X[s0:s0 + 131072].to(DEV).double(), Y[s0:s0 + 131072].to(DEV).double()
-        G += x.T @ x
-        P += y.T @ x
-        c += (y * y).sum()
-    eg = ((acc.G - G).norm() / G.norm()).item()
-    ep = ((acc.P - P).norm() / P.norm()).item()
-    ec = abs(acc.c.item() - c.item()) / c.item()
-    print(f'[parity] fusion sd15 level-0 layer {layer}, {n_concepts} concepts, n = {n}: Gram statistics of the streamed HIP '
-          f'features vs the reference procedure (stored features, oracle attention): rel err G {eg:.3e} P {ep:.3e} c {ec:.3e}')
-    # both paths sample 20 free-running fp16 steps per concept; they differ by the half-precision rounding of every attention
-    # layer upstream (HIP flash kernel vs baddbmm/softmax/bmm in fp16)
-    assert max(eg, ep, ec) <= 5e-3
+    Xs, Ys, _ = FR.merge_spatial_attention_ref(concepts, 1, ncfg, pipe.tokenizer, pipe.text_encoder, pipe.unet, sp, sched, DEV,
+                                               R.bind_concept_prompt_ref, return_features=True)
+    for layer in layers:
+        acc = accs[layer + '.weight']
+        X, Y = Xs[layer + '.weight'], Ys[layer + '.weight']
+        n = n_concepts * 20 * rows[layer]
+        C = acc.cin
+        assert acc.n == n == X.shape[0] and X.shape[1] == Y.shape[1] == C == acc.cout
+        G = torch.zeros(C, C, dtype=torch.float64, device=DEV)
+        P = torch.zeros(C, C, dtype=torch.float64, device=DEV)
+        c = torch.zeros((), dtype=torch.float64, device=DEV)
+        for s0 in range(0, n, 131072):
+            x, y = X[s0:s0 + 131072].to(DEV).double(), Y[s0:s0 + 131072].to(DEV).double()
+            G += x.T @ x
+            P += y.T @ x
+            c += (y * y).sum()
+        eg = ((acc.G - G).norm() / G.norm()).item()
+        ep = ((acc.P - P).norm() / P.norm()).item()
+        ec = abs(acc.c.item() - c.item()) / c.item()
+        # the fused weight: product solver on its streamed statistics vs the reference solver on the stored features
+        W0 = u0[layer + '.weight'].float()
+        W_hip, loss_hip = lbfgs_on_gram(W0.cpu(), acc, 50)
+        W_ref = FR.update_quasi_newton_ref(X.to(DEV).float(), Y.to(DEV).float(), W0.to(DEV), 50).cpu()
+        upd = (W_ref - W0.cpu()).norm().item()
+        ew = ((W_hip.cpu() - W_ref).norm() / max(upd, 1e-30)).item()
+        l_ref = FR.lsq_loss_ref(X[:131072].to(DEV).float(), Y[:131072].to(DEV).float(), W_ref.to(DEV)).item()
+        l_hip = FR.lsq_loss_ref(X[:131072].to(DEV).float(), Y[:131072].to(DEV).float(), W_hip.to(DEV).float()).item()
+        print(f'[parity] fusion sd15 {layer} ({C} -> {C}), {n_concepts} concepts, n = {n}: streamed HIP Gram statistics vs the '
+              f'reference procedure: rel err G {eg:.3e} P {ep:.3e} c {ec:.3e}; FUSED WEIGHT |W_hip - W_ref| / |W_ref - W0| = '
+              f'{ew:.3e} (|W_ref - W0| = {upd:.3e}); loss on the first 131072 stored rows: reference {l_ref:.6e}, HIP {l_hip:.6e}')
+        # both paths sample 20 free-running fp16 steps per concept; they differ by the half-precision rounding of every attention
+        # layer upstream (HIP flash kernel vs baddbmm/softmax/bmm in fp16)
+        assert max(eg, ep, ec) <= 5e-3
+        assert ew <= 2e-2 and l_hip <= l_ref * (1 + 1e-2) + 1e-12
+        del X, Y
 
 
 def test_fusion_reduces_layer_loss_on_real_features():
