@@ -571,6 +571,12 @@ int launch_conv(ConvArgs a, hipStream_t st) {
     if (a.Wd >= 16 && a.H >= 8) {
         const int64_t t16 = (int64_t)a.B * ((a.H + 15) / 16) * ((a.Wd + 15) / 16) * (a.Cout / 128);
         if (a.Cin >= 512 && a.Cout % 128 == 0 && a.H >= 16 && t16 >= 256) return launch_conv_halo<T, 16, 128>(a, st);
+#ifdef MOS_CONV_HALO_WIDE         // (experiment of round 5, variant build: 8 x 16 pixels x 160 outputs, one workgroup per CU)
+        if (a.Cout % 160 == 0) {
+            const int64_t tw = (int64_t)a.B * ((a.H + 7) / 8) * ((a.Wd + 15) / 16) * (a.Cout / 160);
+            if (tw >= MOS_CONV_HALO_WIDE) return launch_conv_halo<T, 8, 160>(a, st);
+        }
+#endif
         return launch_conv_halo<T, 8, 64>(a, st);
     }
 #endif
