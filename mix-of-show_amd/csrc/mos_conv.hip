@@ -552,7 +552,11 @@ constexpr int RING_MAX_WG = 640;
 //     B4 320->320 64x64 46/48 -> 38/40, 960->320 133/129 -> 109/104, 640->640 32x32 55/58 -> 43/43, 1920->640 162/101 -> 123/104,
 //     128->128 512x512 416/425 -> 388/354, B2 640->640 32x48 42/46 -> 32/32; the 16 x 16 x 128 tile only where >= 512 input channels
 //     meet >= 256 such tiles (the VAE's 512-channel stages: 324/305 -> 295/281 at 128x128, 82/86 -> 74/77 at 64x64);
-//     8 x 16 x 128 and 16 x 16 x 64 tiles, and 256-row tiles of the raster form, lost everywhere and are gone;
+//     8 x 16 x 128 and 16 x 16 x 64 tiles, and 256-row tiles of the raster form, lost everywhere and are gone; so did an
+//     8 x 16 x 160 tile (one round of 256 workgroups at level 0 instead of 640 on 512 slots: 41.0 vs 39.3 us, one wave per SIMD
+//     leaves the fragment reads exposed; profiles/r05c3_kernel_bench_conv_forms.txt);
+//     same-box whole step, raster form -> this dispatch: 36.5 -> 35.3 ms (109.6 -> 113.3 images/s), conv3x3 11.0 -> 9.9 ms / step,
+//     regional sample (latent out) 406.2 -> 386 ms, conv3x3 134.5 -> 112.6 ms / sample (profiles/r05c3_ab_same_box_conv_forms.txt);
 //   * what is left (maps narrower than 16 pixels that are not split): raster form.
 template <typename T>
 int launch_conv(ConvArgs a, hipStream_t st) {
@@ -571,12 +575,6 @@ int launch_conv(ConvArgs a, hipStream_t st) {
     if (a.Wd >= 16 && a.H >= 8) {
         const int64_t t16 = (int64_t)a.B * ((a.H + 15) / 16) * ((a.Wd + 15) / 16) * (a.Cout / 128);
         if (a.Cin >= 512 && a.Cout % 128 == 0 && a.H >= 16 && t16 >= 256) return launch_conv_halo<T, 16, 128>(a, st);
-#ifdef MOS_CONV_HALO_WIDE         // (experiment of round 5, variant build: 8 x 16 pixels x 160 outputs, one workgroup per CU)
-        if (a.Cout % 160 == 0) {
-            const int64_t tw = (int64_t)a.B * ((a.H + 7) / 8) * ((a.Wd + 15) / 16) * (a.Cout / 160);
-            if (tw >= MOS_CONV_HALO_WIDE) return launch_conv_halo<T, 8, 160>(a, st);
-        }
-#endif
         return launch_conv_halo<T, 8, 64>(a, st);
     }
 #endif

@@ -978,7 +978,8 @@ def test_fusion_three_sd15_layers_over_14_concepts_vs_oracle(tmp_path, monkeypat
     reference procedure (forward hooks on the nn.Linear modules, features STORED, oracle processors) on the same model and seeds.
     Compared per layer: n, G = X^T X, P = Y^T X, c = sum Y^2, and the FUSED WEIGHT -- the product's Gram-form fp64 L-BFGS on its
     streamed statistics against the reference's own solver (torch.optim.LBFGS on the chunked fp32 closure over the stored
-    features, update_quasi_newton :38-96), 50 iterations as fuse.sh sets for the UNet."""
+    features, update_quasi_newton :38-96), 50 iterations as fuse.sh sets for the UNet: excess loss over the exact minimum and
+    distance to the exact minimiser, both evaluated with the oracle's fp64 statistics."""
     import gradient_fusion as gf
     from bench import synthetic_edlora_checkpoints
     from mixofshow.utils.lsq import lbfgs_on_gram
@@ -1030,21 +1031,35 @@ def test_fusion_three_sd15_layers_over_14_concepts_vs_oracle(tmp_path, monkeypat
         eg = ((acc.G - G).norm() / G.norm()).item()
         ep = ((acc.P - P).norm() / P.norm()).item()
         ec = abs(acc.c.item() - c.item()) / c.item()
-        # the fused weight: product solver on its streamed statistics vs the reference solver on the stored features
+        # the fused weight: product solver on its streamed statistics vs the reference solver on the stored features. 50 L-BFGS
+        # iterations do not converge a 320 x 320 .. 1280 x 1280 problem, and the two closures differ in arithmetic (fp64 Gram form
+        # vs chunked fp32 mean of squares), so the ITERATES separate (first device run: 0.32 of the update at level 0, with the
+        # HIP iterate at the LOWER loss). What is comparable is how close each gets to the solution: the exact full-data loss
+        # L(W) = (tr(W G W^T) - 2 tr(W P^T) + c) / (n C) from the ORACLE's fp64 statistics, and its minimum L* at W* = P G^-1.
         W0 = u0[layer + '.weight'].float()
-        W_hip, loss_hip = lbfgs_on_gram(W0.cpu(), acc, 50)
+        W_hip, _ = lbfgs_on_gram(W0.cpu(), acc, 50)
         W_ref = FR.update_quasi_newton_ref(X.to(DEV).float(), Y.to(DEV).float(), W0.to(DEV), 50).cpu()
+
+        def full_loss(W):
+            Wd = W.to(DEV).double()
+            return (((Wd @ G) * Wd).sum() - 2.0 * (Wd * P).sum() + c).item() / (float(n) * C)
+
+        W_star = torch.linalg.solve(G + 1e-10 * G.diagonal().mean() * torch.eye(C, dtype=torch.float64, device=DEV), P.T).T
+        l0, l_ref, l_hip, l_star = full_loss(W0), full_loss(W_ref), full_loss(W_hip), full_loss(W_star)
         upd = (W_ref - W0.cpu()).norm().item()
         ew = ((W_hip.cpu() - W_ref).norm() / max(upd, 1e-30)).item()
-        l_ref = FR.lsq_loss_ref(X[:131072].to(DEV).float(), Y[:131072].to(DEV).float(), W_ref.to(DEV)).item()
-        l_hip = FR.lsq_loss_ref(X[:131072].to(DEV).float(), Y[:131072].to(DEV).float(), W_hip.to(DEV).float()).item()
+        d_ref = (W_ref.double() - W_star.cpu()).norm().item()
+        d_hip = (W_hip.double() - W_star.cpu()).norm().item()
         print(f'[parity] fusion sd15 {layer} ({C} -> {C}), {n_concepts} concepts, n = {n}: streamed HIP Gram statistics vs the '
-              f'reference procedure: rel err G {eg:.3e} P {ep:.3e} c {ec:.3e}; FUSED WEIGHT |W_hip - W_ref| / |W_ref - W0| = '
-              f'{ew:.3e} (|W_ref - W0| = {upd:.3e}); loss on the first 131072 stored rows: reference {l_ref:.6e}, HIP {l_hip:.6e}')
+              f'reference procedure: rel err G {eg:.3e} P {ep:.3e} c {ec:.3e}; FUSED WEIGHT after 50 iterations: full-data loss '
+              f'start {l0:.6e}, reference solver {l_ref:.6e}, HIP {l_hip:.6e}, minimum {l_star:.6e}; distance to the minimiser '
+              f'reference {d_ref:.3e} / HIP {d_hip:.3e}; |W_hip - W_ref| / |W_ref - W0| = {ew:.3e}')
         # both paths sample 20 free-running fp16 steps per concept; they differ by the half-precision rounding of every attention
         # layer upstream (HIP flash kernel vs baddbmm/softmax/bmm in fp16)
         assert max(eg, ep, ec) <= 5e-3
-        assert ew <= 2e-2 and l_hip <= l_ref * (1 + 1e-2) + 1e-12
+        # the HIP iterate is at least as good a solution of the reference's problem as the reference's own iterate
+        assert l_hip - l_star <= (l_ref - l_star) * 1.02 + 1e-3 * (l0 - l_star), (l0, l_ref, l_hip, l_star)
+        assert d_hip <= 1.05 * d_ref + 1e-6
         del X, Y
 
 
