@@ -205,7 +205,7 @@ def gram_case(n, cin, cout, dtype, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas")
+    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,gn,conv1,probs")
     ap.add_argument('--dtype', default='f16')
     ap.add_argument('--legacy', type=int, default=0, help='gemm: also time the round-1 multi-launch LoRA path')
     ap.add_argument('--ref', type=int, default=1, help='0: skip the MIOpen / hipBLASLt reference timings')
@@ -243,6 +243,15 @@ def main():
                         (2, 640, 640, 32, 48), (2, 1920, 640, 32, 48), (2, 2560, 1280, 16, 24), (2, 1280, 1280, 8, 12),
                         (2, 2560, 1280, 8, 12)],
                        dt, args.iters, ref=bool(args.ref))
+    if 'conv1' in only:          # ONE shape (level-0 ResNet conv, forward + backward-data): clean per-launch PMC counters
+        conv_reference([(4, 320, 320, 64, 64)], dt, args.iters, ref=False)
+    if 'probs' in only:
+        for (B, N, d) in ((2, 4096, 40), (2, 1024, 80), (2, 256, 160)):
+            C = 8 * d
+            q = torch.randn(B, N, C, device='cuda', dtype=dt)
+            kv = torch.randn(B, 77, 2 * C, device='cuda', dtype=dt)
+            cases.append(lambda q=q, kv=kv, C=C, d=d: [ops.attn_pv(ops.attn_probs(q, kv[..., :C], 8, d**-0.5), kv[..., C:], 8)
+                                                         for _ in range(args.iters)])
     if 'ff' in only:
         ff_reference([(12288, 320), (3072, 640), (768, 1280), (192, 1280), (16384, 320), (4096, 640), (1024, 1280), (256, 1280)],
                      dt, args.iters)

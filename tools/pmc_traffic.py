@@ -25,7 +25,7 @@ def collect(d, counter):
         for row in csv.DictReader(open(f)):
             if row.get('Counter_Name') != counter:
                 continue
-            m = re.search(r'(attn_fwd_kernel|attn_fwd_pipe_kernel|attn_bwd_dq_kernel|attn_bwd_dkdv_kernel|attn_bwd_dkdv_pipe_kernel|'
+            m = re.search(r'(attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkdv_kernel|attn_bwd_dkdv_pipe_kernel|'
                           r'region_attn_kernel|gemm_lora_kernel|lora_grad_kernel|gram_kernel)I(DF16_|DF16b)Li(\d+)',
                           row.get('Kernel_Name', ''))
             if not m:
