@@ -352,6 +352,21 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     const T* wfrag = Ws + (wn * (BN / 2) + l15) * CBK;
     const int wsw0 = ((lg ^ (l15 & 7)) * 8), wsw1 = wsw0 ^ 32;
 
+#ifdef MOS_CONV_HALO_PREFETCH
+    constexpr bool PF = (TH == 8 && BN == 64);      // (the 16 x 16 x 128 tile has no registers to spare: 512 VGPRs + spills with it)
+#else
+    constexpr bool PF = false;
+#endif
+    [[maybe_unused]] v8 bnext[CBK / 32][MI];
+    [[maybe_unused]] auto load_b = [&](const T* hsb, int toff, v8 (&bf)[CBK / 32][MI]) {
+#pragma unroll
+        for (int kk = 0; kk < CBK / 32; ++kk)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int hr = hbase[i] + toff;
+                bf[kk][i] = as_v8<T>(ld16(hsb + hr * CBK + (((kk * 4 + lg) ^ (hr & 7)) * 8)));
+            }
+    };
     issue_halo(0, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
@@ -369,6 +384,30 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
             }
             const int tapoff = (tap / 3 - 1) * HW18 + (tap % 3 - 1);
             const T* ws = wfrag + (tap % 3) * BN * CBK;
+            if constexpr (PF) {
+            // The activation fragments of a step do not depend on that step's barrier (the halo of a chunk is stable for its
+            // nine taps, and the next chunk's halo is complete and visible from tap 3 on): they are read one step AHEAD, behind
+            // the weight fragments of the current step, so that they land under its MFMAs; after a barrier only the weight
+            // fragments are waited for. All fragment reads of a step precede its MFMAs.
+            v8 bfrag[CBK / 32][MI], afrag[CBK / 32][NJ];
+            if (tap == 0 && cch == 0) load_b(hs, tapoff, bnext);
+#pragma unroll
+            for (int kk = 0; kk < CBK / 32; ++kk)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) bfrag[kk][i] = bnext[kk][i];
+#pragma unroll
+            for (int kk = 0; kk < CBK / 32; ++kk)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) afrag[kk][j] = as_v8<T>(ld16(ws + j * 16 * CBK + (kk ? wsw1 : wsw0)));
+            if (tap < 8) load_b(hs, ((tap + 1) / 3 - 1) * HW18 + ((tap + 1) % 3 - 1), bnext);
+            else load_b(Hs + ((cch + 1) & 1) * HB, -HW18 - 1, bnext);
+#pragma unroll
+            for (int kk = 0; kk < CBK / 32; ++kk)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16(afrag[kk][j], bfrag[kk][i], acc[j][i]);
+            } else {
 #pragma unroll
             for (int kk = 0; kk < CBK / 32; ++kk) {
                 v8 bfrag[MI], afrag[NJ];
@@ -384,6 +423,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16(afrag[j], bfrag[i], acc[j][i]);
+            }
             }
         }
     }
