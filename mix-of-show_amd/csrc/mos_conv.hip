@@ -352,21 +352,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     const T* wfrag = Ws + (wn * (BN / 2) + l15) * CBK;
     const int wsw0 = ((lg ^ (l15 & 7)) * 8), wsw1 = wsw0 ^ 32;
 
-#ifdef MOS_CONV_HALO_PREFETCH
-    constexpr bool PF = (TH == 8 && BN == 64);      // (the 16 x 16 x 128 tile has no registers to spare: 512 VGPRs + spills with it)
-#else
-    constexpr bool PF = false;
-#endif
-    [[maybe_unused]] v8 bnext[CBK / 32][MI];
-    [[maybe_unused]] auto load_b = [&](const T* hsb, int toff, v8 (&bf)[CBK / 32][MI]) {
-#pragma unroll
-        for (int kk = 0; kk < CBK / 32; ++kk)
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int hr = hbase[i] + toff;
-                bf[kk][i] = as_v8<T>(ld16(hsb + hr * CBK + (((kk * 4 + lg) ^ (hr & 7)) * 8)));
-            }
-    };
     issue_halo(0, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
@@ -384,30 +369,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
             }
             const int tapoff = (tap / 3 - 1) * HW18 + (tap % 3 - 1);
             const T* ws = wfrag + (tap % 3) * BN * CBK;
-            if constexpr (PF) {
-            // The activation fragments of a step do not depend on that step's barrier (the halo of a chunk is stable for its
-            // nine taps, and the next chunk's halo is complete and visible from tap 3 on): they are read one step AHEAD, behind
-            // the weight fragments of the current step, so that they land under its MFMAs; after a barrier only the weight
-            // fragments are waited for. All fragment reads of a step precede its MFMAs.
-            v8 bfrag[CBK / 32][MI], afrag[CBK / 32][NJ];
-            if (tap == 0 && cch == 0) load_b(hs, tapoff, bnext);
-#pragma unroll
-            for (int kk = 0; kk < CBK / 32; ++kk)
-#pragma unroll
-                for (int i = 0; i < MI; ++i) bfrag[kk][i] = bnext[kk][i];
-#pragma unroll
-            for (int kk = 0; kk < CBK / 32; ++kk)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) afrag[kk][j] = as_v8<T>(ld16(ws + j * 16 * CBK + (kk ? wsw1 : wsw0)));
-            if (tap < 8) load_b(hs, ((tap + 1) / 3 - 1) * HW18 + ((tap + 1) % 3 - 1), bnext);
-            else load_b(Hs + ((cch + 1) & 1) * HB, -HW18 - 1, bnext);
-#pragma unroll
-            for (int kk = 0; kk < CBK / 32; ++kk)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16(afrag[kk][j], bfrag[kk][i], acc[j][i]);
-            } else {
 #pragma unroll
             for (int kk = 0; kk < CBK / 32; ++kk) {
                 v8 bfrag[MI], afrag[NJ];
@@ -423,7 +384,6 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int i = 0; i < MI; ++i) acc[j][i] = MT<T>::mfma16(afrag[j], bfrag[i], acc[j][i]);
-            }
             }
         }
     }
@@ -594,7 +554,9 @@ constexpr int RING_MAX_WG = 640;
 //     meet >= 256 such tiles (the VAE's 512-channel stages: 324/305 -> 295/281 at 128x128, 82/86 -> 74/77 at 64x64);
 //     8 x 16 x 128 and 16 x 16 x 64 tiles, and 256-row tiles of the raster form, lost everywhere and are gone; so did an
 //     8 x 16 x 160 tile (one round of 256 workgroups at level 0 instead of 640 on 512 slots: 41.0 vs 39.3 us, one wave per SIMD
-//     leaves the fragment reads exposed; profiles/r05c3_kernel_bench_conv_forms.txt);
+//     leaves the fragment reads exposed; profiles/r05c3_kernel_bench_conv_forms.txt), and so did reading the activation
+//     fragments one step ahead (they do not depend on a step's barrier: neutral, 9.93 vs 9.94 ms of conv3x3 per step, same box,
+//     profiles/r05c4_ab_same_box_conv_prefetch.txt) -- neither fragment latency nor tile width is what bounds this kernel;
 //     same-box whole step, raster form -> this dispatch: 36.5 -> 35.3 ms (109.6 -> 113.3 images/s), conv3x3 11.0 -> 9.9 ms / step,
 //     regional sample (latent out) 406.2 -> 386 ms, conv3x3 134.5 -> 112.6 ms / sample (profiles/r05c3_ab_same_box_conv_forms.txt);
 //   * what is left (maps narrower than 16 pixels that are not split): raster form.

@@ -454,11 +454,11 @@ def test_regional_sd15_hot_path_error_teacher_forced():
 def test_regional_sd15_shipped_example_1024x2048_teacher_forced():
     """VERDICT r04 missing #3: the reference's own shipped regional example (regionally_sample.sh:52-90: 1024 x 2048, the three
     boxes unscaled, seed 14) -- latent 128 x 256, N = 32768 queries AND self-attention keys at level 0, 8192 / 2048 / 512 below:
-    grid limits, 32-bit offsets and the region kernel's box table at 5.3x the largest size of the other tests. First 6 steps of
+    grid limits, 32-bit offsets and the region kernel's box table at 5.3x the largest size of the other tests. First 5 steps of
     the 50-step schedule, teacher-forced, fp32 pipeline (attention layers only in half), HIP vs exact attention (the oracle's
     probability tensors are built in (batch x head) slices: 69 GB otherwise) and vs the reference's fp16 arithmetic."""
     _hot_path_error('regional sd15 1024x2048 (regionally_sample.sh)', lambda dt: _regional_setup('sd15', dt, 1024, 2048), True,
-                    max_steps=6)
+                    max_steps=5)
 
 
 def test_regional_sd15_with_adapter_states_hot_path_error_teacher_forced():
