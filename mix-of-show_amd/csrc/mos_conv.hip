@@ -554,9 +554,7 @@ constexpr int RING_MAX_WG = 640;
 //     meet >= 256 such tiles (the VAE's 512-channel stages: 324/305 -> 295/281 at 128x128, 82/86 -> 74/77 at 64x64);
 //     8 x 16 x 128 and 16 x 16 x 64 tiles, and 256-row tiles of the raster form, lost everywhere and are gone; so did an
 //     8 x 16 x 160 tile (one round of 256 workgroups at level 0 instead of 640 on 512 slots: 41.0 vs 39.3 us, one wave per SIMD
-//     leaves the fragment reads exposed; profiles/r05c3_kernel_bench_conv_forms.txt), and so did reading the activation
-//     fragments one step ahead (they do not depend on a step's barrier: neutral, 9.93 vs 9.94 ms of conv3x3 per step, same box,
-//     profiles/r05c4_ab_same_box_conv_prefetch.txt) -- neither fragment latency nor tile width is what bounds this kernel;
+//     leaves the fragment reads exposed; profiles/r05c3_kernel_bench_conv_forms.txt);
 //     same-box whole step, raster form -> this dispatch: 36.5 -> 35.3 ms (109.6 -> 113.3 images/s), conv3x3 11.0 -> 9.9 ms / step,
 //     regional sample (latent out) 406.2 -> 386 ms, conv3x3 134.5 -> 112.6 ms / sample (profiles/r05c3_ab_same_box_conv_forms.txt);
 //   * what is left (maps narrower than 16 pixels that are not split): raster form.
