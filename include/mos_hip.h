@@ -182,6 +182,32 @@ int mos_lora_linear_fused_bwd_deferred(const void* dy, int64_t lddy, const void*
                                        mos_lora_final_rec* rec_host);
 int mos_lora_grad_final_all(const mos_lora_final_rec* recs_dev, int n_recs, int total_blocks, void* stream);
 
+/* Round 5: the token reductions themselves batched. `_deferred_all` launches only the dx (+dt) GEMM and describes the group's
+ * token reduction in `job_host` (pointers to dt / x / t / dy, which the caller keeps alive) and its final sum in `rec_host`;
+ * mos_lora_grad_all then runs the reductions of EVERY group of one padded-rank class `nj` (4 / 8 / 12 / 16) of a backward pass in
+ * ONE launch from a table in device memory (`block_begin` = running sum of `n_blocks` within the table, filled by the caller),
+ * followed by mos_lora_grad_final_all. Per group the arithmetic
+ * and its order are those of the per-group launch: bit-identical gradients. `flops` / `bytes`: sums of the jobs' figures (profiler). */
+typedef struct {
+    const void* P[2];         /* dt, t   [M,16] */
+    const void* Z[2];         /* x [M,K], dy [M,N] */
+    int64_t ldz[2];
+    int C[2], cb[2];          /* K, N ; 64-column blocks of each */
+    float* partial[2];        /* [nchunk][nj][C] fp32 partial sums inside the group's workspace */
+    int M, rpc, nchunk, nj;
+    int block_begin, n_blocks;
+    double flops, bytes;
+} mos_lora_grad_job;
+int mos_lora_linear_fused_bwd_deferred_all(const void* dy, int64_t lddy, const void* x, int64_t ldx,
+                                           const void* Wt, int64_t ldwt, const void* t,
+                                           const void* A16T, const void* BpT,
+                                           void* dt, void* dx, int64_t lddx,
+                                           const mos_lora_grad_out* grads_host, void* ws,
+                                           int M, int N, int K, int lora_cols, int dtype, void* stream,
+                                           mos_lora_final_rec* rec_host, mos_lora_grad_job* job_host);
+int mos_lora_grad_all(const mos_lora_grad_job* jobs_dev, int n_jobs, int total_blocks, int nj, int dtype, double flops, double bytes,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused attention core: softmax(scale * Q K^T) V with online softmax, no materialised P.
  * Replaces attn.get_attention_scores + torch.bmm / xformers.memory_efficient_attention in

@@ -571,21 +571,22 @@ struct LoraGradArgs {
     mos_lora_grad_out out;
 };
 
-template <typename T, int NJ>
-__global__ __launch_bounds__(256) void lora_grad_kernel(const LoraGradArgs a) {
+// one block of the token reduction: chunk bx of the tokens, column block by (of job 0, then of job 1); `J` is LoraGradArgs or a
+// mos_lora_grad_job (same field names). Shared by the per-group launch and the all-groups launch: identical arithmetic.
+template <typename T, int NJ, typename J>
+__device__ __forceinline__ void lora_grad_block(const J& a, int bx, int by, float (&red)[4][NJ][64]) {
     typedef typename MT<T>::v8 v8;
     typedef typename MT<T>::v4 v4;
-    __shared__ float red[4][NJ][64];
     const int tid = threadIdx.x;
-    const int job = (int)blockIdx.y >= a.cb[0] ? 1 : 0;
-    const int colblk = (int)blockIdx.y - (job ? a.cb[0] : 0);
+    const int job = by >= a.cb[0] ? 1 : 0;
+    const int colblk = by - (job ? a.cb[0] : 0);
     const int C = a.C[job];
     const T* P = reinterpret_cast<const T*>(a.P[job]);
     const T* Z = reinterpret_cast<const T*>(a.Z[job]);
     const int64_t ldz = a.ldz[job];
     const int cg = tid & 7, ry = tid >> 3;
     const int c0 = colblk * 64 + cg * 8;
-    const int mb = blockIdx.x * a.rpc;
+    const int mb = bx * a.rpc;
     const int me = min(mb + a.rpc, a.M);
     float acc[NJ][8];
 #pragma unroll
@@ -648,8 +649,32 @@ __global__ __launch_bounds__(256) void lora_grad_kernel(const LoraGradArgs a) {
     for (int idx = tid; idx < NJ * 64; idx += 256) {
         const int j = idx >> 6, c = idx & 63;
         const int col = colblk * 64 + c;
-        if (col < C) part[((int64_t)blockIdx.x * NJ + j) * C + col] = red[0][j][c] + red[1][j][c] + red[2][j][c] + red[3][j][c];
+        if (col < C) part[((int64_t)bx * NJ + j) * C + col] = red[0][j][c] + red[1][j][c] + red[2][j][c] + red[3][j][c];
     }
+}
+
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void lora_grad_kernel(const LoraGradArgs a) {
+    __shared__ float red[4][NJ][64];
+    lora_grad_block<T, NJ>(a, (int)blockIdx.x, (int)blockIdx.y, red);
+}
+
+// EVERY deferred group of a backward pass in ONE launch (round 5): the per-group launches (~100 per SD-1.5 step, 7-25 us each:
+// small grids on their latency floor, 0.85-1.8 TB/s) become one streaming pass over all x / dy of the step. Block -> job by binary
+// search over the block offsets of the table (device memory); inside a job the blocks are numbered chunk-fastest. One launch per
+// padded-rank class NJ (4 / 8 / 12 / 16: a merged kernel would run every class at the 264 registers of NJ = 16, one wave per SIMD).
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void lora_grad_all_kernel(const mos_lora_grad_job* __restrict__ jobs, int n_jobs) {
+    __shared__ float red[4][NJ][64];
+    const int bid = (int)blockIdx.x;
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].block_begin <= bid) lo = mid; else hi = mid - 1;
+    }
+    const mos_lora_grad_job j = jobs[lo];
+    const int local = bid - j.block_begin;
+    lora_grad_block<T, NJ>(j, local % j.nchunk, local / j.nchunk, red);
 }
 
 // Final, ORDERED sum over token chunks (deterministic) of both jobs, written as raw 16 x C matrices (legacy API) or straight
@@ -782,7 +807,7 @@ inline void lora_grad_plan(int M, int N, int K, int* rpc, int* nchunk) {
 template <typename T>
 int launch_lora_grad(const void* dt, const void* x, int64_t ldx, const void* t, const void* dy, int64_t lddy, float* rawA,
                      float* rawB, const mos_lora_grad_out* out, float* ws, int M, int N, int K, int cols,
-                     hipStream_t st, mos_lora_final_rec* defer = nullptr) {
+                     hipStream_t st, mos_lora_final_rec* defer = nullptr, mos_lora_grad_job* job = nullptr) {
     LoraGradArgs a;
     a.P[0] = dt; a.Z[0] = x; a.ldz[0] = ldx; a.C[0] = K; a.cb[0] = (K + 63) / 64;
     a.P[1] = t; a.Z[1] = dy; a.ldz[1] = lddy; a.C[1] = N; a.cb[1] = (N + 63) / 64;
@@ -795,6 +820,19 @@ int launch_lora_grad(const void* dt, const void* x, int64_t ldx, const void* t, 
     if (out != nullptr) a.out = *out; else { mos_lora_grad_out z = {}; z.rank = 1; a.out = z; }
     char key[64];
     snprintf(key, sizeof(key), "M%d K%d N%d r%d", M, K, N, nj);
+    if (defer != nullptr && job != nullptr) {    // final sums AND token reduction batched by the caller: nothing is launched here
+        for (int q = 0; q < 2; ++q) { job->P[q] = a.P[q]; job->Z[q] = a.Z[q]; job->ldz[q] = a.ldz[q]; job->C[q] = a.C[q];
+                                      job->cb[q] = a.cb[q]; job->partial[q] = a.partial[q]; }
+        job->M = a.M; job->rpc = a.rpc; job->nchunk = a.nchunk; job->nj = nj; job->block_begin = 0;
+        job->n_blocks = a.nchunk * (a.cb[0] + a.cb[1]);
+        job->flops = 2.0 * M * (double)nj * ((double)K + N);
+        job->bytes = 2.0 * ((double)M * ((double)K + N) + 32.0 * M);
+        defer->partial[0] = a.partial[0]; defer->partial[1] = a.partial[1];
+        defer->C[0] = a.C[0]; defer->C[1] = a.C[1]; defer->cb[0] = a.cb[0]; defer->cb[1] = a.cb[1];
+        defer->nchunk = a.nchunk; defer->nj = nj; defer->block_begin = 0; defer->n_blocks = a.cb[0] + a.cb[1];
+        defer->out = a.out;
+        return MOS_OK;
+    }
     MosProfScope prof(st, "lora_grad", key, 2.0 * M * (double)nj * ((double)K + N), 2.0 * ((double)M * ((double)K + N) + 32.0 * M));
     dim3 grid(a.nchunk, a.cb[0] + a.cb[1]);
     dim3 fgrid(a.cb[0] + a.cb[1]);
@@ -1060,7 +1098,7 @@ int mos_lora_linear_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx
 static int fused_bwd_impl(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
                           const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
                           const mos_lora_grad_out* grads_host, void* ws, int M, int N, int K,
-                          int lora_cols, int dtype, void* stream, mos_lora_final_rec* defer) {
+                          int lora_cols, int dtype, void* stream, mos_lora_final_rec* defer, mos_lora_grad_job* job = nullptr) {
     MOS_REQUIRE(dy && x && t && A16T && BpT && dt, "mos_lora_linear_fused_bwd: NULL argument");
     MOS_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 8 == 0 && lddy % 8 == 0 && ldx % 8 == 0,
                 "mos_lora_linear_fused_bwd: M=%d N=%d K=%d lddy=%lld ldx=%lld", M, N, K, (long long)lddy, (long long)ldx);
@@ -1084,8 +1122,8 @@ static int fused_bwd_impl(const void* dy, int64_t lddy, const void* x, int64_t l
     }
     if (rc) return rc;
     if (grads_host == nullptr) return MOS_OK;
-    return h ? launch_lora_grad<f16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st, defer)
-             : launch_lora_grad<bf16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st, defer);
+    return h ? launch_lora_grad<f16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st, defer, job)
+             : launch_lora_grad<bf16_t>(dt, x, ldx, t, dy, lddy, nullptr, nullptr, grads_host, (float*)ws, M, N, K, lora_cols, st, defer, job);
 }
 
 int mos_lora_linear_fused_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
@@ -1103,6 +1141,33 @@ int mos_lora_linear_fused_bwd_deferred(const void* dy, int64_t lddy, const void*
     MOS_REQUIRE(rec_host && grads_host, "mos_lora_linear_fused_bwd_deferred: needs grads_host and rec_host");
     return fused_bwd_impl(dy, lddy, x, ldx, Wt, ldwt, t, A16T, BpT, dt, dx, lddx, grads_host, ws, M, N, K, lora_cols, dtype,
                           stream, rec_host);
+}
+
+int mos_lora_linear_fused_bwd_deferred_all(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* Wt, int64_t ldwt,
+                                           const void* t, const void* A16T, const void* BpT, void* dt, void* dx, int64_t lddx,
+                                           const mos_lora_grad_out* grads_host, void* ws, int M, int N, int K,
+                                           int lora_cols, int dtype, void* stream, mos_lora_final_rec* rec_host,
+                                           mos_lora_grad_job* job_host) {
+    MOS_REQUIRE(rec_host && grads_host && job_host, "mos_lora_linear_fused_bwd_deferred_all: needs grads_host, rec_host and job_host");
+    return fused_bwd_impl(dy, lddy, x, ldx, Wt, ldwt, t, A16T, BpT, dt, dx, lddx, grads_host, ws, M, N, K, lora_cols, dtype,
+                          stream, rec_host, job_host);
+}
+
+int mos_lora_grad_all(const mos_lora_grad_job* jobs_dev, int n_jobs, int total_blocks, int nj, int dtype, double flops, double bytes,
+                      void* stream) {
+    MOS_REQUIRE(jobs_dev && n_jobs > 0 && total_blocks > 0, "mos_lora_grad_all: n_jobs=%d total_blocks=%d", n_jobs, total_blocks);
+    MOS_REQUIRE(nj == 4 || nj == 8 || nj == 12 || nj == 16, "mos_lora_grad_all: nj=%d (4, 8, 12 or 16: every job of the table has it)", nj);
+    MOS_REQUIRE(dtype == MOS_F16 || dtype == MOS_BF16, "mos_lora_grad_all: dtype %d", dtype);
+    hipStream_t st = (hipStream_t)stream;
+    char key[64];
+    snprintf(key, sizeof(key), "r%d groups%d blocks%d", nj, n_jobs, total_blocks);
+    MosProfScope prof(st, "lora_grad", key, flops, bytes);
+    const dim3 grid(total_blocks), block(256);
+#define LGA(T_, NJ_) hipLaunchKernelGGL((lora_grad_all_kernel<T_, NJ_>), grid, block, 0, st, jobs_dev, n_jobs)
+    if (dtype == MOS_F16) { switch (nj) { case 4: LGA(f16_t, 4); break; case 8: LGA(f16_t, 8); break; case 12: LGA(f16_t, 12); break; default: LGA(f16_t, 16); break; } }
+    else { switch (nj) { case 4: LGA(bf16_t, 4); break; case 8: LGA(bf16_t, 8); break; case 12: LGA(bf16_t, 12); break; default: LGA(bf16_t, 16); break; } }
+#undef LGA
+    return mos_check_launch("lora_grad_all");
 }
 
 int mos_lora_grad_final_all(const mos_lora_final_rec* recs_dev, int n_recs, int total_blocks, void* stream) {

@@ -87,6 +87,12 @@ def set_direct_grad_accumulation(flag):
     _direct_grad = bool(flag)
 
 
+# MOS_LORA_GRAD_BATCH (default 1; host-side switch for same-box A/B runs): the token reductions of the LoRA factor gradients of a
+# backward pass as one launch per padded-rank class (mos_lora_grad_all) instead of one per projection group.
+import os as _os_lgb
+_lora_grad_batch = _os_lgb.environ.get('MOS_LORA_GRAD_BATCH', '1') != '0'
+
+
 class _DeferredFinals:
     """The ordered final sums of the LoRA factor gradients of one backward pass, batched into ONE launch
     (mos_lora_grad_final_all) instead of one per projection group (~90 per SD-1.5 training step). Workspaces are persistent
@@ -103,6 +109,11 @@ class _DeferredFinals:
         self.table_bytes = None
         self.capacity = 512
         self.frozen = False      # set once a captured hipGraph holds this store's table address and workspaces
+        # round 5: the token reductions too (mos_lora_grad_all, one launch per padded-rank class instead of one per group)
+        self.defer_reduction = _lora_grad_batch
+        self.jobs = []           # (LoraGradJob, dtype, keep-alive tensors)
+        self.job_table = None    # uint8 device table
+        self.job_host = None     # pinned host image (the H2D copy of a captured scope is a graph node reading it at every replay)
 
     def freeze(self):
         """A captured graph replays ONE mos_lora_grad_final_all launch with this table's address and the workspace pointers
@@ -112,6 +123,7 @@ class _DeferredFinals:
 
     def begin_scope(self):
         self.pending = []
+        self.jobs = []
         self.used = set()
         if not self.frozen and len(self.ws) > self.MAX_WORKSPACES:
             self.ws.clear()          # (keys hold raw addresses the allocator may recycle: bounded, never while frozen)
@@ -126,9 +138,48 @@ class _DeferredFinals:
             self.ws[key] = t
         return t
 
+    def _flush_jobs(self):
+        """The deferred token reductions: jobs grouped by (dtype, padded rank), ONE table, one launch per class. The table holds
+        the addresses of this pass's activations, so it is rewritten every eager pass; inside a hipGraph capture the upload is a
+        copy node from the pinned host image (the addresses of the capture are those of every replay)."""
+        import ctypes
+        from . import lib as _lib
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        jobs.sort(key=lambda e: (e[1] != torch.float16, e[0].nj))            # stable: program order inside a class
+        size = ctypes.sizeof(_lib.LoraGradJob)
+        assert len(jobs) <= self.capacity, 'too many deferred LoRA gradient groups'
+        classes, i = [], 0
+        while i < len(jobs):
+            k = i
+            begin, fl, by = 0, 0.0, 0.0
+            while k < len(jobs) and jobs[k][1] == jobs[i][1] and jobs[k][0].nj == jobs[i][0].nj:
+                jobs[k][0].block_begin = begin
+                begin += jobs[k][0].n_blocks
+                fl += jobs[k][0].flops
+                by += jobs[k][0].bytes
+                k += 1
+            classes.append((i, k - i, begin, jobs[i][0].nj, jobs[i][1], fl, by))
+            i = k
+        raw = bytes((_lib.LoraGradJob * len(jobs))(*[e[0] for e in jobs]))
+        dev = torch.device('cuda', torch.cuda.current_device())
+        if self.job_table is None or self.job_table.device != dev:
+            self.job_table = torch.zeros(self.capacity * size, dtype=torch.uint8, device=dev)
+            self.job_host = torch.zeros(self.capacity * size, dtype=torch.uint8).pin_memory()
+        if torch.cuda.is_current_stream_capturing():
+            self.job_host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            self.job_table[:len(raw)].copy_(self.job_host[:len(raw)], non_blocking=True)      # a memcpy node of the graph
+        else:
+            self.job_table[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        for first, n, blocks, nj, dtype, fl, by in classes:
+            ops.lora_grad_all(self.job_table, first * size, n, blocks, nj, dtype, fl, by)
+        del jobs                     # (dt / x / t / dy of every group were held until the launches above were enqueued)
+
     def flush(self):
         import ctypes
         from . import lib as _lib
+        self._flush_jobs()
         recs, self.pending = self.pending, []
         if not recs:
             return
@@ -199,6 +250,7 @@ class direct_grad_accumulation:
                 store.flush()
             else:
                 store.pending = []
+                store.jobs = []
         return False
 
 
@@ -448,8 +500,12 @@ class _LoRALinear(torch.autograd.Function):
                 st.used.add(wkey)        # (a layer called twice inside one scope: its second call sums immediately)
                 # every gradient of this group is accumulated in place into an existing `.grad`: its final sum can wait
                 dx, rec = ops.linear_fused_bwd(dy2, x2, Wt16, t, A16T, BpT, targets, ctx.rank, need_dx=need_dx,
-                                               defer=lambda key, n: st.workspace(key, n, dy2.device))
-                if rec is not None:
+                                               defer=lambda key, n: st.workspace(key, n, dy2.device),
+                                               defer_reduction=st.defer_reduction)
+                if isinstance(rec, tuple):           # (final-sum record, token-reduction job, tensors the job points to)
+                    st.pending.append(rec[0])
+                    st.jobs.append((rec[1], dy2.dtype, rec[2]))
+                elif rec is not None:
                     st.pending.append(rec)
             else:
                 dx = ops.linear_fused_bwd(dy2, x2, Wt16, t, A16T, BpT, targets, ctx.rank, need_dx=need_dx)

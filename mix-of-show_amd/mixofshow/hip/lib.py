@@ -69,6 +69,16 @@ class LoraFinalRec(ctypes.Structure):          # mos_lora_final_rec
     ]
 
 
+class LoraGradJob(ctypes.Structure):           # mos_lora_grad_job
+    _fields_ = [
+        ('P', ctypes.c_void_p * 2), ('Z', ctypes.c_void_p * 2), ('ldz', ctypes.c_int64 * 2),
+        ('C', ctypes.c_int * 2), ('cb', ctypes.c_int * 2), ('partial', ctypes.c_void_p * 2),
+        ('M', ctypes.c_int), ('rpc', ctypes.c_int), ('nchunk', ctypes.c_int), ('nj', ctypes.c_int),
+        ('block_begin', ctypes.c_int), ('n_blocks', ctypes.c_int),
+        ('flops', ctypes.c_double), ('bytes', ctypes.c_double),
+    ]
+
+
 class GemmEpilogue(ctypes.Structure):          # mos_gemm_epilogue
     _fields_ = [('residual', ctypes.c_void_p), ('ldr', ctypes.c_int64)]
 
@@ -124,6 +134,10 @@ SIGNATURES = {
     'mos_lora_linear_fused_bwd_deferred': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
                                                 ctypes.POINTER(LoraGradOut), _vp, _i, _i, _i, _i, _i, _vp,
                                                 ctypes.POINTER(LoraFinalRec)]),
+    'mos_lora_linear_fused_bwd_deferred_all': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64,
+                                                ctypes.POINTER(LoraGradOut), _vp, _i, _i, _i, _i, _i, _vp,
+                                                ctypes.POINTER(LoraFinalRec), ctypes.POINTER(LoraGradJob)]),
+    'mos_lora_grad_all': (_i, [_vp, _i, _i, _i, _i, ctypes.c_double, ctypes.c_double, _vp]),
     'mos_lora_grad_final_all': (_i, [_vp, _i, _i, _vp]),
     'mos_lora_down': (_i, [_vp, _i64, _vp, _vp, _i, _i, _i, _vp]),
     'mos_lora_linear_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),

@@ -136,12 +136,14 @@ def linear_fused_fwd(x, W, A16, Bp16, bias=None, need_t=True):
     return y, t
 
 
-def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True, defer=None):
+def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True, defer=None, defer_reduction=False):
     """Backward of linear_fused_fwd in three launches (dx+dt; token reduction of both factor gradients; ordered final sum). grad_targets: None (LoRA factors frozen) or a list with one
     (down_grad, up_grad, alpha, n_rows, accumulate_down, accumulate_up) per site — fp32 contiguous tensors shaped like the parameters (either
     may be None); the kernel writes / accumulates into them directly. Returns dx | None.
     defer: None, or a callable (ws_key, nbytes) -> persistent fp32 workspace tensor; then the final sum is NOT launched and
-    the (LoraFinalRec, ws) pair is returned as the second value for lora_grad_final_all."""
+    the (LoraFinalRec, ws) pair is returned as the second value for lora_grad_final_all. defer_reduction (with defer): the token
+    reduction is not launched either -- the second value is (LoraFinalRec, LoraGradJob, keep) with `keep` the tensors the job's
+    pointers refer to (dt, x, t, dy): the caller holds them until it has issued lora_grad_all over all jobs."""
     _dev(dy, x, Wt, t, A16T, BpT)
     M, N = dy.shape
     K = x.shape[1]
@@ -174,6 +176,13 @@ def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True, 
         if defer is not None:
             ws = defer((BpT.data_ptr(), M, N, K), nws)
             rec = _lib.LoraFinalRec()
+            if defer_reduction:
+                job = _lib.LoraGradJob()
+                _lib.check(L.mos_lora_linear_fused_bwd_deferred_all(
+                    _p(dy), _rows(dy), _p(x), _rows(x), _p(Wt), _rows(Wt) if Wt is not None else 0, _p(t), _p(A16T), _p(BpT), _p(dt),
+                    _p(dx), _rows(dx) if dx is not None else 0, ctypes.byref(g), _p(ws), M, N, K, int(cols), _dt(dy), _stream(),
+                    ctypes.byref(rec), ctypes.byref(job)), 'mos_lora_linear_fused_bwd_deferred_all')
+                return dx, (rec, job, (dt, x, t, dy))
             _lib.check(L.mos_lora_linear_fused_bwd_deferred(
                 _p(dy), _rows(dy), _p(x), _rows(x), _p(Wt), _rows(Wt) if Wt is not None else 0, _p(t), _p(A16T), _p(BpT), _p(dt),
                 _p(dx), _rows(dx) if dx is not None else 0, ctypes.byref(g), _p(ws), M, N, K, int(cols), _dt(dy), _stream(),
@@ -185,6 +194,15 @@ def linear_fused_bwd(dy, x, Wt, t, A16T, BpT, grad_targets, rank, need_dx=True, 
                                            ctypes.byref(g) if g is not None else None, _p(ws), M, N, K, int(cols),
                                            _dt(dy), _stream()), 'mos_lora_linear_fused_bwd')
     return (dx, None) if defer is not None else dx
+
+
+def lora_grad_all(jobs_dev, byte_offset, n_jobs, total_blocks, nj, dtype, flops, nbytes):
+    """ONE launch: the token reductions of every deferred LoRA gradient group of one padded-rank class (`n_jobs` records starting
+    `byte_offset` bytes into the uint8 device table `jobs_dev`)."""
+    L = _lib.load()
+    _lib.check(L.mos_lora_grad_all(ctypes.c_void_p(jobs_dev.data_ptr() + int(byte_offset)), int(n_jobs), int(total_blocks), int(nj),
+                                   MOS_F16 if dtype == torch.float16 else MOS_BF16, float(flops), float(nbytes), _stream()),
+               'mos_lora_grad_all')
 
 
 def lora_grad_final_all(recs_dev, n_recs, total_blocks):

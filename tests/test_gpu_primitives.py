@@ -727,29 +727,34 @@ def test_add_layernorm_fp32_stream_vs_fp32_torch(ops, emu, dtype, rows, C):
 
 
 def test_lora_gradient_finals_deferred_equal_immediate():
-    """TrainEngine's scope batches the ordered final sums of all LoRA gradient groups into ONE launch
-    (mos_lora_grad_final_all): bit-identical `.grad`s to the per-group final sums, also on a second pass (persistent
-    workspaces, unchanged record table) and with accumulation into existing gradients."""
+    """TrainEngine's scope batches the LoRA factor gradients of a backward pass: the ordered final sums of all groups in ONE
+    launch (mos_lora_grad_final_all) and -- round 5 -- the token reductions in one launch per padded-rank class
+    (mos_lora_grad_all): bit-identical `.grad`s to the per-group launches, also on a second pass (persistent workspaces) and
+    with accumulation into existing gradients; half and bfloat16 groups in one scope; several rank classes (4, 8, 12)."""
     from mixofshow.hip import functional as F_hip
     torch.manual_seed(3)
     dev = 'cuda'
     layers = []
-    for (K, N) in ((320, 960), (768, 2304), (640, 640)):
-        W = (torch.randn(N, K, device=dev) / K**0.5).half()
-        sites, n_sites = [], 3 if N % 3 == 0 and N != K else 1
+    for (K, N, n_sites, dt) in ((320, 960, 3, torch.float16), (768, 2304, 3, torch.float16), (640, 640, 1, torch.float16),
+                                (768, 1280, 2, torch.float16), (320, 320, 1, torch.float16), (320, 960, 3, torch.bfloat16),
+                                (1280, 1280, 1, torch.bfloat16)):
+        W = (torch.randn(N, K, device=dev) / K**0.5).to(dt)
+        sites = []
         for _ in range(n_sites):
             down = torch.nn.Parameter(torch.randn(4, K, device=dev) * 0.05)
             up = torch.nn.Parameter(torch.randn(N // n_sites, 4, device=dev) * 0.05)
             sites.append((down, up, 0.7))
         layers.append((W, W.t().contiguous(), sites))
-    xs = [torch.randn(2, 300, W.shape[1], device=dev).half().requires_grad_(True) for W, _, _ in layers]
+    xs = [torch.randn(2, 300 + 7 * i, W.shape[1], device=dev).to(W.dtype).requires_grad_(True) for i, (W, _, _) in enumerate(layers)]
 
-    def run(deferred, passes):
+    def run(mode, passes):
         for _, _, sites in layers:
             for d, u, _ in sites:
                 d.grad, u.grad = torch.full_like(d, 0.25), torch.full_like(u, -0.5)     # accumulate on top of these
+        store = F_hip.new_deferred_finals()
+        store.defer_reduction = (mode == 'all')
         for _ in range(passes):
-            scope = F_hip.direct_grad_accumulation(defer_finals=deferred)
+            scope = F_hip.direct_grad_accumulation(defer_finals=mode != 'immediate', store=store if mode != 'immediate' else None)
             with scope:
                 loss = 0
                 for (W, Wt, sites), x in zip(layers, xs):
@@ -759,8 +764,9 @@ def test_lora_gradient_finals_deferred_equal_immediate():
         return [p.grad.clone() for _, _, sites in layers for d, u, _ in sites for p in (d, u)]
 
     for passes in (1, 2):
-        a, b = run(False, passes), run(True, passes)
+        a, b, c = run('immediate', passes), run('finals', passes), run('all', passes)
         assert all(torch.equal(x, y) for x, y in zip(a, b)), f'deferred final sums differ after {passes} pass(es)'
+        assert all(torch.equal(x, y) for x, y in zip(a, c)), f'batched token reductions differ after {passes} pass(es)'
         assert all(torch.isfinite(x).all() and (x != 0.25).any() for x in a)
 
 
