@@ -19,7 +19,7 @@ EXTRA_mos_attn="-mllvm -amdgpu-mfma-vgpr-form=1 ${MOS_ATTN_FLAGS:-}"
 # register allocation with 20-50 v_accvgpr_read/write/mov per K tile rotating the accumulator tuples (64x64 GEMM ring: 42 VALU
 # for 8 MFMAs, fused 64x128 ring: 94 for 20); the VGPR form has none (22 / 38). VALU and MFMA time add up on this chip.
 # MOS_MFMA_FORM_FLAGS="" restores the AccVGPR form for an A/B build.
-EXTRA_mos_gemm="${MOS_MFMA_FORM_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1}"
+EXTRA_mos_gemm="${MOS_MFMA_FORM_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1} ${MOS_GEMM_FLAGS:-}"
 # MOS_CONV_FLAGS="-DMOS_CONV_NO_HALO": a variant build whose 3x3 convolutions all take the raster form of rounds 2-4 (same-box A/B
 # of the halo-staged form; load with MOS_HIP_LIB=...). Build-time only: the library reads no environment variable.
 EXTRA_mos_conv="${MOS_MFMA_FORM_FLAGS--mllvm -amdgpu-mfma-vgpr-form=1} ${MOS_CONV_FLAGS:-}"

@@ -594,7 +594,11 @@ __device__ __forceinline__ void lora_grad_block(const J& a, int bx, int by, floa
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
     if (c0 < C) {
+#ifdef MOS_GRAD_U
+        constexpr int U = NJ <= 4 ? MOS_GRAD_U : (NJ <= 8 ? (MOS_GRAD_U > 6 ? 6 : MOS_GRAD_U) : 4);     // (variant build: deeper unroll where registers allow)
+#else
         constexpr int U = 4;
+#endif
         for (int m = mb + ry; m < me; m += 32 * U) {
             u32x4 z[U];
             u32x2 p[U][NJ / 4];
