@@ -31,7 +31,11 @@
 #define MOS_TN_TARGET_WG 512      // workgroups the legacy LoRA-gradient kernel aims at
 #endif
 #ifndef MOS_GRAD_TARGET_WG
-#define MOS_GRAD_TARGET_WG 1024   // workgroups the fused LoRA-gradient kernel aims at
+// workgroups the token reduction of ONE LoRA group aims at. 1024 while every group was its own launch (rounds 2-4); since the groups
+// of a backward pass share one launch per rank class (mos_lora_grad_all, ~15 k blocks) fewer, longer blocks per group win: fewer
+// partial sums to write and to sum, fewer re-reads of the 16-wide t / dt rows -- same box, per step: 0.81 ms at 1024, 0.61 at 512,
+// 0.51 at 256 (3.0 TB/s; profiles/r05c7_ab_same_box_lora_grad_tuning.txt)
+#define MOS_GRAD_TARGET_WG 256
 #endif
 #ifndef MOS_GEMM_DEEP_MAX_WG
 #define MOS_GEMM_DEEP_MAX_WG 96   // GEMMs with at most this many workgroups use the deep-stage variants (measured: a win only
@@ -594,11 +598,7 @@ __device__ __forceinline__ void lora_grad_block(const J& a, int bx, int by, floa
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
     if (c0 < C) {
-#ifdef MOS_GRAD_U
-        constexpr int U = NJ <= 4 ? MOS_GRAD_U : (NJ <= 8 ? (MOS_GRAD_U > 6 ? 6 : MOS_GRAD_U) : 4);     // (variant build: deeper unroll where registers allow)
-#else
-        constexpr int U = 4;
-#endif
+        constexpr int U = 4;      // (8 measured in round 5: no gain, profiles/r05c7_ab_same_box_lora_grad_tuning.txt)
         for (int m = mb + ry; m < me; m += 32 * U) {
             u32x4 z[U];
             u32x2 p[U][NJ / 4];
