@@ -103,6 +103,10 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 __device__ __forceinline__ void dma16(rsrc_t src, void* lds_wave_base, int byte_off) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void_t*)lds_wave_base, 16, byte_off, 0, 0, 0);
 }
+// the same with a wave-uniform part of the offset in the instruction's scalar-offset operand (no VALU add per piece)
+__device__ __forceinline__ void dma16s(rsrc_t src, void* lds_wave_base, int lane_byte_off, int uniform_byte_off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void_t*)lds_wave_base, 16, lane_byte_off, uniform_byte_off, 0, 0);
+}
 
 // ---- host-side error plumbing (defined in mos_api.hip) --------------------------------------
 int mos_set_error(int code, const char* fmt, ...);

@@ -868,9 +868,11 @@ def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
     (1, 320, 320, 13, 21, 'u'),       # upsampled read with ragged halo tiles (26 x 42 output)
     (2, 128, 128, 96, 80, 't'),       # VAE-like stage
     (1, 128, 256, 250, 203, 'r'),     # VAE stage, ragged last tile in both directions
-    (1, 128, 128, 512, 500, ''),      # VAE 512-px stage
-    (1, 512, 512, 128, 128, 'r'),     # VAE 512-channel stage: the 16 x 16 x 128 halo tile (256 of them)
-    (1, 512, 512, 130, 100, ''),      # ... ragged
+    (1, 128, 128, 512, 500, ''),      # VAE 512-px stage: the 16 x 16 x 128 halo tile on 32-channel chunks (>= 512 of them)
+    (1, 256, 128, 300, 490, 't'),     # ... ragged in both directions, 8 chunks of 32 channels
+    (1, 512, 512, 128, 128, 'r'),     # VAE 512-channel stage: the same tile (256 of them)
+    (1, 512, 512, 64, 96, 'u'),       # VAE decoder up-sampler of a 512x768 sample: that tile with the upsampled halo fetch
+    (1, 512, 512, 130, 100, ''),      # ... ragged, below the tile-count rule: 8 x 16 x 64 tiles
     (1, 64, 8, 5, 7, 'tr'),           # tiny / odd sizes (raster form: narrower than a halo tile)
     (1, 64, 72, 9, 17, 'tr'),         # one row / one column past a halo tile, Cout not a multiple of the 64-wide tile
     (2, 1280, 1280, 16, 24, 'tr'),    # 512x768 sample, level 2: split-K form (240 tiles, 4 K ranges)

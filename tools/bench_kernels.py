@@ -205,7 +205,7 @@ def gram_case(n, cin, cout, dtype, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,gn,conv1,probs")
+    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,gn,conv1,convvae,probs")
     ap.add_argument('--dtype', default='f16')
     ap.add_argument('--legacy', type=int, default=0, help='gemm: also time the round-1 multi-launch LoRA path')
     ap.add_argument('--ref', type=int, default=1, help='0: skip the MIOpen / hipBLASLt reference timings')
@@ -243,6 +243,12 @@ def main():
                         (2, 640, 640, 32, 48), (2, 1920, 640, 32, 48), (2, 2560, 1280, 16, 24), (2, 1280, 1280, 8, 12),
                         (2, 2560, 1280, 8, 12)],
                        dt, args.iters, ref=bool(args.ref))
+    if 'convvae' in only:        # the VAE's convolutions: encoder of the training step (batch 4, 512 px), decoder of the 512x768 sample
+        conv_reference([(4, 128, 128, 512, 512), (4, 128, 256, 256, 256), (4, 256, 256, 256, 256), (4, 256, 512, 128, 128),
+                        (4, 512, 512, 128, 128), (4, 512, 512, 64, 64), (1, 512, 512, 64, 96), (1, 512, 512, 128, 192),
+                        (1, 512, 512, 256, 384), (1, 512, 256, 256, 384), (1, 256, 256, 256, 384), (1, 256, 256, 512, 768),
+                        (1, 256, 128, 512, 768), (1, 128, 128, 512, 768), (2, 1920, 640, 32, 48), (2, 640, 640, 32, 48),
+                        (2, 1920, 640, 32, 48)], dt, args.iters, ref=False)
     if 'conv1' in only:          # ONE shape (level-0 ResNet conv, forward + backward-data): clean per-launch PMC counters
         conv_reference([(4, 320, 320, 64, 64)], dt, args.iters, ref=False)
     if 'probs' in only:
