@@ -4,7 +4,8 @@
 #   2. HBM-traffic PMC passes (attention + regional kernels) for the current kernel sources
 #   3. the default bench line (train + regional halves, cpu baselines)
 #   4. rocprofv3 --kernel-trace --stats of BOTH halves
-#   5. the JPEG-fed training step, 6. the configs[3] fusion line
+#   5b. the shipped 1024x2048 example, 5. the JPEG-fed training step, 2b. PMC of the halo convolution / probability kernels,
+#   6. the configs[3] fusion line   (least essential last: the call's time limit is whatever GPU budget is left)
 # Copy gpurun_out/<tag>_* into profiles/ afterwards.        bash tools/final_gpu_run.sh <tag>
 set -u
 TAG="${1:-r05}"
@@ -33,9 +34,6 @@ if python -c "import json,sys; d=json.load(open('$O/${TAG}_pmc_traffic.json')); 
   cp "$O/${TAG}_pmc_traffic.json" profiles/pmc_traffic.json; echo "pmc_traffic.json refreshed: $(python -c "import json; print(list(json.load(open('profiles/pmc_traffic.json'))['kernels']))")"
 else echo "PMC FAILED"; tail -5 "$O/${TAG}_pmc_run.log"; fi
 fi
-echo "== 2b. PMC of the halo convolution (one shape: B4 320->320 64x64) and of the materialised-probability kernels"
-PMC_BENCH_ARGS="--ref 0" bash tools/pmc_collect.sh conv1,probs > "$O/${TAG}_pmc_conv_run.log" 2>&1
-cp "$O/pmc_conv1,probs.txt" "$O/${TAG}_pmc_conv_halo_and_probs_kernels.txt" 2>/dev/null; grep -A16 "conv3x3_halo_kernel f16" "$O/${TAG}_pmc_conv_halo_and_probs_kernels.txt" | head -40
 echo "== 3. default bench"
 timeout 900 python bench.py --steps 20 --warmup 5 > "$O/${TAG}_bench_train_n1.json" 2> "$O/${TAG}_bench_train_n1.err"
 tail -2 "$O/${TAG}_bench_train_n1.err"; cut -c1-260 "$O/${TAG}_bench_train_n1.json"
@@ -56,12 +54,15 @@ cd "$ROOT"
 grep -E "attn_bwd_dkdv(_pipe)?_kernelIDF16_Li40|conv3x3_(nhwc|halo)_kernel|gn_col_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_train.csv" | cut -c1-160 | head -8
 grep -E "attn_fwd_kernelIDF16_Li40|region_attn_kernel|gn_col_kernel" "$O/${TAG}_rocprofv3_kernel_stats_bench_regional.csv" | cut -c1-160 | head -8
 cut -c1-200 "$O/${TAG}_bench_train_under_rocprof.json"; cut -c1-200 "$O/${TAG}_bench_regional_under_rocprof.json"
-echo "== 5. train step fed by the JPEG data pipeline (SURVEY 8(f).4)"
-timeout 150 python bench.py --steps 20 --warmup 5 --data jpeg --no-cpu-baseline --no-regional > "$O/${TAG}_bench_train_jpeg.json" 2> "$O/${TAG}_bench_train_jpeg.err"
-tail -1 "$O/${TAG}_bench_train_jpeg.err"; cut -c1-200 "$O/${TAG}_bench_train_jpeg.json"
 echo "== 5b. the reference's shipped regional example, 1024x2048"
 timeout 400 python bench.py --mode regional --height 1024 --width 2048 --steps 2 --warmup 1 > "$O/${TAG}_bench_regional_1024x2048.json" 2> "$O/${TAG}_bench_regional_1024x2048.err"
 cut -c1-260 "$O/${TAG}_bench_regional_1024x2048.json"
+echo "== 5. train step fed by the JPEG data pipeline (SURVEY 8(f).4)"
+timeout 150 python bench.py --steps 20 --warmup 5 --data jpeg --no-cpu-baseline --no-regional > "$O/${TAG}_bench_train_jpeg.json" 2> "$O/${TAG}_bench_train_jpeg.err"
+tail -1 "$O/${TAG}_bench_train_jpeg.err"; cut -c1-200 "$O/${TAG}_bench_train_jpeg.json"
+echo "== 2b. PMC of the halo convolution (one shape: B4 320->320 64x64) and of the materialised-probability kernels"
+PMC_BENCH_ARGS="--ref 0" bash tools/pmc_collect.sh conv1,probs > "$O/${TAG}_pmc_conv_run.log" 2>&1
+cp "$O/pmc_conv1,probs.txt" "$O/${TAG}_pmc_conv_halo_and_probs_kernels.txt" 2>/dev/null; grep -A16 "conv3x3_halo_kernel f16" "$O/${TAG}_pmc_conv_halo_and_probs_kernels.txt" | head -40
 echo "== 6. configs[3]: gradient fusion of 14 synthetic ED-LoRAs"
 timeout 420 python bench.py --mode fusion --concepts 14 --steps 2 --warmup 1 > "$O/${TAG}_bench_fusion.json" 2> "$O/${TAG}_bench_fusion.err"
 echo "rc=$?"; grep "fusion pass" "$O/${TAG}_bench_fusion.err"; cut -c1-300 "$O/${TAG}_bench_fusion.json"
