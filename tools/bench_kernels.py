@@ -205,7 +205,7 @@ def gram_case(n, cin, cout, dtype, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,gn,conv1,convvae,probs")
+    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,gn,conv1,convvae,convvae1,probs")
     ap.add_argument('--dtype', default='f16')
     ap.add_argument('--legacy', type=int, default=0, help='gemm: also time the round-1 multi-launch LoRA path')
     ap.add_argument('--ref', type=int, default=1, help='0: skip the MIOpen / hipBLASLt reference timings')
@@ -251,6 +251,8 @@ def main():
                         (2, 1920, 640, 32, 48)], dt, args.iters, ref=False)
     if 'conv1' in only:          # ONE shape (level-0 ResNet conv, forward + backward-data): clean per-launch PMC counters
         conv_reference([(4, 320, 320, 64, 64)], dt, args.iters, ref=False)
+    if 'convvae1' in only:       # ONE VAE shape on the 16 x 16 x 128 / 32-channel-chunk tile: clean per-launch PMC counters
+        conv_reference([(4, 128, 128, 512, 512)], dt, args.iters, ref=False)
     if 'probs' in only:
         for (B, N, d) in ((2, 4096, 40), (2, 1024, 80), (2, 256, 160)):
             C = 8 * d
