@@ -25,9 +25,27 @@ def _train_lines():
     return sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_train_n1.json')))
 
 
+def _check_compact_train_line(d, raw):
+    """Round 6 on: the stdout line is the COMPACT record (<= 4096 bytes, flat regional keys); the verbose one is a file."""
+    assert len(raw.encode()) <= 4096
+    assert d['metric'] == 'edlora_train_images_per_sec_512_sd15' and d['unit'] == 'images/s'
+    assert d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic'
+    assert isinstance(d['config']['workload'], str) and 'model' not in d['config'] and d['config']['hipgraph'] is True
+    assert abs(d['value'] - d['config']['global_batch'] / (d['ms_per_step'] * 1e-3)) < 0.02 * d['value']
+    _check_roofline(d['roofline'])
+    _check_cpu_baseline(d['cpu_baseline'], d['unit'])
+    assert d['value'] > d['cpu_baseline']['value']
+    assert d['regional_ms_image'] > 0 and d['regional_ms_latent'] > 0 and 0 < d['regional_roofline_frac'] < 1
+    assert d['regional_cpu_baseline_ms'] > d['regional_ms_image']
+    assert 'id' in d['config']['box'] and 'kernels' not in d and 'regional' not in d
+
+
 @pytest.mark.parametrize('path', _train_lines())
 def test_committed_train_bench_line_schema(path):
-    d = json.load(open(path))
+    raw = open(path).read().strip().splitlines()[-1]
+    d = json.loads(raw)
+    if 'full_record' in d:
+        return _check_compact_train_line(d, raw)
     base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
     assert d['metric'] == 'edlora_train_images_per_sec_512_sd15' and 'ED-LoRA train images/sec' in base['metric']
     for k, t in (('value', float), ('unit', str), ('n_gpus', int), ('steps', int), ('warmup', int),
@@ -50,6 +68,43 @@ def test_committed_train_bench_line_schema(path):
         a = d['attention_path']
         assert abs(a['algorithmic_tflop'] - 0.604 * d['config']['per_gpu_batch']) < 1e-3
         assert abs(a['frac_of_mfma_peak'] - a['achieved_tflops'] / 2500.0) < 1e-4
+
+
+@pytest.mark.parametrize('path', ['profiles/r05_bench_train_n1.json', 'profiles/r05_bench_fusion.json',
+                                  'profiles/r05_bench_regional_1024x2048.json'])
+def test_stdout_line_is_compact_and_parseable(path):
+    """the 30 KB round-5 line could not be parsed by the driver. The line bench.py prints is now built by
+    `compact_line` from the verbose record; fed the largest verbose records on file it must stay under 4096 bytes, parse, and
+    still carry the contract's keys, `roofline`, `cpu_baseline` and both halves of BASELINE's metric."""
+    import bench
+    full = json.loads(open(os.path.join(ROOT, path)).read().strip().splitlines()[-1])
+    line = bench.compact_line(full, 'gpurun_out/bench_full.json')
+    assert len(line.encode()) <= bench.COMPACT_LIMIT == 4096 and '\n' not in line
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'parity', 'full_record'):
+        assert k in d, k
+    assert d['value'] == full['value'] and d['ms_per_step'] == full['ms_per_step']
+    assert d['roofline']['frac'] == full['roofline']['frac'] and d['roofline']['kernel'] == full['roofline']['kernel']
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    assert not any(k in d for k in ('kernels', 'regional', 'dominant_kernels_by_name'))     # verbose tables stay in the file
+    assert len(d['parity']) <= 11 and d['parity']['tol'] == 1e-3
+    if full['metric'].startswith('edlora_train'):
+        assert d['cpu_baseline']['value'] == full['cpu_baseline']['value'] and d['cpu_baseline']['kind'] == 'port'
+        assert d['regional_ms_image'] == full['regional']['value_ms_image']
+        assert d['regional_ms_latent'] == full['regional']['value_ms_latent']
+        assert d['regional_roofline_frac'] == full['regional']['roofline']['frac']
+        assert d['regional_cpu_baseline_ms'] == full['regional']['cpu_baseline']['value']
+        assert d['whole_step']['frac_of_mfma_peak'] == full['whole_step']['frac_of_mfma_peak']
+        assert 'fp32pipe.latent_rms' in d['parity'] and 'fp32pipe.latent_max' in d['parity']
+
+
+def test_main_prints_exactly_one_compact_stdout_line():
+    """bench.main() writes the verbose record to stderr / gpurun_out and ONLY the compact line to stdout."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    main = src[src.index('def main():'):]
+    assert main.count('print(compact_line(res, full), flush=True)') == 1
+    assert 'print(json.dumps(res))' not in src
 
 
 def test_product_default_is_the_benchmarked_mode():
