@@ -905,7 +905,7 @@ def _pick(d, keys):
 def compact_line(res, full_path=None):
     """The ONE stdout line of a run: the contract's keys + `roofline` + `cpu_baseline` + both halves of BASELINE's metric, in
     <= COMPACT_LIMIT bytes. Everything else `res` carries (kernel tables, per-case parity, the regional sub-record) is the
-    VERBOSE record: written to gpurun_out/bench_full.json and to stderr, never to stdout."""
+    VERBOSE record: written to gpurun_out/bench_full.json, never to stdout."""
     rl_keys = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_us', 'launches',
                'algorithmic_flops_per_launch', 'algorithmic_bytes_per_launch')
     out = {k: res.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
@@ -961,7 +961,8 @@ def compact_line(res, full_path=None):
 
 
 def write_full_record(res):
-    """Verbose record -> gpurun_out/bench_full.json (scratch on the GPU box, merged back by gpurun) + stderr."""
+    """Verbose record -> gpurun_out/bench_full.json (scratch on the GPU box, merged back by gpurun). Not echoed: a 30 KB dump
+    would push the timing lines out of the stderr tail the driver keeps."""
     path = None
     try:
         d = os.path.join(ROOT, 'gpurun_out')
@@ -972,7 +973,7 @@ def write_full_record(res):
         path = 'gpurun_out/bench_full.json'
     except OSError:
         path = None
-    print('[bench full record] ' + json.dumps(res), file=sys.stderr, flush=True)
+    _log(f'verbose record ({len(json.dumps(res))} bytes: kernel tables, per-case parity, regional sub-record) -> {path}')
     return path
 
 

@@ -284,6 +284,17 @@ typedef struct {
 int mos_region_cross_attn_fwd(const void* q, const void* k_src, const void* v_src, void* o,
                               const mos_attn_shape* shape_host, const mos_region_desc* reg_host,
                               int dtype, void* stream);
+/* Region lists longer than MOS_MAX_SOURCES-1 (the reference loops over an unbounded `region_list`,
+ * mixofshow/pipelines/pipeline_regionally_t2iadapter.py:60-83): walk the list in chunks of <= MOS_MAX_SOURCES-1 boxes.
+ *   total_count : device pointer, Nq bytes: number of boxes of the WHOLE list covering each query (the reference's `count`
+ *                 tensor, :56,80); every chunk divides by it. NULL = count this launch's boxes (one-launch case).
+ *   accumulate  : 0 = first chunk: o = blend of this chunk's regions, queries with total_count 0 get the context prompt
+ *                 (source 0); 1 = later chunk: o += blend of this chunk's regions, source 0 is not read (pass the pointer of
+ *                 the source just before the chunk's first region so that sources 1.. are the chunk's regions).
+ * One chunk == mos_region_cross_attn_fwd. */
+int mos_region_cross_attn_fwd_chunk(const void* q, const void* k_src, const void* v_src, void* o,
+                                    const mos_attn_shape* shape_host, const mos_region_desc* reg_host,
+                                    const void* total_count, int accumulate, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Cross-attention with the probabilities MATERIALISED: the controller half of the processor boundary. The reference hands

@@ -506,7 +506,14 @@ struct RegionStage {     // registers of one source in flight
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(AttnArgs a, mos_region_desc reg) {
+__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(AttnArgs a, mos_region_desc reg,
+                                                                          const unsigned char* __restrict__ total_count,
+                                                                          int accumulate) {
+    // total_count / accumulate: a region list longer than one launch holds (MOS_MAX_SOURCES - 1) is walked in chunks. The
+    // blend is additive over regions with ONE divisor -- the number of boxes of the WHOLE list that cover the query
+    // (pipeline_regionally_t2iadapter.py:60-83: += per region, / count at the end) -- so every chunk weighs its regions with
+    // 1 / total_count[q] (a per-query byte map the caller built from all boxes), the first chunk also serves the queries no box
+    // covers from the context prompt, and the later chunks add into o.
     typedef typename MT<T>::v8 v8;
     typedef RG<D> G;
     constexpr int KS = HD<D>::KS, DT = HD<D>::DT, RS = HD<D>::RS, DCH = HD<D>::DCH, TS3 = G::TS3, NSP = G::NSP;
@@ -529,7 +536,8 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(Att
         inbits |= in ? (2u << r) : 0u;
         cnt += in ? 1 : 0;
     }
-    if (cnt == 0) inbits = 1u;
+    if (total_count != nullptr) cnt = total_count[min(qi, a.Nq - 1)];
+    if (cnt == 0) inbits = accumulate ? 0u : 1u;
     if (qi >= a.Nq) inbits = 0u;
     const float wreg = cnt > 0 ? 1.f / (float)cnt : 1.f;      // weight of every source this query uses
     unsigned wave_need = 0;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(Att
     // issued): the block's queries are feature rows y_first..y_last (columns x_first..x_last when it sits in one row); a
     // region is staged when its box meets that range -- a superset of what the waves use (they skip per wave below) --
     // and the context prompt always.
-    unsigned need = 1u;
+    unsigned need = accumulate ? 0u : 1u;
     {
         const int qf0 = qb * 128, ql0 = min(qb * 128 + 127, a.Nq - 1);
         const int y_first = qf0 / reg.feat_w, y_last = ql0 / reg.feat_w;
@@ -763,6 +771,24 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(Att
 #pragma unroll
         for (int i = 0; i < NSP; ++i) cur_src[i] = nxt_src[i];
         ncur = nnxt;
+    }
+    if (accumulate) {
+        if (qi < a.Nq && inbits != 0u) {      // queries none of this chunk's boxes covers keep what the earlier chunks wrote
+            T* orow = op + (int64_t)qi * a.o_rs;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int db = 32 * dt + 8 * r4 + 4 * hh;
+                    if (db < D) {
+                        const u32x2 old = ld8(orow + db);
+                        const T* oh = reinterpret_cast<const T*>(&old);
+                        st8(orow + db, pack4<T>((float)oh[0] + fin[dt][4 * r4], (float)oh[1] + fin[dt][4 * r4 + 1],
+                                                 (float)oh[2] + fin[dt][4 * r4 + 2], (float)oh[3] + fin[dt][4 * r4 + 3]));
+                    }
+                }
+        }
+        return;
     }
     store_out_rows<T, D>(op + (int64_t)qi * a.o_rs, qi < a.Nq, fin, 1.0f, hh);
 }
@@ -1559,7 +1585,7 @@ int launch_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
 
 template <typename T, int D>
 int launch_region(const void* q, const void* k, const void* v, void* o, const mos_attn_shape* s,
-                  const mos_region_desc* reg, hipStream_t st) {
+                  const mos_region_desc* reg, const unsigned char* total_count, int accumulate, hipStream_t st) {
     AttnArgs a = make_args(q, k, v, o, nullptr, nullptr, 0, nullptr, s, 128);
     const dim3 grid((unsigned)(a.H * a.nqb * a.B));
     const size_t lds = RG<D>::lds_bytes(sizeof(T));
@@ -1575,7 +1601,7 @@ int launch_region(const void* q, const void* k, const void* v, void* o, const mo
     char rk[128];
     snprintf(rk, sizeof(rk), "%s R%d", key.s, reg->n_regions);
     MosProfScope prof(st, "region_attn", rk, key.flops * cover / (double)s->Nq, key.bytes);
-    hipLaunchKernelGGL((region_attn_kernel<T, D>), grid, dim3(256), lds, st, a, *reg);
+    hipLaunchKernelGGL((region_attn_kernel<T, D>), grid, dim3(256), lds, st, a, *reg, total_count, accumulate);
     return mos_check_launch("region_attn");
 }
 
@@ -1757,7 +1783,14 @@ int mos_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
 
 int mos_region_cross_attn_fwd(const void* q, const void* k_src, const void* v_src, void* o, const mos_attn_shape* s,
                               const mos_region_desc* reg, int dtype, void* stream) {
+    return mos_region_cross_attn_fwd_chunk(q, k_src, v_src, o, s, reg, nullptr, 0, dtype, stream);
+}
+
+int mos_region_cross_attn_fwd_chunk(const void* q, const void* k_src, const void* v_src, void* o, const mos_attn_shape* s,
+                                    const mos_region_desc* reg, const void* total_count, int accumulate, int dtype,
+                                    void* stream) {
     int rc = check_shape(s, "mos_region_cross_attn_fwd");
+    MOS_REQUIRE(!accumulate || total_count, "mos_region_cross_attn_fwd_chunk: accumulate needs the total count map");
     if (rc) return rc;
     MOS_REQUIRE(q && k_src && v_src && o && reg, "mos_region_cross_attn_fwd: NULL argument");
     MOS_REQUIRE(reg->n_regions >= 0 && reg->n_regions <= MOS_MAX_SOURCES - 1, "mos_region_cross_attn_fwd: n_regions=%d",
@@ -1768,7 +1801,8 @@ int mos_region_cross_attn_fwd(const void* q, const void* k_src, const void* v_sr
         return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_region_cross_attn_fwd: built for CLIP's 77-token context "
                              "(65..96 keys per source), got Nkv=%d", s->Nkv);
     hipStream_t st = (hipStream_t)stream;
-    MOS_DISPATCH_TD(dtype, s->d, (launch_region<TT, DD>(q, k_src, v_src, o, s, reg, st)));
+    MOS_DISPATCH_TD(dtype, s->d, (launch_region<TT, DD>(q, k_src, v_src, o, s, reg, (const unsigned char*)total_count,
+                                                        accumulate ? 1 : 0, st)));
 }
 
 }  // extern "C"

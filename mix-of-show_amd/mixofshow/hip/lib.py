@@ -152,6 +152,8 @@ SIGNATURES = {
     'mos_cross_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
     'mos_region_cross_attn_fwd': (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(AttnShape), ctypes.POINTER(RegionDesc),
                                        _i, _vp]),
+    'mos_region_cross_attn_fwd_chunk': (_i, [_vp, _vp, _vp, _vp, ctypes.POINTER(AttnShape), ctypes.POINTER(RegionDesc),
+                                             _vp, _i, _i, _vp]),
     'mos_attn_probs': (_i, [_vp, _vp, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
     'mos_attn_pv': (_i, [_vp, _vp, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
     'mos_gram_workspace_bytes': (_i64, [_i64, _i, _i]),

@@ -345,28 +345,55 @@ def attn_bwd(q, k, v, o, lse, dO, heads, scale, dq, dk, dv, tok_idx=None, pcols=
     return dq, dk, dv
 
 
+_region_count_cache = {}
+
+
+def region_total_count(boxes, feat_h, feat_w, device):
+    """The reference's `count` tensor (pipeline_regionally_t2iadapter.py:56,80) for a whole region list: per query, how many
+    boxes cover it -- a (feat_h*feat_w,) uint8 device tensor, built on the host from the integer boxes (no device work, no
+    sync) and kept per (boxes, size, device): the same handful of layouts recurs at every layer and step of a call."""
+    key = (tuple(tuple(int(v) for v in b) for b in boxes), int(feat_h), int(feat_w), str(device))
+    t = _region_count_cache.get(key)
+    if t is None:
+        cnt = torch.zeros((feat_h, feat_w), dtype=torch.int32)
+        for h0, w0, h1, w1 in key[0]:
+            if h1 > h0 and w1 > w0:
+                cnt[max(h0, 0):h1, max(w0, 0):w1] += 1
+        assert int(cnt.max()) <= 255, 'more than 255 overlapping regions on one query'
+        if len(_region_count_cache) > 256:
+            _region_count_cache.clear()
+        t = _region_count_cache[key] = cnt.to(torch.uint8).reshape(-1).to(device)
+    return t
+
+
 def region_attn_fwd(q, k_src, v_src, heads, scale, boxes, feat_h, feat_w):
     """Regional mask-and-blend cross attention.
 
     q (B,Nq,C); k_src/v_src (S,B,Nkv,C) views with contiguous channels, source 0 = context prompt,
-    sources 1.. = regions; boxes: list of (h0, w0, h1, w1) integer feature-cell boxes per region."""
+    sources 1.. = regions; boxes: list of (h0, w0, h1, w1) integer feature-cell boxes per region -- any number of them
+    (the reference's region_list is unbounded): up to MOS_MAX_SOURCES-1 in one launch, longer lists in chunks that share the
+    whole list's per-query count (mos_region_cross_attn_fwd_chunk)."""
     _dev(q, k_src, v_src)
     assert k_src.dim() == 4 and v_src.dim() == 4 and k_src.shape[0] == len(boxes) + 1
-    assert len(boxes) <= MOS_MAX_SOURCES - 1, f'at most {MOS_MAX_SOURCES - 1} regions per launch'
-    assert k_src.stride() == v_src.stride() or True
     B, Nq, C = q.shape
     o = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
     s = _shape(q, k_src[0], v_src[0], o, heads, scale)
     assert k_src.stride(0) == v_src.stride(0), 'k_src and v_src must share the source stride'
-    r = _lib.RegionDesc()
-    r.n_regions, r.feat_h, r.feat_w = len(boxes), int(feat_h), int(feat_w)
-    for i, b in enumerate(boxes):
-        for j in range(4):
-            r.box[i][j] = int(b[j])
-    r.src_stride = k_src.stride(0)
     L = _lib.load()
-    _lib.check(L.mos_region_cross_attn_fwd(_p(q), _p(k_src), _p(v_src), _p(o), ctypes.byref(s), ctypes.byref(r),
-                                           _dt(q), _stream()), 'mos_region_cross_attn_fwd')
+    per = MOS_MAX_SOURCES - 1
+    total = region_total_count(boxes, feat_h, feat_w, q.device) if len(boxes) > per else None
+    for c0 in range(0, max(len(boxes), 1), per):
+        chunk = boxes[c0:c0 + per]
+        r = _lib.RegionDesc()
+        r.n_regions, r.feat_h, r.feat_w = len(chunk), int(feat_h), int(feat_w)
+        for i, b in enumerate(chunk):
+            for j in range(4):
+                r.box[i][j] = int(b[j])
+        r.src_stride = k_src.stride(0)
+        # source 0 of a later chunk is the source before its first region (never read there: accumulate skips the context)
+        _lib.check(L.mos_region_cross_attn_fwd_chunk(_p(q), _p(k_src[c0]), _p(v_src[c0]), _p(o), ctypes.byref(s),
+                                                     ctypes.byref(r), _p(total), int(c0 > 0), _dt(q), _stream()),
+                   'mos_region_cross_attn_fwd')
     return o
 
 

@@ -8,7 +8,7 @@ OUT="gpurun_out/${TAG}"
 mkdir -p "${OUT}"
 (rocm-smi --showclocks --showpower --showmaxpower --showperflevel 2>&1 | head -60) > "${OUT}/rocm_smi_before.txt" || true
 for i in 1 2 3; do
-  /usr/bin/time -v -o "${OUT}/run${i}.time" python3 bench.py --gpus 1 --steps 20 --warmup 5 > "${OUT}/run${i}.json" 2> "${OUT}/run${i}.err"
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 > "${OUT}/run${i}.json" 2> "${OUT}/run${i}.err"
   echo "run ${i}: rc $? bytes $(wc -c < "${OUT}/run${i}.json")"
   cp gpurun_out/bench_full.json "${OUT}/run${i}_full.json" 2>/dev/null || true
   grep -E "timed region|captured|cold|regional" "${OUT}/run${i}.err" | head -8
