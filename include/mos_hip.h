@@ -256,12 +256,19 @@ int mos_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                  const mos_attn_shape* shape_host, const mos_attn_grad_strides* gs_host,
                  int dtype, void* stream);
 
-/* Names the reference-side binding uses (thin wrappers over mos_attn_fwd/bwd). */
+/* Names the reference-side binding uses (thin wrappers over mos_attn_fwd/bwd; SURVEY 8(b)'s proposed set). */
 int mos_self_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                       const mos_attn_shape* shape_host, int dtype, void* stream);
 int mos_cross_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                        const int32_t* tok_idx, int n_pcols, float* pcols,
                        const mos_attn_shape* shape_host, int dtype, void* stream);
+int mos_self_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dO,
+                      void* dq, void* dk, void* dv, void* ws, const mos_attn_shape* shape_host,
+                      const mos_attn_grad_strides* gs_host, int dtype, void* stream);
+int mos_cross_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dO,
+                       const int32_t* tok_idx, int n_pcols, const float* pcols, const float* dpcols,
+                       void* dq, void* dk, void* dv, void* ws, const mos_attn_shape* shape_host,
+                       const mos_attn_grad_strides* gs_host, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Regional cross-attention mask-and-blend: replaces RegionT2I_AttnProcessor.region_rewrite
@@ -305,10 +312,23 @@ int mos_region_cross_attn_fwd_chunk(const void* q, const void* k_src, const void
  *   mos_attn_probs: probs[(b*H + h), q, j] = softmax_j(scale * q_h[q] . k_h[j])   dense (B*H, Nq, Nkv) in `dtype`
  *   mos_attn_pv   : o[b, q, h*d + c]       = sum_j probs[(b*H + h), q, j] * v_h[j, c]
  * shape as for mos_attn_fwd (q/k strides for _probs, v/o strides for _pv); Nkv <= 96, d in {40, 80, 160}, no causal mask.
- * Inference only (no backward).
+ * Backward (round 6; the reference gives the map WITH grad to any controller, e.g. its own AttentionStore(training=True) whose
+ * stored maps cal_attn_reg differentiates, ptp_util.py:37-53,79-82 / trainer_edlora.py:263-313):
+ *   mos_attn_pv_bwd   : dprobs[(b*H+h), q, j] = sum_c dO[b, q, h*d+c] v_h[j, c]   dense, `dtype`
+ *                       dv[b, j, h*d+c]       = sum_q probs[(b*H+h), q, j] dO[b, q, h*d+c]
+ *   mos_attn_probs_bwd: dS = probs o (dprobs - rowsum(probs o dprobs)); dq = scale * dS . k_h ; dk = scale * dS^T . q_h
+ *   (probs = what mos_attn_probs returned for _probs_bwd, what the controller returned for _pv_bwd; dprobs of _probs_bwd = the
+ *   SUM of the gradient arriving through mos_attn_pv and the one the controller's loss sends into the map: autograd adds them.)
+ *   Strides: v in shape.v_*, q / k in shape.q_* / k_*; dO, dq, dk, dv in mos_attn_grad_strides. ws: mos_attn_probs_bwd_workspace_bytes
+ *   (per-64-query-block fp32 partials of the key-side sum, combined in block order: deterministic). One workspace size for both.
  * ------------------------------------------------------------------------------------------ */
 int mos_attn_probs(const void* q, const void* k, void* probs, const mos_attn_shape* shape_host, int dtype, void* stream);
 int mos_attn_pv(const void* probs, const void* v, void* o, const mos_attn_shape* shape_host, int dtype, void* stream);
+int64_t mos_attn_probs_bwd_workspace_bytes(const mos_attn_shape* shape_host);
+int mos_attn_pv_bwd(const void* probs, const void* v, const void* dO, void* dprobs, void* dv, void* ws,
+                    const mos_attn_shape* shape_host, const mos_attn_grad_strides* gs_host, int dtype, void* stream);
+int mos_attn_probs_bwd(const void* q, const void* k, const void* probs, const void* dprobs, void* dq, void* dk, void* ws,
+                       const mos_attn_shape* shape_host, const mos_attn_grad_strides* gs_host, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gradient-fusion least squares: replaces chunk_compute_mse + the closure of

@@ -1781,6 +1781,18 @@ int mos_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                     (launch_bwd<TT, DD>(q, k, v, o, lse, dO, tok_idx, n_pcols, pcols, dpcols, dq, dk, dv, ws, s, g, st)));
 }
 
+int mos_self_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dO, void* dq,
+                      void* dk, void* dv, void* ws, const mos_attn_shape* s, const mos_attn_grad_strides* g, int dtype,
+                      void* stream) {
+    return mos_attn_bwd(q, k, v, o, lse, dO, nullptr, 0, nullptr, nullptr, dq, dk, dv, ws, s, g, dtype, stream);
+}
+
+int mos_cross_attn_bwd(const void* q, const void* k, const void* v, const void* o, const float* lse, const void* dO,
+                       const int32_t* tok_idx, int n_pcols, const float* pcols, const float* dpcols, void* dq, void* dk,
+                       void* dv, void* ws, const mos_attn_shape* s, const mos_attn_grad_strides* g, int dtype, void* stream) {
+    return mos_attn_bwd(q, k, v, o, lse, dO, tok_idx, n_pcols, pcols, dpcols, dq, dk, dv, ws, s, g, dtype, stream);
+}
+
 int mos_region_cross_attn_fwd(const void* q, const void* k_src, const void* v_src, void* o, const mos_attn_shape* s,
                               const mos_region_desc* reg, int dtype, void* stream) {
     return mos_region_cross_attn_fwd_chunk(q, k_src, v_src, o, s, reg, nullptr, 0, dtype, stream);

@@ -114,6 +114,9 @@ class _DeferredFinals:
         self.jobs = []           # (LoraGradJob, dtype, keep-alive tensors)
         self.job_table = None    # uint8 device table
         self.job_host = None     # pinned host image (the H2D copy of a captured scope is a graph node reading it at every replay)
+        self.job_bytes = None    # image the device table holds (eager passes: uploaded only when it changes)
+        self.job_stage = None    # eager passes: two pinned staging buffers, each with the event of the copy that last read it
+        self.job_slot = 0
 
     def freeze(self):
         """A captured graph replays ONE mos_lora_grad_final_all launch with this table's address and the workspace pointers
@@ -167,11 +170,28 @@ class _DeferredFinals:
         if self.job_table is None or self.job_table.device != dev:
             self.job_table = torch.zeros(self.capacity * size, dtype=torch.uint8, device=dev)
             self.job_host = torch.zeros(self.capacity * size, dtype=torch.uint8).pin_memory()
+            self.job_bytes = None
         if torch.cuda.is_current_stream_capturing():
             self.job_host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
             self.job_table[:len(raw)].copy_(self.job_host[:len(raw)], non_blocking=True)      # a memcpy node of the graph
-        else:
-            self.job_table[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            self.job_bytes = None
+        elif raw != self.job_bytes:
+            # Eager pass: no blocking copy out of pageable memory. Under the caching allocator the activations
+            # of a step usually sit at the addresses of the step before, so the image is mostly unchanged and nothing is
+            # uploaded at all; when it did change it goes through one of two pinned staging buffers (the other one may still
+            # be feeding the previous pass's copy) with a non-blocking H2D on the launch stream.
+            if self.job_stage is None:
+                self.job_stage = [[torch.zeros(self.capacity * size, dtype=torch.uint8).pin_memory(), None] for _ in range(2)]
+            self.job_slot ^= 1
+            host, ev = self.job_stage[self.job_slot]
+            if ev is not None:
+                ev.synchronize()         # the copy that read this buffer two uploads ago: long finished, never a real wait
+            host[:len(raw)].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+            self.job_table[:len(raw)].copy_(host[:len(raw)], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.job_stage[self.job_slot][1] = ev
+            self.job_bytes = raw
         for first, n, blocks, nj, dtype, fl, by in classes:
             ops.lora_grad_all(self.job_table, first * size, n, blocks, nj, dtype, fl, by)
         del jobs                     # (dt / x / t / dy of every group were held until the launches above were enqueued)
@@ -661,6 +681,55 @@ def attention(q, k, v, heads, scale, tok_idx=None, causal=False):
     _check_half(q, k, v)
     o, pcols = _Attention.apply('sep', heads, scale, tok_idx, q, k, v, causal)
     return o, (pcols if tok_idx is not None else None)
+
+
+class _AttnProbs(torch.autograd.Function):
+    """softmax(scale q k^T) as a dense (B*H, Nq, Nkv) tensor WITH autograd (mos_attn_probs / mos_attn_probs_bwd): the
+    reference's `attn.get_attention_scores(query, key)` (edlora.py:81) for controllers that take the full map in training."""
+
+    @staticmethod
+    def forward(ctx, q, k, heads, scale):
+        probs = ops.attn_probs(q, k, heads, scale)
+        ctx.save_for_backward(q, k, probs)
+        ctx.heads, ctx.scale = heads, scale
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        q, k, probs = ctx.saved_tensors           # (an in-place edit of the map by the controller trips autograd's version check)
+        dq, dk = ops.attn_probs_bwd(q, k, probs, dprobs, ctx.heads, ctx.scale)
+        return dq, dk, None, None
+
+
+class _AttnPV(torch.autograd.Function):
+    """torch.bmm(attention_probs, value) + batch_to_head_dim (edlora.py:83-85) with autograd (mos_attn_pv / mos_attn_pv_bwd)."""
+
+    @staticmethod
+    def forward(ctx, probs, v, heads):
+        o = ops.attn_pv(probs, v, heads)
+        ctx.save_for_backward(probs, v)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        probs, v = ctx.saved_tensors
+        if dO.dtype != v.dtype:
+            dO = dO.to(v.dtype)
+        dprobs, dv = ops.attn_pv_bwd(probs, v, dO, ctx.heads)
+        return dprobs, dv, None
+
+
+def attn_probs(q, k, heads, scale):
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad):
+        return _AttnProbs.apply(q, k, heads, scale)
+    return ops.attn_probs(q, k, heads, scale)
+
+
+def attn_pv(probs, v, heads):
+    if torch.is_grad_enabled() and (probs.requires_grad or v.requires_grad):
+        return _AttnPV.apply(probs, v, heads)
+    return ops.attn_pv(probs, v, heads)
 
 
 def _dense_format(x):

@@ -156,6 +156,14 @@ SIGNATURES = {
                                              _vp, _i, _i, _vp]),
     'mos_attn_probs': (_i, [_vp, _vp, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
     'mos_attn_pv': (_i, [_vp, _vp, _vp, ctypes.POINTER(AttnShape), _i, _vp]),
+    'mos_attn_probs_bwd_workspace_bytes': (_i64, [ctypes.POINTER(AttnShape)]),
+    'mos_attn_pv_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(AttnShape), ctypes.POINTER(AttnGradStrides), _i, _vp]),
+    'mos_attn_probs_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(AttnShape), ctypes.POINTER(AttnGradStrides),
+                                _i, _vp]),
+    'mos_self_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(AttnShape),
+                               ctypes.POINTER(AttnGradStrides), _i, _vp]),
+    'mos_cross_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(AttnShape),
+                                ctypes.POINTER(AttnGradStrides), _i, _vp]),
     'mos_gram_workspace_bytes': (_i64, [_i64, _i, _i]),
     'mos_gram_accumulate': (_i, [_vp, _i64, _vp, _i64, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'mos_groupnorm_workspace_bytes': (_i64, [_i, _i, _i, _i]),

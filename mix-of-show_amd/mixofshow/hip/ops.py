@@ -400,9 +400,9 @@ def region_attn_fwd(q, k_src, v_src, heads, scale, boxes, feat_h, feat_w):
 def attn_probs(q, k, heads, scale):
     """The reference's `attn.get_attention_scores(query, key)` (edlora.py:81) on the token-major tensors: q (B,Nq,C), k (B,Nkv,C)
     views -> softmax(scale q k^T) per head as a dense (B*heads, Nq, Nkv) tensor of q's dtype (index b * heads + h, the
-    reference's head_to_batch_dim order). Nkv <= 96. For controllers that need the full map; inference only."""
+    reference's head_to_batch_dim order). Nkv <= 96. For controllers that need the full map (no autograd here: see
+    mixofshow.hip.functional.attn_probs / attn_pv for the differentiable pair)."""
     _dev(q, k)
-    assert not (q.requires_grad or k.requires_grad), 'attn_probs has no backward (controllers with gradients declare token_positions)'
     B, Nq, C = q.shape
     probs = torch.empty((B * heads, Nq, k.shape[1]), dtype=q.dtype, device=q.device)
     s = _shape(q, k, k, q, heads, scale)
@@ -422,6 +422,57 @@ def attn_pv(probs, v, heads):
     s = _shape(o, v, v, o, heads, 1.0)
     _lib.check(_lib.load().mos_attn_pv(_p(probs), _p(v), _p(o), ctypes.byref(s), _dt(v), _stream()), 'mos_attn_pv')
     return o
+
+
+def _probs_bwd_ws(L, s, device):
+    return torch.empty((L.mos_attn_probs_bwd_workspace_bytes(ctypes.byref(s)) + 3) // 4, dtype=torch.float32, device=device)
+
+
+def attn_pv_bwd(probs, v, dO, heads):
+    """Backward of attn_pv: probs (B*heads, Nq, Nkv) as the controller returned them, v (B,Nkv,C) view, dO (B,Nq,C)
+    -> (dprobs dense like probs, dv (B,Nkv,C))."""
+    _dev(probs, v, dO)
+    B, Nkv, C = v.shape
+    Nq = probs.shape[1]
+    assert probs.shape == (B * heads, Nq, Nkv) and dO.shape == (B, Nq, C) and probs.dtype == v.dtype == dO.dtype
+    probs = probs if probs.is_contiguous() else probs.contiguous()
+    dO = dO if dO.stride(-1) == 1 else dO.contiguous()
+    dprobs = torch.empty_like(probs)
+    dv = torch.empty((B, Nkv, C), dtype=v.dtype, device=v.device)
+    s = _shape(dO, v, v, dO, heads, 1.0)
+    g = _lib.AttnGradStrides()
+    g.do_bs, g.do_rs = _attn_view(dO)
+    g.dv_bs, g.dv_rs = _attn_view(dv)
+    g.dq_bs = g.dq_rs = g.dk_bs = g.dk_rs = 0
+    L = _lib.load()
+    ws = _probs_bwd_ws(L, s, v.device)
+    _lib.check(L.mos_attn_pv_bwd(_p(probs), _p(v), _p(dO), _p(dprobs), _p(dv), _p(ws), ctypes.byref(s), ctypes.byref(g),
+                                 _dt(v), _stream()), 'mos_attn_pv_bwd')
+    return dprobs, dv
+
+
+def attn_probs_bwd(q, k, probs, dprobs, heads, scale):
+    """Backward of attn_probs: q (B,Nq,C), k (B,Nkv,C) views, probs = what attn_probs returned, dprobs = the gradient that
+    reached the map (through attn_pv AND from whatever the controller's loss read) -> (dq (B,Nq,C), dk (B,Nkv,C))."""
+    _dev(q, k, probs, dprobs)
+    B, Nq, C = q.shape
+    Nkv = k.shape[1]
+    assert probs.shape == dprobs.shape == (B * heads, Nq, Nkv) and probs.dtype == q.dtype
+    probs = probs if probs.is_contiguous() else probs.contiguous()
+    dprobs = dprobs.to(probs.dtype)
+    dprobs = dprobs if dprobs.is_contiguous() else dprobs.contiguous()
+    dq = torch.empty((B, Nq, C), dtype=q.dtype, device=q.device)
+    dk = torch.empty((B, Nkv, C), dtype=k.dtype, device=k.device)
+    s = _shape(q, k, k, q, heads, scale)
+    g = _lib.AttnGradStrides()
+    g.dq_bs, g.dq_rs = _attn_view(dq)
+    g.dk_bs, g.dk_rs = _attn_view(dk)
+    g.do_bs = g.do_rs = g.dv_bs = g.dv_rs = 0
+    L = _lib.load()
+    ws = _probs_bwd_ws(L, s, q.device)
+    _lib.check(L.mos_attn_probs_bwd(_p(q), _p(k), _p(probs), _p(dprobs), _p(dq), _p(dk), _p(ws), ctypes.byref(s),
+                                    ctypes.byref(g), _dt(q), _stream()), 'mos_attn_probs_bwd')
+    return dq, dk
 
 
 # ------------------------------------------------------------------------------------------------

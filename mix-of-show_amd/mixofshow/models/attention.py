@@ -171,13 +171,9 @@ def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_i
 
 def _attention_through_probs(attn, q, e, cd, edit_probs):
     """softmax(scale q k^T) as a tensor -> edit_probs -> P' v (mos_attn_probs / mos_attn_pv): the controller boundary of the
-    reference with the full map, for controllers that do not declare the columns they read. Inference only."""
-    from mixofshow.hip import ops
-    if torch.is_grad_enabled() and (q.requires_grad or e.requires_grad):
-        raise NotImplementedError(
-            'materialised attention probabilities have no backward on the HIP path: a controller used in TRAINING must declare '
-            '`token_positions` (mixofshow.utils.ptp_util.AttentionStore does), and receives those probability columns with '
-            'autograd through them')
+    reference with the full map, for controllers that do not declare the columns they read. Differentiable since round 6
+    (mos_attn_probs_bwd / mos_attn_pv_bwd): the map reaches the controller WITH grad, as in the reference (edlora.py:81-83),
+    so a reference-side `AttentionStore(training=True)` object trains."""
     if e.shape[1] > 96:
         raise NotImplementedError(f'materialised probabilities are built for text keys (<= 96), got {e.shape[1]}')
     if _sites(attn.to_k, attn.to_v) is not None:
@@ -187,12 +183,12 @@ def _attention_through_probs(attn, q, e, cd, edit_probs):
     else:
         k = project(attn, 'k', [attn.to_k], e, cd)
         v = project(attn, 'v', [attn.to_v], e, cd)
-    probs = ops.attn_probs(q.detach(), k.detach(), attn.heads, attn.scale)
+    probs = F_hip.attn_probs(q, k, attn.heads, attn.scale)
     edited = edit_probs(probs)
     probs = probs if edited is None else edited
     if probs.dtype != v.dtype:
         probs = probs.to(v.dtype)
-    return ops.attn_pv(probs, v.detach(), attn.heads)
+    return F_hip.attn_pv(probs, v, attn.heads)
 
 
 def _check_plain(attn):

@@ -116,7 +116,9 @@ class EDLoRA_Control_AttnProcessor:
         (mixofshow/utils/ptp_util.py:22-108), prompt-to-prompt editors -- gets the reference's protocol verbatim: the dense
         (B*H, N, 77) probability tensor (mos_attn_probs), may store it or edit it in place (the eval-mode rule "second half of
         the CFG batch only", ptp_util.py:45-46, is the controller's own code), and what it returns goes into P.V (mos_attn_pv).
-        Inference only: under autograd this raises (declare `token_positions` for training-time controllers)."""
+        With autograd since round 6 (mos_attn_probs_bwd / mos_attn_pv_bwd): the map carries grad like the reference's, so its
+        own AttentionStore(training=True) + a loss on the stored maps trains; declaring `token_positions` remains the fast
+        path (no dense map)."""
 
     def __init__(self, cross_attention_idx, place_in_unet, controller, attention_op=None):
         self.cross_attention_idx = cross_attention_idx

@@ -237,7 +237,8 @@ class StableDiffusionPipeline:
         if hipgraph is None:
             hipgraph = hipgraph_util.sampling_default()
         hipgraph = (bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
-                    and not hasattr(self, 'controller') and not hipgraph_util.has_forward_hooks(self.unet))
+                    and not hasattr(self, 'controller') and not hipgraph_util.has_forward_hooks(self.unet)
+                    and not hipgraph_util.has_python_controllers(self.unet))
         graphed, ent, replay_from = None, None, 1
         if hipgraph and cross_attention_kwargs is None:
             # (model epoch: see RegionallyT2IAdapterPipeline.__call__ -- weights, derived weight copies, processor objects)

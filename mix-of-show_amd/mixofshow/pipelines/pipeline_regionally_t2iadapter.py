@@ -318,7 +318,8 @@ class RegionallyT2IAdapterPipeline(StableDiffusionPipeline):
         if hipgraph is None:
             hipgraph = hipgraph_util.sampling_default()
         hipgraph = (bool(hipgraph) and hipgraph_util.graphs_usable(device) and len(timesteps) >= 4
-                    and not hipgraph_util.has_forward_hooks(self.unet))
+                    and not hipgraph_util.has_forward_hooks(self.unet)
+                    and not hipgraph_util.has_python_controllers(self.unet))
         # The captured graph is kept ACROSS calls of the same shape (prompts of the same layout, same boxes, same
         # resolution): everything it reads besides (latents, t) -- prompt embeddings, region embeddings, adapter features,
         # the processors' K/V caches -- lives in static tensors that a later call refreshes in place (step 0 of every call

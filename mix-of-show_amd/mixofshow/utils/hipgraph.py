@@ -27,6 +27,19 @@ def has_forward_hooks(module):
     return any(m._forward_hooks or m._forward_pre_hooks for m in module.modules())
 
 
+def has_python_controllers(module):
+    """True if any attention layer reports to a controller that keeps Python-side state (stores or edits attention maps,
+    counts layers and steps: `revise_edlora_unet_attention_controller_forward(unet, controller)` with anything but a
+    pass-through). Such a controller runs at capture time only -- a replayed UNet call would leave its stored maps, its
+    `cur_step` / `between_steps` bookkeeping and its edits silently stale -- so the model must be called eagerly, however the
+    controller got there (pipe.set_controller or the public revise_* function)."""
+    for m in module.modules():
+        ctrl = getattr(getattr(m, 'processor', None), 'controller', None)
+        if ctrl is not None and not getattr(ctrl, 'is_passthrough', False):
+            return True
+    return False
+
+
 def model_epoch(module):
     """A value that changes whenever a captured graph of `module` may have gone stale: parameter / buffer storage (address,
     dtype) or content (tensor version counters: load_state_dict, in-place merges, optimiser steps). The graph bakes in not

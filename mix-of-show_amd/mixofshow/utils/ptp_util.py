@@ -12,6 +12,21 @@ out of scope (cv2 / IPython).
 import abc
 
 
+class EmptyControl:
+    """reference ptp_util.py:11-19: the no-op controller. `is_passthrough` tells the processor that it neither reads nor edits
+    the map, so no (B*H, N, 77) tensor is materialised for it and the sampling loop may replay a captured graph."""
+    is_passthrough = True
+
+    def step_callback(self, x_t):
+        return x_t
+
+    def between_steps(self):
+        return
+
+    def __call__(self, attn, is_cross, place_in_unet):
+        return attn
+
+
 class AttentionControl(abc.ABC):
 
     def __init__(self, low_resource, training):

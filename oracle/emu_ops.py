@@ -7,7 +7,7 @@ Emulations compute in fp32 from the (possibly half) inputs and round the result 
 """
 import torch
 
-EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_fwd_ex', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'attn_probs', 'attn_pv', 'region_attn_fwd',
+EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_fwd_ex', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'attn_probs', 'attn_pv', 'attn_probs_bwd', 'attn_pv_bwd', 'region_attn_fwd',
             'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
             'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
 PAD = 16
@@ -162,6 +162,27 @@ def attn_pv(probs, v, heads):
     B, Nkv, C = v.shape
     o = probs.float().reshape(B, heads, -1, Nkv) @ _heads(v, heads)
     return o.permute(0, 2, 1, 3).reshape(B, -1, C).to(v.dtype)
+
+
+def attn_pv_bwd(probs, v, dO, heads):
+    """dP' = dO V^T (dense, layer dtype), dV = P'^T dO: backward of torch.bmm(attention_probs, value) (edlora.py:83)."""
+    B, Nkv, C = v.shape
+    Pf = probs.float().reshape(B, heads, -1, Nkv)
+    dOh, vh = _heads(dO, heads), _heads(v, heads)
+    dP = (dOh @ vh.transpose(-1, -2)).reshape(B * heads, -1, Nkv).to(probs.dtype)
+    dv = (Pf.transpose(-1, -2) @ dOh).permute(0, 2, 1, 3).reshape(B, Nkv, C).to(v.dtype)
+    return dP, dv
+
+
+def attn_probs_bwd(q, k, probs, dprobs, heads, scale):
+    """softmax Jacobian + the two score GEMMs: backward of get_attention_scores (edlora.py:81)."""
+    B, Nq, C = q.shape
+    Nkv = k.shape[1]
+    P, dP = probs.float().reshape(B, heads, Nq, Nkv), dprobs.float().reshape(B, heads, Nq, Nkv)
+    dS = P * (dP - (P * dP).sum(-1, keepdim=True)) * scale
+    dq = (dS @ _heads(k, heads)).permute(0, 2, 1, 3).reshape(B, Nq, C).to(q.dtype)
+    dk = (dS.transpose(-1, -2) @ _heads(q, heads)).permute(0, 2, 1, 3).reshape(B, Nkv, C).to(k.dtype)
+    return dq, dk
 
 
 def region_attn_fwd(q, k_src, v_src, heads, scale, boxes, feat_h, feat_w):

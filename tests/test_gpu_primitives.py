@@ -286,6 +286,58 @@ def test_materialised_probabilities_split(ops, emu, dtype, B, H, Nq, Nkv, d):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,H,Nq,Nkv,d', [
+    (2, 8, 4096, 77, 40), (2, 8, 1024, 77, 80), (2, 8, 256, 77, 160), (2, 8, 64, 77, 160),     # the four UNet levels
+    (1, 8, 70, 77, 40), (3, 8, 33, 5, 80), (1, 8, 130, 96, 160), (1, 8, 64, 3, 40),           # ragged queries, few / max keys
+])
+def test_materialised_probabilities_backward(ops, emu, dtype, B, H, Nq, Nkv, d):
+    """mos_attn_pv_bwd / mos_attn_probs_bwd (round 6: the full-map controller boundary under autograd, reference edlora.py:81-83
+    with a training-time store) against (a) the per-primitive emulation and (b) torch's fp32 autograd of
+    softmax(scale q k^T) -> P' = edit(P) -> P' v with an extra loss that reads the map directly, as cal_attn_reg does; q / k / v
+    and dq / dk / dv as strided slices of fused projection buffers; the key-side sums are deterministic (two runs bit-equal)."""
+    from mixofshow.hip import functional as F_hip
+    C = H * d
+    g = torch.Generator(device='cpu').manual_seed(23)
+    q = torch.randn(B, Nq, C, generator=g).to('cuda', dtype)
+    kv = torch.randn(B, Nkv, 2 * C, generator=g).to('cuda', dtype)
+    k, v = kv[..., :C], kv[..., C:]                      # column slices of ONE fused projection output
+    dO = torch.randn(B, Nq, C, generator=g).to('cuda', dtype)
+    w_map = (torch.randn(B * H, Nq, Nkv, generator=g) * 0.3).to('cuda')          # d(loss)/dP read straight off the stored map
+    scale = d**-0.5
+    P = ops.attn_probs(q, k, H, scale)
+    dP, dv = ops.attn_pv_bwd(P, v, dO, H)
+    dP_r, dv_r = emu.attn_pv_bwd(P, v, dO, H)
+    _check(f'attn_pv_bwd.dP[{B}x{H}x{Nq}x{Nkv}x{d}]', dP, dP_r, dtype, ulps=2.0)
+    _check('attn_pv_bwd.dv', dv, dv_r, dtype, ulps=4.0)
+    dP2, dv2 = ops.attn_pv_bwd(P, v, dO, H)
+    assert torch.equal(dP, dP2) and torch.equal(dv, dv2)
+    dtot = (dP.float() + w_map).to(dtype)
+    dq, dk = ops.attn_probs_bwd(q, k, P, dtot, H, scale)
+    dq_r, dk_r = emu.attn_probs_bwd(q, k, P, dtot, H, scale)
+    _check('attn_probs_bwd.dq', dq, dq_r, dtype, ulps=4.0)
+    _check('attn_probs_bwd.dk', dk, dk_r, dtype, ulps=6.0)
+    dq2, dk2 = ops.attn_probs_bwd(q, k, P, dtot, H, scale)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2)
+    # the autograd pair against torch's own fp32 autograd of the same computation
+    qa, kva = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    Pa = F_hip.attn_probs(qa, kva[..., :C], H, scale)
+    assert Pa.requires_grad
+    oa = F_hip.attn_pv(Pa, kva[..., C:], H)
+    ((oa.float() * dO.float()).sum() + (Pa.float() * w_map).sum()).backward()
+    qf, kvf = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+
+    def hb(t):
+        return t.reshape(B, t.shape[1], H, d).permute(0, 2, 1, 3)
+    Pf = torch.softmax(hb(qf) @ hb(kvf[..., :C]).transpose(-1, -2) * scale, -1)
+    of = (Pf @ hb(kvf[..., C:])).permute(0, 2, 1, 3).reshape(B, Nq, C)
+    ((of * dO.float()).sum() + (Pf.reshape(B * H, Nq, Nkv) * w_map).sum()).backward()
+    for name, a, b in (('dq', qa.grad, qf.grad), ('dkv', kva.grad, kvf.grad)):
+        rel = ((a.float() - b).norm() / b.norm()).item()
+        print(f'[parity] full-map autograd {name} [{B}x{H}x{Nq}x{Nkv}x{d} {dtype}]: rel-L2 {rel:.3e}')
+        assert rel < (3e-2 if dtype == torch.bfloat16 else 5e-3), (name, rel)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,Nq,Nkv', [(2, 6144, 6144), (1, 200, 256), (2, 1000, 1536)])
 def test_attention_fwd_drifting_scores(ops, emu, dtype, B, Nq, Nkv):
     """The online softmax of attn_fwd_kernel (d = 40) on scores that DRIFT from key tile to key tile: a case in which every
@@ -820,7 +872,7 @@ def test_lora_gradient_finals_deferred_equal_immediate():
         torch.cuda.synchronize()
         return [p.grad.clone() for _, _, sites in layers for d, u, _ in sites for p in (d, u)]
 
-    for passes in (1, 2):
+    for passes in (1, 3):             # 3: both pinned staging slots of the eager job-table upload, and the unchanged-image skip
         a, b, c = run('immediate', passes), run('finals', passes), run('all', passes)
         assert all(torch.equal(x, y) for x, y in zip(a, b)), f'deferred final sums differ after {passes} pass(es)'
         assert all(torch.equal(x, y) for x, y in zip(a, c)), f'batched token reductions differ after {passes} pass(es)'

@@ -861,10 +861,40 @@ def test_full_probability_controllers_vs_reference_golden(emulated_hip, golden):
             y = attns[i](g['hs'][0][i].half(), encoder_hidden_states=ehs)
             torch.testing.assert_close(y.float(), g['outs_edit'][i], rtol=2e-2, atol=3e-3)
         assert edit.cur_step == g['edit_cur_step']
-    # training with such a controller is refused loudly (no backward through the materialised map)
-    x = g['hs'][0][0].half().requires_grad_(True)
-    with pytest.raises(NotImplementedError, match='token_positions'):
-        attns[0](x, encoder_hidden_states=ehs)
+
+
+def test_full_map_controller_trains_vs_reference_golden(emulated_hip, golden):
+    """VERDICT r05 missing #3: the reference gives the (B*H, N, 77) map WITH grad to any controller (edlora.py:81-83); its own
+    AttentionStore(training=True) keeps the maps and cal_attn_reg differentiates through them. Golden G3 was produced by exactly
+    that reference code (processor + store + EDLoRATrainer.cal_attn_reg, values and gradients). Here the PRODUCT's processor
+    hands its differentiable map (functional.attn_probs / attn_pv: mos_attn_probs_bwd / mos_attn_pv_bwd, emulated on the CPU)
+    to a full-map store that declares no token positions."""
+    from oracle import edlora_ref as R
+    from mixofshow.models.attention import Attention
+    from mixofshow.models.edlora import EDLoRA_Control_AttnProcessor
+    g = golden['control']
+    store = R.AttentionStoreRef(training=True)          # the reference's store protocol: full maps, no `token_positions`
+    store.num_att_layers = 4
+    assert not hasattr(store, 'token_positions')
+    hss = [h.clone().requires_grad_(True) for h in g['hs']]
+    outs = []
+    for i, (state, place) in enumerate(zip(g['states'], g['places'])):
+        C = hss[i].shape[-1]
+        a = Attention(C, cross_attention_dim=g['ehs'].shape[-1], heads=2, dim_head=C // 2)
+        a.load_state_dict(state)
+        a.set_processor(EDLoRA_Control_AttnProcessor(i, place, store))
+        outs.append(a(hss[i], encoder_hidden_states=g['ehs']))
+    for o, ref in zip(outs, g['outs']):
+        torch.testing.assert_close(o.float(), ref, rtol=2e-2, atol=2e-3)
+    maps = store.get_average_attention()
+    assert {k: len(v) for k, v in maps.items()} == g['n_stored'] and all(m.requires_grad for v in maps.values() for m in v)
+    reg = R.cal_attn_reg_ref({k: [m.float() for m in v] for k, v in maps.items()}, g['masks'], g['ids'], g['concept_ids'], 0.01, False)
+    torch.testing.assert_close(reg, g['reg_false'], rtol=2e-2, atol=1e-5)
+    total = reg + sum(o.float().square().mean() for o in outs)
+    grads = torch.autograd.grad(total, hss)
+    for a, b in zip(grads, g['grads']):
+        rel = (a.float() - b).norm() / b.norm()
+        assert rel < 3e-2, rel                       # half-precision layer against the reference's fp32 run
 
 
 @pytest.mark.parametrize('upsample', [False, True])
@@ -918,6 +948,37 @@ def test_sampling_hipgraph_default_and_hook_guard(monkeypatch):
     h.remove()
     assert not hg.has_forward_hooks(net)
     assert not hg.graphs_usable('cpu')
+
+
+def test_sampling_hipgraph_guard_sees_controllers_installed_through_the_public_function():
+    """a controller installed with `revise_edlora_unet_attention_controller_forward(pipe.unet, ctrl)` -- without
+    `pipe.set_controller` -- is neither a pipeline attribute nor a forward hook; its Python code would run at capture only.
+    The guard reads it off the UNet's processors: anything but a pass-through controller selects the eager loop."""
+    from mixofshow.models.edlora import (revise_edlora_unet_attention_controller_forward,
+                                         revise_edlora_unet_attention_forward)
+    import os
+    from mixofshow.utils.pretrained import load_unet
+    from mixofshow.utils import hipgraph as hg
+    from mixofshow.utils.ptp_util import AttentionStore, EmptyControl
+    unet = load_unet('synthetic://tiny')
+    revise_edlora_unet_attention_forward(unet)
+    assert not hg.has_python_controllers(unet)
+    revise_edlora_unet_attention_controller_forward(unet, None)                 # the reference's DummyController case
+    assert not hg.has_python_controllers(unet)
+    revise_edlora_unet_attention_controller_forward(unet, EmptyControl())       # reference ptp_util.py:11-19
+    assert not hg.has_python_controllers(unet)
+    revise_edlora_unet_attention_controller_forward(unet, AttentionStore(training=False))
+    assert hg.has_python_controllers(unet)
+
+    class Editor:                                                               # a prompt-to-prompt style editor, duck-typed
+        def __call__(self, attn, is_cross, place):
+            return attn * 0.5
+    revise_edlora_unet_attention_controller_forward(unet, Editor())
+    assert hg.has_python_controllers(unet)
+    revise_edlora_unet_attention_forward(unet)
+    assert not hg.has_python_controllers(unet)
+    src = open(os.path.join(os.path.dirname(hg.__file__), '..', 'pipelines', 'pipeline_edlora.py')).read()
+    assert 'has_python_controllers(self.unet)' in src
 
 
 # ---- VERDICT r03 item 8: the other LoRA placements of the reference (trainer_edlora.py:97-136) ------------------------------
