@@ -524,6 +524,27 @@ def run_train(args, rank, world, device):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     spread = [round(per_step[0], 2), round(statistics.median(per_step), 2), round(per_step[-1], 2)] if per_step else None
     _log(f'timed region: {args.steps} steps in {dt:.3f}s; device-side step ms min/median/max {spread}; clocks {clocks.summary()}')
+    allreduce = None
+    if world > 1:
+        # the one collective of the path, on its own -- the flat fp32 gradient bucket over RCCL/xGMI (latency-bound at
+        # 4.5 MB). Timed on a scratch copy so the optimiser state of the run is untouched; bus bandwidth = 2(N-1)/N x bytes / time.
+        scratch = engine.bucket.flat.clone()
+        for _ in range(5):
+            torch.distributed.all_reduce(scratch)
+        _sync_barrier(world)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_ar = 50
+        e0.record()
+        for _ in range(n_ar):
+            torch.distributed.all_reduce(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        us = _max_over_ranks(e0.elapsed_time(e1) * 1e3 / n_ar, world, device)
+        allreduce = dict(bytes=engine.bucket.nbytes, us=round(us, 1),
+                         busbw_gbps=round(2.0 * (world - 1) / world * engine.bucket.nbytes / (us * 1e-6) / 1e9, 2),
+                         peak_gbps_per_gpu=7 * 153.0, backend=torch.distributed.get_backend())
+        _log(f'gradient-bucket all-reduce: {allreduce}')
+        del scratch
     # profiled pass (same workload, same process): per-kernel HIP-event timings of the library kernels
     recs = []
     saved_graph, engine._graph = getattr(engine, '_graph', None), None   # events are recorded at launch: eager pass
@@ -545,7 +566,8 @@ def run_train(args, rank, world, device):
                     parallelism=f'dp{world}', grad_bucket_bytes=engine.bucket.nbytes, preset=args.preset,
                     hipgraph=graphed, graph_capture_s=capture_s, channels_last=bool(args.channels_last),
                     host_cores=os.cpu_count(), kernel_source_sha16=kernel_source_fingerprint(),
-                    box=box_info(device.index or 0), clocks_timed_region=clocks.summary(), **_tuning_switches()),
+                    box=box_info(device.index or 0), clocks_timed_region=clocks.summary(), allreduce=allreduce,
+                    **_tuning_switches()),
         roofline=roofline_from_profile(recs) if recs else None,
         attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_TRAINED_IMAGE, B, recs, 2) if recs else None,
         dominant_kernels_by_name=dominant_by_kernel_name(recs, 2) if recs else None,

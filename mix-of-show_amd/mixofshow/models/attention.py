@@ -100,16 +100,18 @@ def _sites(*linears):
     return s
 
 
-def project(attn, name, linears, x, cd):
-    """Fused projection of x through 1..3 Linear layers of `attn` (+ their LoRA branches): one GEMM."""
+def project(attn, name, linears, x, cd, residual=None):
+    """Fused projection of x through 1..3 Linear layers of `attn` (+ their LoRA branches): one GEMM (+ `residual` added to the
+    rounded result in its epilogue: bit-identical to the GEMM followed by a half add)."""
     need_wt = torch.is_grad_enabled() and (x.requires_grad or any(
         getattr(l, '_mos_lora', None) is not None for l in linears))
     W16, Wt16 = attn._mos_cache.weight(name, [l.weight for l in linears], cd, transposed=need_wt)
     b32 = attn._mos_cache.bias(name, [l.bias for l in linears])
     sites = _sites(*linears)
     assert sites is not None
-    y = F_hip.lora_linear(x, W16, Wt16, b32, sites)
+    y = F_hip.lora_linear(x, W16, Wt16, b32, sites, residual=residual)
     tap = getattr(attn, '_mos_tap', None)
+    assert tap is None or residual is None
     if tap is not None:
         # feature tap (gradient fusion): the fused GEMM bypasses nn.Linear.__call__, so forward hooks on
         # to_q/to_k/to_v/to_out.0 would never fire — report (module, input, output) per projection instead
@@ -137,6 +139,15 @@ def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_i
         else hidden_states.dtype
     x = hidden_states if hidden_states.dtype == cd else hidden_states.to(cd)
     pcols = None
+    # BasicTransformerBlock's `attn(norm(h)) + h` (round 6): the block leaves h here and the out-projection GEMM adds it in its
+    # epilogue, so the LayerNorm that follows reads ONE tensor and writes one. Taken only where it is exact: same dtype and
+    # shape as the layer output, no feature tap on the projections (gradient fusion records the bare to_out.0 output), no
+    # output rescaling. A processor that never gets here leaves the attribute in place and the block adds as before.
+    residual = attn.__dict__.pop('_mos_residual', None)
+    if residual is not None and not (residual.dtype == cd and out_dtype == cd and residual.shape == hidden_states.shape
+                                     and getattr(attn, '_mos_tap', None) is None and attn.rescale_output_factor == 1.0
+                                     and not attn.residual_connection):
+        residual = None
     if encoder_hidden_states is None:
         if _sites(attn.to_q, attn.to_k, attn.to_v) is not None:
             qkv = project(attn, 'qkv', [attn.to_q, attn.to_k, attn.to_v], x, cd)
@@ -162,7 +173,9 @@ def fused_attention_layer(attn, hidden_states, encoder_hidden_states=None, tok_i
             k = project(attn, 'k', [attn.to_k], e, cd)
             v = project(attn, 'v', [attn.to_v], e, cd)
             o, pcols = F_hip.attention(q, k, v, attn.heads, attn.scale, tok_idx=tok_idx)
-    out = project(attn, 'out', [attn.to_out[0]], o, cd)
+    out = project(attn, 'out', [attn.to_out[0]], o, cd, residual=residual)
+    if residual is not None:
+        attn.__dict__['_mos_residual_fused'] = True
     out = attn.to_out[1](out)
     if out.dtype != out_dtype:
         out = out.to(out_dtype)

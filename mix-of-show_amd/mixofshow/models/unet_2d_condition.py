@@ -200,6 +200,24 @@ class FeedForward(nn.Module):
         return linear_residual(self.net[2], x, residual)
 
 
+_attn_out_residual = os.environ.get('MOS_ATTN_OUT_RESIDUAL', '1') != '0'      # host-side A/B switch (read once)
+
+
+def _attn_plus_stream(attn, n, x, encoder_hidden_states, cak):
+    """(attn(n) + x, True) with the add inside the out-projection GEMM's epilogue when the layer's processor runs
+    mixofshow.models.attention.fused_attention_layer on half CUDA tensors; (attn(n), False) otherwise -- any other processor
+    never looks at the side channel, and the caller adds in the LayerNorm kernel as before (same rounding points either way)."""
+    offer = _attn_out_residual and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.shape == n.shape
+    if offer:
+        attn.__dict__['_mos_residual'] = x
+        attn.__dict__.pop('_mos_residual_fused', None)
+    a = attn(n, encoder_hidden_states=encoder_hidden_states, **cak)
+    if not offer:
+        return a, False
+    attn.__dict__.pop('_mos_residual', None)
+    return a, bool(attn.__dict__.pop('_mos_residual_fused', False))
+
+
 class BasicTransformerBlock(nn.Module):
 
     def __init__(self, dim, heads, dim_head, cross_attention_dim):
@@ -215,11 +233,13 @@ class BasicTransformerBlock(nn.Module):
         cak = cross_attention_kwargs if cross_attention_kwargs is not None else {}
         # x = attn1(norm1(x)) + x; x = attn2(norm2(x)) + x; x = ff(norm3(x)) + x  with each residual sum formed inside the
         # LayerNorm kernel that consumes it, and each bypass gradient added inside that norm's backward kernel
+        # Round 6: where the attention layer runs on the fused HIP path its out-projection GEMM adds the residual stream in its
+        # epilogue (`_attn_plus_stream`), so the next LayerNorm takes the sum as its only input.
         x, n = add_layer_norm(self.norm1, x)
-        a = self.attn1(n, encoder_hidden_states=None, **cak)
-        x, n = add_layer_norm(self.norm2, x, a)
-        a = self.attn2(n, encoder_hidden_states=encoder_hidden_states, **cak)
-        x, n = add_layer_norm(self.norm3, x, a)
+        a, summed = _attn_plus_stream(self.attn1, n, x, None, cak)
+        x, n = add_layer_norm(self.norm2, a) if summed else add_layer_norm(self.norm2, x, a)
+        a, summed = _attn_plus_stream(self.attn2, n, x, encoder_hidden_states, cak)
+        x, n = add_layer_norm(self.norm3, a) if summed else add_layer_norm(self.norm3, x, a)
         return self.ff(n, residual=x)
 
 

@@ -382,3 +382,62 @@ def test_conv1x1_residual_epilogue_matches_conv_plus_residual(gpu_branches):
     for a, b in zip(fused, plain):
         assert a.shape == b.shape and torch.equal(a, b)
     assert fused[0].is_contiguous(memory_format=cl)
+
+
+@pytest.mark.parametrize('cross_dim', [64])
+def test_transformer_block_attention_residual_in_the_out_projection_epilogue(gpu_branches, monkeypatch, cross_dim):
+    """Round 6: `attn(norm(h)) + h` of BasicTransformerBlock with the add in the epilogue of the
+    out-projection GEMM (mos_lora_linear_fwd_ex) instead of in the LayerNorm kernel that follows. Same rounding points, so the
+    block's output AND its gradients (input, LoRA factors) are bit-identical to the separate-add form; both attention layers of
+    a block take the epilogue; a processor that does not run the fused layer leaves the block on the old path."""
+    import mixofshow.hip.ops as ops
+    import mixofshow.models.unet_2d_condition as U
+    from mixofshow.models.edlora import EDLoRA_AttnProcessor, LoRALinearLayer
+    torch.manual_seed(0)
+    C, heads = 64, 8
+    blk = U.BasicTransformerBlock(C, heads, C // heads, cross_dim).half().requires_grad_(False)
+    blk.attn2.set_processor(EDLoRA_AttnProcessor(0))
+    loras = []
+    for name in ('to_q', 'to_k', 'to_v'):
+        for attn in (blk.attn1, blk.attn2):
+            loras.append(LoRALinearLayer(name, getattr(attn, name), rank=4, alpha=1.0))
+    for attn in (blk.attn1, blk.attn2):
+        loras.append(LoRALinearLayer('to_out.0', attn.to_out[0], rank=4, alpha=1.0))
+    with torch.no_grad():
+        for l in loras:
+            l.lora_up.weight.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(2, 48, C, generator=g).half()
+    ehs = torch.randn(2, 16, 77, cross_dim, generator=g).half()
+    wy = torch.randn(2, 48, C, generator=g).half()
+    calls = []
+    real = ops.linear_fwd_ex
+
+    def spy(x, W, A16, Bp16, bias, residual=None, **kw):
+        calls.append(residual is not None)
+        return real(x, W, A16, Bp16, bias, residual=residual, **kw)
+    monkeypatch.setattr(ops, 'linear_fwd_ex', spy)
+
+    def run(flag):
+        monkeypatch.setattr(U, '_attn_out_residual', flag)
+        calls.clear()
+        for l in loras:
+            l.lora_down.weight.grad = l.lora_up.weight.grad = None
+        x = x0.clone().requires_grad_(True)
+        y = blk(x, encoder_hidden_states=ehs)
+        (y * wy).float().sum().backward()
+        return [y.detach(), x.grad] + [None if p.grad is None else p.grad.clone() for l in loras for p in (l.lora_down.weight, l.lora_up.weight)], sum(calls)
+
+    fused, n_fused = run(True)
+    plain, n_plain = run(False)
+    assert n_fused == n_plain + 2                          # attn1 and attn2 out-projections took the residual epilogue
+    for a, b in zip(fused, plain):
+        assert a is not None and torch.equal(a, b)
+    assert '_mos_residual' not in blk.attn1.__dict__ and '_mos_residual' not in blk.attn2.__dict__
+
+    class Foreign:                                           # a processor outside the fused path: never sees the side channel
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None, **kw):
+            return hidden_states * 0.5
+    blk.attn1.set_processor(Foreign())
+    out, n = run(True)
+    assert n == n_plain + 1 and '_mos_residual' not in blk.attn1.__dict__

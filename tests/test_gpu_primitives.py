@@ -503,6 +503,8 @@ def test_region_attention_more_regions_than_one_launch_holds(ops, emu, fh, fw, d
         if r == R // 2:
             c0 = (rnd.randint(0, fw - 1) + 0.3) / fw
             fr.append([0.1, c0, 0.9, c0 + 0.4 / fw])              # collapses to zero area after ceil / floor
+        elif r in (0, 1, R - 2):
+            fr.append([0.1, 0.1, 0.45, 0.4 + 0.05 * (r % 3)])       # three boxes (first and last chunk) share one area
         elif r == R - 1:
             fr.append([0.55, 0.6, 1.0, 1.0])                        # a corner that (mostly) only the LAST chunk covers
         else:
