@@ -409,6 +409,15 @@ int mos_conv3x3_nhwc(const void* x, const void* w, const float* bias, const void
 int64_t mos_conv3x3_nhwc_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const void* tbias, const void* residual,
                         void* y, int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws, void* stream);
+/* 3x3 / STRIDE-2 convolution of the down-samplers (round 6; diffusers Downsample2D: UNet `padding=1`, VAE encoder
+ * `F.pad(x, (0, 1, 0, 1))` + `padding=0`), forward only, same operand layout as mos_conv3x3_nhwc:
+ *   x [B, Hin, Win, Cin] NHWC, w [Cout, 3, 3, Cin], bias fp32 or NULL, y [B, Hout, Wout, Cout]
+ *   pad_mode 1: Hout = (Hin - 1) / 2 + 1 (padding 1);  pad_mode 2: Hout = (Hin - 2) / 2 + 1 (zero row / column appended at the
+ *   bottom / right -- folded into the kernel's bounds, the padded copy is never materialised).
+ *   ws: mos_conv3x3_nhwc_workspace_bytes(B, Hout, Wout, Cin, Cout) bytes or NULL (split-K form of the low-resolution levels). */
+int mos_conv3x3_s2_nhwc(const void* x, const void* w, const float* bias, void* y, int B, int Hin, int Win, int Cin, int Cout,
+                        int pad_mode, int dtype, void* ws, void* stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Row-wise operators of the transformer blocks around the attention layers:

@@ -524,11 +524,20 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(Att
     const int h = blockIdx.x % a.H;
     const int rest = blockIdx.x / a.H;
     const int qb = rest % a.nqb, b = rest / a.nqb;
-    const int qi = qb * 128 + wave * 32 + l31;
+    // Round 6: a workgroup's 128 queries are a 2-D TILE of the feature map (8 rows x 16 columns; a wave = 2 rows), not 128
+    // consecutive tokens. Regions are boxes: a run of consecutive tokens spans whole rows and so touches every box that shares
+    // those rows (the shipped example's three vertical strips: all of them, plus the context prompt -- 49 KB of K / V staged per
+    // workgroup at d = 40 for 20 KB of its own q / o), whereas a tile lies inside one or two boxes: which sources a workgroup
+    // stages is an exact rectangle test, the context prompt is staged only if some cell of the tile is uncovered, and the small
+    // levels (d = 160: one source resident at a time) make one or two passes instead of one per source.
+    const int ntx = (reg.feat_w + 15) >> 4;
+    const int ty0 = (qb / ntx) * 8, tx0 = (qb - (qb / ntx) * ntx) * 16;
+    const int y = ty0 + wave * 2 + (l31 >> 4), x = tx0 + (l31 & 15);
+    const bool qvalid = y < reg.feat_h && x < reg.feat_w;
+    const int qi = qvalid ? y * reg.feat_w + x : a.Nq;      // (>= Nq: masked everywhere below)
     const int S = reg.n_regions + 1;
 
     // ---- which sources does this lane / wave / block use ------------------------------------------------------------
-    const int y = qi / reg.feat_w, x = qi - y * reg.feat_w;
     unsigned inbits = 0;
     int cnt = 0;
     for (int r = 0; r < reg.n_regions; ++r) {
@@ -543,19 +552,18 @@ __global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(Att
     unsigned wave_need = 0;
     for (int j = 0; j < S; ++j) wave_need |= (__ballot((inbits >> j) & 1u) != 0ull) ? (1u << j) : 0u;
     // Sources this BLOCK stages: decided from the box table alone (scalar arithmetic, no vote / barrier before the loads are
-    // issued): the block's queries are feature rows y_first..y_last (columns x_first..x_last when it sits in one row); a
-    // region is staged when its box meets that range -- a superset of what the waves use (they skip per wave below) --
-    // and the context prompt always.
+    // issued): a region is staged when its box meets the tile's rectangle (exact), the context prompt unless ONE box of this
+    // launch contains the whole tile (then no cell of it is uncovered; a superset otherwise -- the waves skip per wave below).
     unsigned need = accumulate ? 0u : 1u;
     {
-        const int qf0 = qb * 128, ql0 = min(qb * 128 + 127, a.Nq - 1);
-        const int y_first = qf0 / reg.feat_w, y_last = ql0 / reg.feat_w;
-        const int x_first = qf0 - y_first * reg.feat_w, x_last = ql0 - y_last * reg.feat_w;
+        const int ty1 = min(ty0 + 8, reg.feat_h), tx1 = min(tx0 + 16, reg.feat_w);      // tile = [ty0, ty1) x [tx0, tx1)
+        bool covered = false;
         for (int r = 0; r < reg.n_regions; ++r) {
-            bool hit = reg.box[r][0] <= y_last && reg.box[r][2] > y_first && reg.box[r][3] > reg.box[r][1];
-            if (y_first == y_last) hit = hit && reg.box[r][1] <= x_last && reg.box[r][3] > x_first;
+            const bool hit = reg.box[r][0] < ty1 && reg.box[r][2] > ty0 && reg.box[r][1] < tx1 && reg.box[r][3] > tx0;
             need |= hit ? (2u << r) : 0u;
+            covered = covered || (reg.box[r][0] <= ty0 && reg.box[r][2] >= ty1 && reg.box[r][1] <= tx0 && reg.box[r][3] >= tx1);
         }
+        if (covered) need &= ~1u;      // (also with a whole-list count map: covered by a box of this launch => total count >= 1)
     }
     // constant parts of the images: K pad columns [D, DK) = 0, V^T ones row (row sums), for every resident slot (disjoint
     // from what the staging stores write: made visible by the barrier that follows the first staging)
@@ -1587,6 +1595,7 @@ template <typename T, int D>
 int launch_region(const void* q, const void* k, const void* v, void* o, const mos_attn_shape* s,
                   const mos_region_desc* reg, const unsigned char* total_count, int accumulate, hipStream_t st) {
     AttnArgs a = make_args(q, k, v, o, nullptr, nullptr, 0, nullptr, s, 128);
+    a.nqb = ((reg->feat_w + 15) / 16) * ((reg->feat_h + 7) / 8);        // 8 x 16 query tiles of the feature map
     const dim3 grid((unsigned)(a.H * a.nqb * a.B));
     const size_t lds = RG<D>::lds_bytes(sizeof(T));
     set_lds(&region_attn_kernel<T, D>, lds);

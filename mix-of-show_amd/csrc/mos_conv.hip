@@ -40,6 +40,7 @@ struct ConvArgs {
     int B, H, Wd, Cin, Cout;      // Wd = image width
     int M, mt, nt, cpt;           // M = B*H*W ; cpt = Cin / 64 channel chunks per tap
     int up;                       // 1: the input is read through a nearest 2x upsample (x is (B, H/2, W/2, Cin))
+    int Hin, Win;                 // stride-2 form only: the source image size (H, Wd are the OUTPUT size)
     int ksplit, kt_per;           // split-K form: K tiles [z * kt_per, (z + 1) * kt_per) per workgroup, z < ksplit
     float* partial;               // split-K form: fp32 partial sums [ksplit][M][Cout]
 };
@@ -57,8 +58,14 @@ __device__ __forceinline__ void wait_vmcnt_then_barrier() {
 // slab); each workgroup leaves its fp32 partial tile in `partial[z]`, conv_splitk_reduce_kernel sums them in z order
 // (deterministic) and applies the epilogue. All m-tiles of one (n-tile, K range) run on ONE XCD, back to back: its weight
 // slice is fetched into that L2 once.
-template <typename T, int BM, int BN, bool UP, int NS, bool SPLIT = false>
+// S2 (round 6): the 3x3 / STRIDE 2 convolutions of the down-samplers on the same kernel -- 1: padding 1 (diffusers Downsample2D of
+// the UNet), 2: padding 0 on a map padded by one row / column of zeros at the bottom / right (the VAE encoder's asymmetric pad,
+// F.pad(x, (0, 1, 0, 1)): folded into the bounds, the padded copy is never made). Output pixel (y, x) reads source pixel
+// (2y + ky - P, 2x + kx - P), P = 1 / 0: only the per-pixel base offset, the nine validity bits and the tap delta change.
+template <typename T, int BM, int BN, bool UP, int NS, bool SPLIT = false, int S2 = 0>
 __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
+    static_assert(!(UP && S2), "upsampled input and stride 2 exclude each other");
+    constexpr int ST = S2 ? 2 : 1, PD = S2 == 2 ? 0 : 1;
     typedef typename MT<T>::v8 v8;
     constexpr int MI = BM / 32, NJ = BN / 32;
     constexpr int XCH = BM * 8 / 256, WCH = BN * 8 / 256;
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     const int n0 = n_tile * BN, m0 = m_tile * BM;
     const int M = a.M, N = a.Cout, C = a.Cin, H = a.H, Wd = a.Wd;
     const int K = 9 * C;
-    const int Hs = UP ? H / 2 : H, Ws_ = UP ? Wd / 2 : Wd;     // source image size
+    const int Hs = S2 ? a.Hin : (UP ? H / 2 : H), Ws_ = S2 ? a.Win : (UP ? Wd / 2 : Wd);     // source image size
 
     const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((int64_t)a.B * Hs * Ws_ * C * (int64_t)sizeof(T)));
     const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * K + K) * (int64_t)sizeof(T)));
@@ -111,11 +118,11 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
         if (m < M) {
             const int b = m / (H * Wd), p = m - b * (H * Wd);
             py[i] = p / Wd; px[i] = p - py[i] * Wd;
-            rowoff[i] = UP ? b * Hs : (((b * Hs + py[i]) * Ws_ + px[i]) * C + cc8) * (int)sizeof(T);
+            rowoff[i] = UP ? b * Hs : (((b * Hs + ST * py[i]) * Ws_ + ST * px[i]) * C + cc8) * (int)sizeof(T);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int yy = py[i] + t / 3 - 1, xx = px[i] + t % 3 - 1;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < Wd) tapmask[i] |= 1u << t;
+                const int yy = ST * py[i] + t / 3 - PD, xx = ST * px[i] + t % 3 - PD;
+                if (yy >= 0 && yy < (S2 ? Hs : H) && xx >= 0 && xx < (S2 ? Ws_ : Wd)) tapmask[i] |= 1u << t;
             }
         } else {
             py[i] = -100000; px[i] = 0; rowoff[i] = 0;
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
 
     auto issue_tile = [&](int kt, int buf) {   // tile kt -> LDS buffer buf; wave w's i-th piece = slots (4 i + w) * 64 ..
         const bool live = kt < nk;             // ring only: tiles past the end are issued out of range (zeros, no traffic)
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int dy = tap / 3 - PD, dx = tap - (tap / 3) * 3 - PD;
         T* xs = Xs + buf * BM * CBK + wave * 512;
         T* ws = Ws + buf * BN * CBK + wave * 512;
         const int delta = ((dy * Ws_ + dx) * C + cch * CBK) * (int)sizeof(T);      // non-upsampled source: linear in the tap
@@ -538,16 +545,16 @@ inline int conv_ksplit(int M, int Cout, int Cin, int* kt_per) {
     return (nk + per - 1) / per;
 }
 
-template <typename T, int BM, int BN, bool UP>
+template <typename T, int BM, int BN, bool UP, int S2 = 0>
 int launch_conv_split(ConvArgs a, hipStream_t st) {
     constexpr int NS = 3;
     const size_t lds = (size_t)NS * (BM + BN) * CBK * sizeof(T);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN, UP, NS, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN, UP, NS, true, S2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     a.mt = (a.M + BM - 1) / BM;
     a.nt = (a.Cout + BN - 1) / BN;
     const int units8 = (a.nt * a.ksplit + 7) / 8;
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, BM, BN, UP, NS, true>), dim3(8 * units8 * a.mt), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, BM, BN, UP, NS, true, S2>), dim3(8 * units8 * a.mt), dim3(256), lds, st, a);
     int rc = mos_check_launch("conv3x3_nhwc(split-K)");
     if (rc) return rc;
     const int64_t chunks = (int64_t)a.M * (a.Cout / 8);
@@ -555,18 +562,43 @@ int launch_conv_split(ConvArgs a, hipStream_t st) {
     return mos_check_launch("conv_splitk_reduce");
 }
 
-template <typename T, int BM, int BN, bool UP, int NS>
+template <typename T, int BM, int BN, bool UP, int NS, int S2 = 0>
 int launch_conv_cfg2(ConvArgs a, hipStream_t st) {
     size_t lds = (size_t)NS * (BM + BN) * CBK * sizeof(T);
     const size_t stage = (size_t)BM * (BN + 8) * sizeof(T);
     if (stage > lds) lds = stage;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN, UP, NS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_nhwc_kernel<T, BM, BN, UP, NS, false, S2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     a.mt = (a.M + BM - 1) / BM;
     a.nt = (a.Cout + BN - 1) / BN;
     const int mt8 = (a.mt + 7) / 8 * 8;
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, BM, BN, UP, NS>), dim3(mt8 * a.nt), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, BM, BN, UP, NS, false, S2>), dim3(mt8 * a.nt), dim3(256), lds, st, a);
     return mos_check_launch("conv3x3_nhwc");
+}
+
+// stride-2 form (down-samplers): raster kernel only (the halo form's LDS image assumes unit stride). Tiles as the unsplit
+// stride-1 dispatch chooses them; the low-resolution UNet down-samplers (<= 320 tiles, deep K) take the split-K form.
+template <typename T, int S2>
+int launch_conv_s2(ConvArgs a, hipStream_t st) {
+    char key[112];
+    int kt_per = 0;
+    const int ks = a.partial != nullptr ? conv_ksplit(a.M, a.Cout, a.Cin, &kt_per) : 1;
+    snprintf(key, sizeof(key), "%s B%d %dx%d Cin%d Cout%d stride2%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", a.B, a.H, a.Wd,
+             a.Cin, a.Cout, S2 == 2 ? " pad(0,1,0,1)" : "", ks > 1 ? " splitK" : "");
+    MosProfScope prof(st, "conv3x3", key, 2.0 * a.M * (double)a.Cout * 9.0 * a.Cin,
+                      2.0 * ((double)a.B * a.Hin * a.Win * a.Cin + 9.0 * a.Cin * a.Cout + (double)a.M * a.Cout));
+    if (ks > 1) {
+        a.ksplit = ks; a.kt_per = kt_per;
+        return launch_conv_split<T, 64, 64, false, S2>(a, st);
+    }
+    int bn = (a.Cout % 128 == 0) ? 128 : 64, bm = 128;
+    auto tiles = [&](int m, int n) { return (int64_t)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
+    if (tiles(bm, bn) < 384) bm = 64;
+    if (tiles(bm, bn) < 256 && bn == 128) bn = 64;
+    if (bm == 128 && bn == 128) return launch_conv_cfg2<T, 128, 128, false, 2, S2>(a, st);
+    if (bm == 128) return launch_conv_cfg2<T, 128, 64, false, 2, S2>(a, st);
+    if (bn == 128) return launch_conv_cfg2<T, 64, 128, false, 2, S2>(a, st);
+    return launch_conv_cfg2<T, 64, 64, false, 2, S2>(a, st);
 }
 
 template <typename T, int BM, int BN, int NS>
@@ -660,11 +692,34 @@ int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const v
     ConvArgs a;
     a.X = x; a.W = w; a.bias = bias; a.tbias = tbias; a.R = residual; a.Y = y;
     a.B = B; a.H = H; a.Wd = W; a.Cin = Cin; a.Cout = Cout; a.M = B * H * W; a.cpt = Cin / 64; a.up = upsample2x ? 1 : 0;
-    a.mt = a.nt = 0;
+    a.mt = a.nt = 0; a.Hin = H; a.Win = W;
     a.ksplit = 1; a.kt_per = 0; a.partial = (float*)ws;
     if (dtype == MOS_F16) return launch_conv<f16_t>(a, (hipStream_t)stream);
     if (dtype == MOS_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_conv3x3_nhwc: dtype %d", dtype);
+}
+
+int mos_conv3x3_s2_nhwc(const void* x, const void* w, const float* bias, void* y, int B, int Hin, int Win, int Cin, int Cout,
+                        int pad_mode, int dtype, void* ws, void* stream) {
+    MOS_REQUIRE(x && w && y, "mos_conv3x3_s2_nhwc: NULL argument");
+    MOS_REQUIRE(B > 0 && Hin > 1 && Win > 1 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 8 == 0,
+                "mos_conv3x3_s2_nhwc: B=%d Hin=%d Win=%d Cin=%d Cout=%d (need Cin %% 64 == 0, Cout %% 8 == 0)", B, Hin, Win, Cin, Cout);
+    MOS_REQUIRE(pad_mode == 1 || pad_mode == 2, "mos_conv3x3_s2_nhwc: pad_mode %d (1: padding 1; 2: zero row / column at bottom / right)",
+                pad_mode);
+    // output size of a 3x3 / stride-2 window: padding 1 -> floor((Hin - 1) / 2) + 1; (0, 1, 0, 1) pad -> floor((Hin - 2) / 2) + 1
+    const int H = pad_mode == 1 ? (Hin - 1) / 2 + 1 : (Hin - 2) / 2 + 1, W = pad_mode == 1 ? (Win - 1) / 2 + 1 : (Win - 2) / 2 + 1;
+    MOS_REQUIRE((int64_t)B * Hin * Win * (int64_t)Cin * 2 < (1ll << 31) && (int64_t)B * H * W * (int64_t)Cout * 2 < (1ll << 31) &&
+                    (int64_t)Cout * 9 * Cin * 2 < (1ll << 31),
+                "mos_conv3x3_s2_nhwc: tensor exceeds the 2 GiB range of one buffer descriptor");
+    ConvArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.tbias = nullptr; a.R = nullptr; a.Y = y;
+    a.B = B; a.H = H; a.Wd = W; a.Cin = Cin; a.Cout = Cout; a.M = B * H * W; a.cpt = Cin / 64; a.up = 0;
+    a.mt = a.nt = 0; a.Hin = Hin; a.Win = Win;
+    a.ksplit = 1; a.kt_per = 0; a.partial = (float*)ws;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MOS_F16) return pad_mode == 1 ? launch_conv_s2<f16_t, 1>(a, st) : launch_conv_s2<f16_t, 2>(a, st);
+    if (dtype == MOS_BF16) return pad_mode == 1 ? launch_conv_s2<bf16_t, 1>(a, st) : launch_conv_s2<bf16_t, 2>(a, st);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_conv3x3_s2_nhwc: dtype %d", dtype);
 }
 
 }  // extern "C"

@@ -1101,6 +1101,36 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
     return _Conv3x3.apply(x, w_fwd, w_bwd, bias32, tbias, residual, bool(upsample))
 
 
+_conv_s2_enabled = _os.environ.get('MOS_CONV3X3_S2', '1') != '0'      # host-side A/B switch (read once)
+
+
+def conv3x3_stride2(conv, x, pad_bottom_right=False):
+    """The down-samplers' 3x3 / stride-2 convolution (diffusers Downsample2D): `conv(x)` for padding 1 (UNet), or
+    `conv(F.pad(x, (0, 1, 0, 1)))` for padding 0 (VAE encoder) WITHOUT building the padded copy. HIP path (round 6,
+    mos_conv3x3_s2_nhwc: the raster implicit-GEMM kernel with stride-2 addressing): device tensors, half activations or half
+    autocast, frozen weights, no gradient needed for x (forward only: the frozen VAE encoder, sampling); anything else -- the
+    UNet down-samplers inside a training step need d/dx -- runs the torch ops."""
+    half = x.dtype in (torch.float16, torch.bfloat16)
+    ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
+    want_pad = (0, 0) if pad_bottom_right else (1, 1)
+    ok = (_conv_s2_enabled and _conv_enabled and x.is_cuda and (half or ac) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+          and conv.padding == want_pad and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0
+          and conv.out_channels % 8 == 0 and _frozen(conv.weight, conv.bias) and x.dim() == 4 and x.shape[2] > 1 and x.shape[3] > 1
+          and not conv._forward_hooks and not conv._forward_pre_hooks
+          and not (torch.is_grad_enabled() and x.requires_grad))
+    if not ok:
+        if pad_bottom_right:
+            x = torch.nn.functional.pad(x, (0, 1, 0, 1))
+        return conv(x)
+    dt = x.dtype if half else torch.get_autocast_dtype('cuda')
+    cache = conv.__dict__.get('_mos_conv_cache')
+    if cache is None:
+        cache = _ConvWeights()
+        object.__setattr__(conv, '_mos_conv_cache', cache)
+    w_fwd, _, bias32 = cache.get(conv, dt, False)
+    return ops.conv3x3_s2_nhwc(_as_nhwc(x, dt), w_fwd, bias32, pad_mode=2 if pad_bottom_right else 1)
+
+
 _conv_enabled = _os.environ.get('MOS_CONV3X3', '1') != '0'
 _conv1x1_enabled = _os.environ.get('MOS_CONV1X1', '1') != '0'
 _conv_min_pixels = int(_os.environ.get('MOS_CONV3X3_MIN_PIXELS', 0))

@@ -175,6 +175,7 @@ SIGNATURES = {
     'mos_groupnorm_silu_bwd_nhwc_res': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_conv3x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_conv3x3_nhwc_workspace_bytes': (_i64, [_i, _i, _i, _i, _i]),
+    'mos_conv3x3_s2_nhwc': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mos_conv3x3_nhwc_ws': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'mos_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     'mos_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -712,6 +712,26 @@ def single_head_attention_nograd(q, k, v, scale):
 # ------------------------------------------------------------------------------------------------
 # 3x3 convolution on channels-last activations (implicit GEMM) — caller-side operator
 # ------------------------------------------------------------------------------------------------
+def conv3x3_s2_nhwc(x, w_ohwi, bias=None, pad_mode=1, split_k=True):
+    """3x3 / stride-2 convolution (forward): x (B, Cin, Hin, Win) half, channels_last; w_ohwi (Cout, 3, 3, Cin).
+    pad_mode 1: padding 1 (UNet Downsample2D); 2: the VAE encoder's F.pad(x, (0, 1, 0, 1)) + padding 0, without the padded copy."""
+    _dev(x, w_ohwi, bias)
+    B, Cin, Hin, Win = x.shape
+    assert _is_nhwc(x) or x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_s2_nhwc needs channels_last'
+    Cout = w_ohwi.shape[0]
+    assert w_ohwi.shape == (Cout, 3, 3, Cin) and w_ohwi.is_contiguous() and w_ohwi.dtype == x.dtype and pad_mode in (1, 2)
+    H, W = ((Hin - 1) // 2 + 1, (Win - 1) // 2 + 1) if pad_mode == 1 else ((Hin - 2) // 2 + 1, (Win - 2) // 2 + 1)
+    y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.is_contiguous()
+    L = _lib.load()
+    nbytes = L.mos_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout) if split_k else 0
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device) if nbytes > 0 else None
+    _lib.check(L.mos_conv3x3_s2_nhwc(_p(x), _p(w_ohwi), _p(bias), _p(y), B, Hin, Win, Cin, Cout, int(pad_mode), _dt(x), _p(ws),
+                                     _stream()), 'mos_conv3x3_s2_nhwc')
+    return y
+
+
 def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False, split_k=True):
     """x: (B, Cin, H, W) half tensor in channels_last memory format; w_ohwi: (Cout, 3, 3, Cin) contiguous half;
     bias fp32 (Cout,); tbias (B, Cout) half; residual like the output. Returns (B, Cout, H', W') channels_last

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from mixofshow.hip.functional import (add_layer_norm, conv1x1, conv3x3, geglu, group_norm_act, linear_geglu,  # noqa: F401
+from mixofshow.hip.functional import (add_layer_norm, conv1x1, conv3x3, conv3x3_stride2, geglu, group_norm_act, linear_geglu,  # noqa: F401
                                        linear_residual)
 from mixofshow.models.attention import Attention
 
@@ -159,9 +159,8 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=padding)
 
     def forward(self, x):
-        if self.padding == 0:  # VAE encoder: asymmetric pad
-            x = F.pad(x, (0, 1, 0, 1))
-        return self.conv(x)
+        # VAE encoder (padding 0): the asymmetric F.pad(x, (0, 1, 0, 1)) is folded into the kernel's bounds on the HIP path
+        return conv3x3_stride2(self.conv, x, pad_bottom_right=self.padding == 0)
 
 
 class Upsample2D(nn.Module):

@@ -9,7 +9,7 @@ import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_fwd_ex', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'attn_probs', 'attn_pv', 'attn_probs_bwd', 'attn_pv_bwd', 'region_attn_fwd',
             'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
-            'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc')
+            'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc', 'conv3x3_s2_nhwc')
 PAD = 16
 
 
@@ -356,3 +356,13 @@ def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=Fal
     if residual is not None:
         y = (y.float() + residual.float()).to(x.dtype)
     return y.contiguous(memory_format=torch.channels_last)
+
+
+def conv3x3_s2_nhwc(x, w_ohwi, bias=None, pad_mode=1, split_k=True):
+    """fp32 3x3 / stride-2 convolution of the half inputs, rounded once. pad_mode 1: padding 1; 2: F.pad(x, (0, 1, 0, 1)), padding 0."""
+    import torch.nn.functional as F
+    xf = x.float()
+    if pad_mode == 2:
+        xf = F.pad(xf, (0, 1, 0, 1))
+    y = F.conv2d(xf, w_ohwi.float().permute(0, 3, 1, 2), bias, stride=2, padding=1 if pad_mode == 1 else 0)
+    return y.to(x.dtype).contiguous(memory_format=torch.channels_last)

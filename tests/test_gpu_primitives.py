@@ -966,6 +966,45 @@ def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('pad_mode', [1, 2])
+@pytest.mark.parametrize('B,Cin,Cout,Hin,Win', [
+    (2, 320, 320, 64, 96),       # UNet down-sampler of a 512x768 sample, level 0 -> 1
+    (4, 640, 640, 32, 32),       # level 1 -> 2, training batch
+    (2, 1280, 1280, 16, 24),     # level 2 -> 3: 8 x 12 output, split-K form
+    (1, 128, 128, 256, 256),     # VAE encoder stage (128 x 128 tiles)
+    (2, 256, 256, 128, 120),     # VAE encoder stage 2
+    (1, 512, 512, 64, 64),       # VAE encoder stage 3
+    (1, 64, 72, 33, 47),         # odd sizes, Cout not a multiple of the tile
+    (1, 64, 8, 2, 3),            # smallest map
+])
+def test_conv3x3_stride2_nhwc(ops, emu, dtype, pad_mode, B, Cin, Cout, Hin, Win):
+    """The down-samplers' 3x3 / stride-2 convolution on the raster implicit-GEMM kernel (round 6, mos_conv3x3_s2_nhwc) against
+    fp32 torch conv2d on the same half operands: padding 1 (UNet Downsample2D) and the VAE encoder's F.pad(x, (0, 1, 0, 1)) +
+    padding 0, whose padded copy the kernel never builds."""
+    g = torch.Generator(device='cpu').manual_seed(33)
+    x = torch.randn(B, Cin, Hin, Win, generator=g).to('cuda', dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to('cuda', dtype)
+    bias = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    w_fwd = w.permute(0, 2, 3, 1).contiguous()
+    y = ops.conv3x3_s2_nhwc(x, w_fwd, bias, pad_mode=pad_mode)
+    y_ref = emu.conv3x3_s2_nhwc(x, w_fwd, bias, pad_mode=pad_mode)
+    assert y.shape == y_ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    _check(f'conv3x3 stride 2 pad_mode {pad_mode} [{B}x{Cin}->{Cout}x{Hin}x{Win}]', y, y_ref, dtype)
+    from mixofshow.hip import lib as _lib
+    if _lib.load().mos_conv3x3_nhwc_workspace_bytes(B, y.shape[2], y.shape[3], Cin, Cout) > 0:
+        y1 = ops.conv3x3_s2_nhwc(x, w_fwd, bias, pad_mode=pad_mode, split_k=False)
+        _check('conv3x3 stride 2: split-K vs unsplit', y, y1, dtype, ulps=1.0)
+    # through the module path (diffusers Downsample2D semantics), no gradient needed for x
+    from mixofshow.models.unet_2d_condition import Downsample2D
+    if Cin == Cout:
+        ds = Downsample2D(Cin, padding=1 if pad_mode == 1 else 0).to('cuda', dtype).requires_grad_(False)
+        with torch.no_grad():
+            ds.conv.weight.copy_(w)
+            ds.conv.bias.copy_(bias)
+            _check('Downsample2D forward (HIP path)', ds(x), y_ref, dtype)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('B,Cin,Cout,H,W,extras', [
     (4, 320, 320, 64, 64, 'tr'),      # level-0 ResNet conv1 (+temb) / conv2 (+residual)     halo form, 8 x 16 x 64 tiles
     (4, 640, 640, 32, 32, 't'),       # level 1                                              halo form

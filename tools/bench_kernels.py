@@ -85,6 +85,20 @@ def blas_reference(shapes, dtype, iters):
         print(f"{f'M{M} N{N} K{K}':30s} {us:14.1f} {fl / us / 1e6:9.1f} {us2:12.1f} {fl / us2 / 1e6:9.1f}")
 
 
+def blas_dx_reference(shapes, dtype, iters):
+    """Backward-data GEMMs of frozen Linear layers that still run on hipBLASLt through autograd (dX = dY . W, "NN"): the
+    feed-forward and CLIP MLP projections. Against the library's GEMM on the cached transposed weight (dX = dY . (W^T)^T)."""
+    print(f"{'dX = dY[M,N] . W[N,K]':34s} {'hipBLASLt us':>13s} {'TFLOP/s':>9s} {'libmos us':>11s} {'TFLOP/s':>9s}")
+    for M, N, K in shapes:
+        dy = torch.randn(M, N, device='cuda', dtype=dtype)
+        W = torch.randn(N, K, device='cuda', dtype=dtype) / math.sqrt(N)
+        Wt = W.t().contiguous()
+        t_b = _timed(lambda: torch.matmul(dy, W), iters)
+        t_m = _timed(lambda: ops.linear_fwd(dy, Wt), iters)
+        fl = 2.0 * M * N * K
+        print(f"{f'M{M} N{N} K{K}':34s} {t_b:13.1f} {fl / t_b / 1e6:9.1f} {t_m:11.1f} {fl / t_m / 1e6:9.1f}")
+
+
 def conv_reference(shapes, dtype, iters, ref=True):
     """3x3 convolutions of the SD-1.5 UNet / VAE: the implicit-GEMM kernel vs MIOpen (torch conv2d, channels_last), forward
     and backward-data, one event pair around `iters` back-to-back launches."""
@@ -119,6 +133,21 @@ def conv_reference(shapes, dtype, iters, ref=True):
             t_rb = timed(lambda: torch.autograd.grad(yg, xg, dy, retain_graph=True))
         fl = 2.0 * B * H * W * Cout * 9 * Cin
         print(f"{f'B{B} {Cin}->{Cout} {H}x{W}':34s} {t_mf:9.1f} {t_rf:11.1f} {t_mb:9.1f} {t_rb:11.1f} {fl / t_mf / 1e6:9.1f}")
+
+
+def conv_s2_reference(shapes, dtype, iters):
+    """3x3 / stride-2 convolutions of the down-samplers: mos_conv3x3_s2_nhwc vs MIOpen (torch conv2d; VAE: + the F.pad copy)."""
+    print(f"{'conv3x3 stride 2  B C HinxWin pad':40s} {'mos':>9s} {'torch':>9s} {'mos TF/s':>9s}")
+    for B, C, Hin, Win, pad_mode in shapes:
+        x = torch.randn(B, C, Hin, Win, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
+        conv = torch.nn.Conv2d(C, C, 3, stride=2, padding=1 if pad_mode == 1 else 0).to('cuda', dtype).to(memory_format=torch.channels_last)
+        w_fwd = conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+        b32 = conv.bias.detach().float()
+        with torch.no_grad():
+            t_m = _timed(lambda: ops.conv3x3_s2_nhwc(x, w_fwd, b32, pad_mode=pad_mode), iters)
+            t_r = _timed(lambda: conv(x if pad_mode == 1 else torch.nn.functional.pad(x, (0, 1, 0, 1))), iters)
+        fl = 2.0 * B * (Hin // 2) * (Win // 2) * C * 9 * C
+        print(f"{f'B{B} {C} {Hin}x{Win} pad_mode {pad_mode}':40s} {t_m:9.1f} {t_r:9.1f} {fl / t_m / 1e6:9.1f}")
 
 
 def _timed(fn, iters):
@@ -249,6 +278,10 @@ def main():
                         (1, 512, 512, 256, 384), (1, 512, 256, 256, 384), (1, 256, 256, 256, 384), (1, 256, 256, 512, 768),
                         (1, 256, 128, 512, 768), (1, 128, 128, 512, 768), (2, 1920, 640, 32, 48), (2, 640, 640, 32, 48),
                         (2, 1920, 640, 32, 48)], dt, args.iters, ref=False)
+    if 'convs2' in only:         # the down-samplers: VAE encoder of a training batch, UNet of a training batch and of a 512x768 sample
+        conv_s2_reference([(4, 128, 512, 512, 2), (4, 256, 256, 256, 2), (4, 512, 128, 128, 2), (4, 320, 64, 64, 1),
+                           (4, 640, 32, 32, 1), (4, 1280, 16, 16, 1), (2, 320, 64, 96, 1), (2, 640, 32, 48, 1),
+                           (2, 1280, 16, 24, 1)], dt, args.iters)
     if 'conv1' in only:          # ONE shape (level-0 ResNet conv, forward + backward-data): clean per-launch PMC counters
         conv_reference([(4, 320, 320, 64, 64)], dt, args.iters, ref=False)
     if 'convvae1' in only:       # ONE VAE shape on the 16 x 16 x 128 / 32-channel-chunk tile: clean per-launch PMC counters
@@ -260,6 +293,14 @@ def main():
             kv = torch.randn(B, 77, 2 * C, device='cuda', dtype=dt)
             cases.append(lambda q=q, kv=kv, C=C, d=d: [ops.attn_pv(ops.attn_probs(q, kv[..., :C], 8, d**-0.5), kv[..., C:], 8)
                                                          for _ in range(args.iters)])
+    if 'ffgemm' in only:         # every feed-forward / CLIP-MLP GEMM of a training step (batch 4) and of a CFG-pair sample
+        blas_reference([(16384, 2560, 320), (4096, 5120, 640), (1024, 10240, 1280), (256, 10240, 1280),      # FF1 forward
+                        (4096, 640, 2560), (1024, 1280, 5120), (256, 1280, 5120),                             # FF2 forward (wide levels)
+                        (4928, 3072, 768), (4928, 768, 3072),                                                 # CLIP fc1 / fc2
+                        (12288, 2560, 320), (3072, 5120, 640), (768, 10240, 1280), (192, 10240, 1280)], dt, args.iters)
+        blas_dx_reference([(16384, 2560, 320), (4096, 5120, 640), (1024, 10240, 1280), (256, 10240, 1280),   # FF1 backward-data
+                           (4096, 640, 2560), (1024, 1280, 5120), (256, 1280, 5120),                          # FF2 backward-data
+                           (4928, 3072, 768), (4928, 768, 3072)], dt, args.iters)                             # CLIP fc1 / fc2
     if 'ff' in only:
         ff_reference([(12288, 320), (3072, 640), (768, 1280), (192, 1280), (16384, 320), (4096, 640), (1024, 1280), (256, 1280)],
                      dt, args.iters)
