@@ -379,6 +379,10 @@ int mos_groupnorm_silu_bwd(const void* dy, const void* x, const float* gamma, co
 int64_t mos_groupnorm_nhwc_workspace_bytes(int B, int C, int HW, int G);
 int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                 void* ws, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
+int mos_groupnorm_nhwc_reads_twice(int B, int C, int HW, int G);
+int mos_groupnorm_silu_fwd_nhwc_pre(const void* x, const float* chan_part, int tiles_per_image, const float* gamma,
+                                    const float* beta, void* y, float* stats, void* ws, int B, int C, int HW, int G, float eps,
+                                    int silu, int dtype, void* stream);
 int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamma, const float* beta,
                                 const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu,
                                 int dtype, void* stream);
@@ -415,6 +419,14 @@ int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const v
  *   pad_mode 1: Hout = (Hin - 1) / 2 + 1 (padding 1);  pad_mode 2: Hout = (Hin - 2) / 2 + 1 (zero row / column appended at the
  *   bottom / right -- folded into the kernel's bounds, the padded copy is never materialised).
  *   ws: mos_conv3x3_nhwc_workspace_bytes(B, Hout, Wout, Cin, Cout) bytes or NULL (split-K form of the low-resolution levels). */
+/* The same convolution, also leaving the GroupNorm statistics of its OUTPUT (round 6): gn_part [B][tiles][Cout][2] fp32 = per
+ * (pixel tile, channel) sum and sum of squares of the stored values; tiles = mos_conv3x3_gn_tiles(B, H, W, Cin, Cout) per image
+ * (H, W = output size), 0 = this shape's kernel form keeps no statistics (pass gn_part NULL). Consumer:
+ * mos_groupnorm_silu_fwd_nhwc_pre. Replaces nothing in the reference -- it removes the statistics pass of the GroupNorm that
+ * follows every ResnetBlock2D convolution (diffusers resnet.py; callers mixofshow/pipelines/trainer_edlora.py:237). */
+int mos_conv3x3_gn_tiles(int B, int H, int W, int Cin, int Cout);
+int mos_conv3x3_nhwc_gn(const void* x, const void* w, const float* bias, const void* tbias, const void* residual, void* y,
+                        int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws, void* gn_part, void* stream);
 int mos_conv3x3_s2_nhwc(const void* x, const void* w, const float* bias, void* y, int B, int Hin, int Win, int Cin, int Cout,
                         int pad_mode, int dtype, void* ws, void* stream);
 

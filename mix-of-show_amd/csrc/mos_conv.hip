@@ -41,6 +41,7 @@ struct ConvArgs {
     int M, mt, nt, cpt;           // M = B*H*W ; cpt = Cin / 64 channel chunks per tap
     int up;                       // 1: the input is read through a nearest 2x upsample (x is (B, H/2, W/2, Cin))
     int Hin, Win;                 // stride-2 form only: the source image size (H, Wd are the OUTPUT size)
+    float* gn_part;               // halo form only, or NULL: per-(pixel tile, output channel) sum and sum of squares of the stored values
     int ksplit, kt_per;           // split-K form: K tiles [z * kt_per, (z + 1) * kt_per) per workgroup, z < ksplit
     float* partial;               // split-K form: fp32 partial sums [ksplit][M][Cout]
 };
@@ -451,6 +452,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     T* Y = reinterpret_cast<T*>(a.Y);
     const T* R = reinterpret_cast<const T*>(a.R);
     constexpr int OCH = BM * (BN / 8) / 256;
+    // Round 6: the GroupNorm that consumes this map takes its statistics from HERE instead of re-reading the
+    // map: per output channel the sum and the sum of squares of the values AS STORED (rounded, residual added) over the tile's
+    // valid pixels. A thread's channel chunk is the same in every iteration of the store loop (256 % (BN / 8) == 0), so the
+    // sums ride in 16 registers; one LDS pass folds the 256 / (BN / 8) threads of a chunk. The consumer combines tiles in a
+    // fixed order (deterministic) -- gn_chan_finalize_kernel, mos_norm.hip.
+    const bool want_gn = a.gn_part != nullptr;        // uniform
+    float g0[8], g1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { g0[e] = 0.f; g1[e] = 0.f; }
 #pragma unroll
     for (int i = 0; i < OCH; ++i) {
         const int c = tid + 256 * i;
@@ -467,6 +477,31 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
                 val = from_v8<T>(q);
             }
             st16(Y + o, val);
+            if (want_gn) {
+                const v8 s = as_v8<T>(val);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)s[e]; g0[e] += f; g1[e] = fmaf(f, f, g1[e]); }
+            }
+        }
+    }
+    if (want_gn) {
+        constexpr int RG = 256 / (BN / 8);                 // threads that share a channel chunk
+        static_assert(256 % (BN / 8) == 0 && (size_t)RG * BN * 2 * sizeof(float) <= (size_t)BM * CS * sizeof(T), "statistics fit the staging tile");
+        __syncthreads();                                   // every thread is done reading the staged tile
+        float* red = reinterpret_cast<float*>(smem_raw);   // [RG][BN][2]
+        const int rg = tid / (BN / 8), col = (tid % (BN / 8)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((rg * BN) + col + e) * 2] = g0[e];
+            red[((rg * BN) + col + e) * 2 + 1] = g1[e];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BN * 2; idx += 256) {    // idx = channel * 2 + moment
+            float t = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < RG; ++r) t += red[r * BN * 2 + idx];
+            const int ch = n0 + (idx >> 1);
+            if (ch < N) a.gn_part[((int64_t)m_tile * N + ch) * 2 + (idx & 1)] = t;
         }
     }
 }
@@ -629,11 +664,26 @@ constexpr int RING_MAX_WG = 640;
 //     8 x 16 x 64 / 8 x 16 x 128 tiles of the UNet maps (3-4 workgroups per CU) measured level with or behind the 64-channel
 //     8 x 16 x 64 tile (B2 640->640 32x48 30 -> 38 / 47 us) and are not built;
 //   * what is left (maps narrower than 16 pixels that are not split): raster form.
+// which halo tile (if any) launch_conv gives a shape: 2 = 16 x 16 x 128 on 32-channel chunks, 1 = 8 x 16 x 64, 0 = not the halo form
+inline int conv_halo_form(int B, int H, int Wd, int Cin, int Cout, bool has_ws) {
+    int kt_per = 0;
+    if (has_ws && conv_ksplit(B * H * Wd, Cout, Cin, &kt_per) > 1) return 0;
+#ifdef MOS_CONV_NO_HALO
+    return 0;
+#endif
+    if (!(Wd >= 16 && H >= 8)) return 0;
+    const int64_t t16 = (int64_t)B * ((H + 15) / 16) * ((Wd + 15) / 16) * (Cout / 128);
+    if (Cout % 128 == 0 && H >= 16 && ((Cin >= 512 && t16 >= 256) || (Cin <= 256 && t16 >= 512))) return 2;
+    return 1;
+}
+
 template <typename T>
 int launch_conv(ConvArgs a, hipStream_t st) {
     char key[112];
     int kt_per = 0;
     const int ks = a.partial != nullptr ? conv_ksplit(a.M, a.Cout, a.Cin, &kt_per) : 1;
+    if (a.gn_part != nullptr && conv_halo_form(a.B, a.H, a.Wd, a.Cin, a.Cout, a.partial != nullptr) == 0)
+        return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_conv3x3_nhwc_gn: this shape does not take the halo form (ask mos_conv3x3_gn_tiles first)");
     snprintf(key, sizeof(key), "%s B%d %dx%d Cin%d Cout%d%s%s%s%s", std::is_same<T, f16_t>::value ? "f16" : "bf16", a.B, a.H, a.Wd,
              a.Cin, a.Cout, a.up ? " up2x" : "", a.tbias ? " +tbias" : "", a.R ? " +res" : "", ks > 1 ? " splitK" : "");
     MosProfScope prof(st, "conv3x3", key, 2.0 * a.M * (double)a.Cout * 9.0 * a.Cin,
@@ -683,6 +733,11 @@ int mos_conv3x3_nhwc(const void* x, const void* w, const float* bias, const void
 
 int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const void* tbias, const void* residual, void* y,
                         int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws, void* stream) {
+    return mos_conv3x3_nhwc_gn(x, w, bias, tbias, residual, y, B, H, W, Cin, Cout, upsample2x, dtype, ws, nullptr, stream);
+}
+
+int mos_conv3x3_nhwc_gn(const void* x, const void* w, const float* bias, const void* tbias, const void* residual, void* y,
+                        int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws, void* gn_part, void* stream) {
     MOS_REQUIRE(x && w && y, "mos_conv3x3_nhwc: NULL argument");
     MOS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 8 == 0,
                 "mos_conv3x3_nhwc: B=%d H=%d W=%d Cin=%d Cout=%d (need Cin %% 64 == 0, Cout %% 8 == 0)", B, H, W, Cin, Cout);
@@ -692,11 +747,19 @@ int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const v
     ConvArgs a;
     a.X = x; a.W = w; a.bias = bias; a.tbias = tbias; a.R = residual; a.Y = y;
     a.B = B; a.H = H; a.Wd = W; a.Cin = Cin; a.Cout = Cout; a.M = B * H * W; a.cpt = Cin / 64; a.up = upsample2x ? 1 : 0;
-    a.mt = a.nt = 0; a.Hin = H; a.Win = W;
+    a.mt = a.nt = 0; a.Hin = H; a.Win = W; a.gn_part = (float*)gn_part;
     a.ksplit = 1; a.kt_per = 0; a.partial = (float*)ws;
     if (dtype == MOS_F16) return launch_conv<f16_t>(a, (hipStream_t)stream);
     if (dtype == MOS_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_conv3x3_nhwc: dtype %d", dtype);
+}
+
+int mos_conv3x3_gn_tiles(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 8) return 0;
+    const int form = conv_halo_form(B, H, W, Cin, Cout, true);
+    if (form == 0) return 0;
+    const int th = form == 2 ? 16 : 8;
+    return ((H + th - 1) / th) * ((W + 15) / 16);
 }
 
 int mos_conv3x3_s2_nhwc(const void* x, const void* w, const float* bias, void* y, int B, int Hin, int Win, int Cin, int Cout,
@@ -714,7 +777,7 @@ int mos_conv3x3_s2_nhwc(const void* x, const void* w, const float* bias, void* y
     ConvArgs a;
     a.X = x; a.W = w; a.bias = bias; a.tbias = nullptr; a.R = nullptr; a.Y = y;
     a.B = B; a.H = H; a.Wd = W; a.Cin = Cin; a.Cout = Cout; a.M = B * H * W; a.cpt = Cin / 64; a.up = 0;
-    a.mt = a.nt = 0; a.Hin = Hin; a.Win = Win;
+    a.mt = a.nt = 0; a.Hin = Hin; a.Win = Win; a.gn_part = nullptr;
     a.ksplit = 1; a.kt_per = 0; a.partial = (float*)ws;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MOS_F16) return pad_mode == 1 ? launch_conv_s2<f16_t, 1>(a, st) : launch_conv_s2<f16_t, 2>(a, st);

@@ -542,6 +542,54 @@ int gn_nhwc_run(GnNhwcArgs a, int silu, hipStream_t st) {
     return mos_check_launch("gn_nhwc_apply");
 }
 
+// Round 6: statistics that arrive WITH the map -- the producing convolution's epilogue left, per (pixel tile, channel), the sum and
+// the sum of squares of the stored values (conv3x3_halo_kernel, mos_conv.hip). One 64-thread block per (image, group) adds its
+// cpg channels over all tiles in a fixed order, in double, and writes the per-group constants where gn_nhwc_apply_kernel reads them
+// (and `stats` for the backward): the statistics pass over the activation and its finalize launch are replaced by this one.
+__global__ __launch_bounds__(64) void gn_chan_finalize_kernel(GnNhwcArgs a, const float* __restrict__ chan_part, int tiles) {
+    const int b = blockIdx.x / a.G, g = blockIdx.x - b * a.G, lane = threadIdx.x;
+    const int n = tiles * a.cpg;
+    double t0 = 0.0, t1 = 0.0;
+    for (int i = lane; i < n; i += 64) {
+        const int tile = i / a.cpg, c = g * a.cpg + (i - tile * a.cpg);
+        const float2 v = *reinterpret_cast<const float2*>(chan_part + (((int64_t)b * tiles + tile) * a.C + c) * 2);
+        t0 += (double)v.x; t1 += (double)v.y;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o); t1 += __shfl_xor(t1, o); }
+    if (lane == 0) {
+        const double cnt = (double)a.cpg * a.HW;
+        const double m = t0 / cnt;
+        double var = t1 / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        float* fin = a.partial + (int64_t)a.B * a.nsplit * a.G * 2 + ((int64_t)b * a.G + g) * 2;
+        fin[0] = mean; fin[1] = rstd;
+        if (a.stats != nullptr) { a.stats[(b * a.G + g) * 2] = mean; a.stats[(b * a.G + g) * 2 + 1] = rstd; }
+    }
+}
+
+template <typename T>
+int gn_nhwc_run_pre(GnNhwcArgs a, const float* chan_part, int tiles, int silu, hipStream_t st) {
+    const int vt = (a.V + 255) / 256;
+    const dim3 grid(a.B, a.nsplit), block(a.TP * a.R);
+    char key[96];
+    snprintf(key, sizeof(key), "nhwc B%d C%d HW%d%s", a.B, a.C, a.HW, silu ? " +silu" : "");
+    const double n = (double)a.B * a.C * a.HW;
+    {
+        MosProfScope prof(st, "groupnorm_finalize_pre", key, 2.0 * a.B * tiles * a.C, 8.0 * a.B * tiles * a.C);
+        hipLaunchKernelGGL(gn_chan_finalize_kernel, dim3(a.B * a.G), dim3(64), 0, st, a, chan_part, tiles);
+    }
+    int rc = mos_check_launch("gn_chan_finalize");
+    if (rc) return rc;
+    MosProfScope prof(st, "groupnorm_apply", key, 8.0 * n, 4.0 * n);
+#define GN_APPLY(VTN, S) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, VTN, false, S, false>), grid, block, 0, st, a)
+    if (vt == 1) { if (silu) GN_APPLY(1, true); else GN_APPLY(1, false); }
+    else { if (silu) GN_APPLY(2, true); else GN_APPLY(2, false); }
+#undef GN_APPLY
+    return mos_check_launch("gn_nhwc_apply");
+}
+
 int gn_nhwc_check(const void* x, const void* out, const float* gamma, const float* beta, void* ws, GnNhwcArgs& a,
                   const char* who) {
     if (!x || !out || !gamma || !beta || !ws) return mos_set_error(MOS_ERR_BAD_ARG, "%s: NULL argument", who);
@@ -860,6 +908,35 @@ int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* 
     int rc = gn_nhwc_check(x, y, gamma, beta, ws, a, "mos_groupnorm_silu_fwd_nhwc");
     if (rc) return rc;
     return gn_nhwc_dispatch<false>(a, silu, dtype, (hipStream_t)stream, "mos_groupnorm_silu_fwd_nhwc");
+}
+
+/* GroupNorm(+SiLU) forward on a map whose per-channel statistics came with it (round 6): `chan_part` [B][tiles][C][2] fp32 = sum and
+ * sum of squares of the stored values per (pixel tile, channel), as mos_conv3x3_nhwc_gn leaves them. Same y / stats / ws as
+ * mos_groupnorm_silu_fwd_nhwc; two launches (finalize over the tiles, apply) instead of three and ONE read of x instead of two.
+ * mos_groupnorm_nhwc_reads_twice: 1 where the plain entry point would take the three-launch slice form (the producer's statistics
+ * pay), 0 where it runs the one-launch column kernel (they do not). */
+int mos_groupnorm_nhwc_reads_twice(int B, int C, int HW, int G) {
+    GnNhwcArgs a = {};
+    a.B = B; a.C = C; a.HW = HW; a.G = G;
+    if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G || C % 8) return 0;
+    a.cpg = C / G;
+    if (!gn_nhwc_plan(a)) return 0;
+    GnColArgs c = {};
+    return gn_col_plan(a, c) ? 0 : 1;
+}
+
+int mos_groupnorm_silu_fwd_nhwc_pre(const void* x, const float* chan_part, int tiles_per_image, const float* gamma,
+                                    const float* beta, void* y, float* stats, void* ws, int B, int C, int HW, int G, float eps,
+                                    int silu, int dtype, void* stream) {
+    GnNhwcArgs a = {};
+    a.x = x; a.out = y; a.gamma = gamma; a.beta = beta; a.stats = stats; a.partial = (float*)ws;
+    a.B = B; a.C = C; a.HW = HW; a.G = G; a.eps = eps;
+    int rc = gn_nhwc_check(x, y, gamma, beta, ws, a, "mos_groupnorm_silu_fwd_nhwc_pre");
+    if (rc) return rc;
+    MOS_REQUIRE(chan_part && tiles_per_image > 0, "mos_groupnorm_silu_fwd_nhwc_pre: no channel statistics");
+    if (dtype == MOS_F16) return gn_nhwc_run_pre<f16_t>(a, chan_part, tiles_per_image, silu & 1, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return gn_nhwc_run_pre<bf16_t>(a, chan_part, tiles_per_image, silu & 1, (hipStream_t)stream);
+    return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_fwd_nhwc_pre: dtype %d", dtype);
 }
 
 int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamma, const float* beta, const float* stats,

@@ -743,9 +743,9 @@ class _GroupNormSiLU(torch.autograd.Function):
     """Fused GroupNorm (+ SiLU) on half NCHW or channels_last activations; affine parameters are frozen constants."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu):
+    def forward(ctx, x, gamma, beta, groups, eps, silu, chan_part=None):
         xc = _dense_format(x)
-        y, stats = ops.groupnorm_silu_fwd(xc, gamma, beta, groups, eps, silu)
+        y, stats = ops.groupnorm_silu_fwd(xc, gamma, beta, groups, eps, silu, chan_part=chan_part if xc is x else None)
         ctx.save_for_backward(xc, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
         return y
@@ -757,7 +757,7 @@ class _GroupNormSiLU(torch.autograd.Function):
             dy = dy.to(x.dtype)
         if not ops._same_layout(dy, x):
             dy = dy.contiguous(memory_format=torch.channels_last) if ops._is_nhwc(x) else dy.contiguous()
-        return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
+        return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None, None
 
 
 class _GroupNormSiLUTap(torch.autograd.Function):
@@ -766,9 +766,9 @@ class _GroupNormSiLUTap(torch.autograd.Function):
     instead of in a separate autograd accumulation launch."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu):
+    def forward(ctx, x, gamma, beta, groups, eps, silu, chan_part=None):
         xc = _dense_format(x)
-        y, stats = ops.groupnorm_silu_fwd(xc, gamma, beta, groups, eps, silu)
+        y, stats = ops.groupnorm_silu_fwd(xc, gamma, beta, groups, eps, silu, chan_part=chan_part if xc is x else None)
         ctx.save_for_backward(xc, gamma, beta, stats)
         ctx.groups, ctx.silu = groups, silu
         ctx.set_materialize_grads(False)
@@ -778,19 +778,19 @@ class _GroupNormSiLUTap(torch.autograd.Function):
     def backward(ctx, ds, dy):
         x, gamma, beta, stats = ctx.saved_tensors
         if dy is None:
-            return ds, None, None, None, None, None
+            return ds, None, None, None, None, None, None
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         if not ops._same_layout(dy, x):
             dy = dy.contiguous(memory_format=torch.channels_last) if ops._is_nhwc(x) else dy.contiguous()
         if ds is None:
-            return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None
+            return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None, None
         if ops._is_nhwc(x) and ds.dtype == x.dtype and ds.shape == x.shape:
             if not ops._same_layout(ds, x):            # e.g. a channel slice of a concatenated gradient
                 ds = ds.contiguous(memory_format=torch.channels_last)
             return (ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu, ds=ds), None, None, None, None,
-                    None)
-        return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu) + ds, None, None, None, None, None
+                    None, None)
+        return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu) + ds, None, None, None, None, None, None
 
 
 def _frozen(*params):
@@ -812,6 +812,28 @@ def _affine32(norm):
     return ent[1], ent[2]
 
 
+# Round 6: GroupNorm statistics from the producing convolution's epilogue. conv3x3(..., gn_groups=G) leaves the per-(tile,
+# channel) sums of its output ON the output tensor (a Python attribute, with the tensor's version counter at that moment);
+# group_norm_act picks them up if the tensor is still that object and has not been written to since -- anything else (a new
+# tensor from an add or a concat, an in-place update) simply finds no statistics and takes the normal path.
+_gn_from_conv = _os.environ.get('MOS_GN_FROM_CONV', '1') != '0'      # host-side A/B switch (read once)
+
+
+def _attach_gn_stats(y, part):
+    if part is not None:
+        y._mos_gn_part = (part, y._version, y.data_ptr())
+
+
+def _producer_gn_stats(x):
+    ent = getattr(x, '_mos_gn_part', None)
+    if ent is None or not _gn_from_conv:
+        return None
+    part, version, ptr = ent
+    if version != x._version or ptr != x.data_ptr() or part.shape[0] != x.shape[0] or part.shape[2] != x.shape[1]:
+        return None
+    return part
+
+
 def group_norm_act(norm, x, silu, tap=False):
     """`silu(norm(x))` (or `norm(x)`) for an nn.GroupNorm `norm`. tap=True returns (x, y): use the returned x for the skip
     path around the norm (residual / shortcut) -- on the HIP path that routes the skip's gradient into the norm's backward
@@ -826,9 +848,10 @@ def group_norm_act(norm, x, silu, tap=False):
                and norm.weight is not None and norm.bias is not None and _frozen(norm.weight, norm.bias))
     if use_hip:
         gamma, beta = _affine32(norm)
+        part = _producer_gn_stats(x) if nhwc else None
         if tap and _fuse_gn_res and torch.is_grad_enabled() and x.requires_grad:
-            return _GroupNormSiLUTap.apply(x, gamma, beta, norm.num_groups, norm.eps, bool(silu))
-        y = _GroupNormSiLU.apply(x, gamma, beta, norm.num_groups, norm.eps, bool(silu))
+            return _GroupNormSiLUTap.apply(x, gamma, beta, norm.num_groups, norm.eps, bool(silu), part)
+        y = _GroupNormSiLU.apply(x, gamma, beta, norm.num_groups, norm.eps, bool(silu), part)
         return (x, y) if tap else y
     y = norm(x)
     y = torch.nn.functional.silu(y) if silu else y
@@ -1033,12 +1056,16 @@ def _as_nhwc(t, dtype):
 class _Conv3x3(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, x, w_fwd, w_bwd, bias32, tbias, residual, upsample):
+    def forward(ctx, x, w_fwd, w_bwd, bias32, tbias, residual, upsample, gn_stats=False):
         dt = w_fwd.dtype
         xc = _as_nhwc(x, dt)
         tb = None if tbias is None else tbias.to(dt).contiguous()
         rs = None if residual is None else _as_nhwc(residual, dt)
-        y = ops.conv3x3_nhwc(xc, w_fwd, bias32, tb, rs, upsample)
+        if gn_stats:
+            y, part = ops.conv3x3_nhwc(xc, w_fwd, bias32, tb, rs, upsample, gn_stats=True)
+            _attach_gn_stats(y, part)       # (the object returned here IS the one .apply hands to the caller)
+        else:
+            y = ops.conv3x3_nhwc(xc, w_fwd, bias32, tb, rs, upsample)
         ctx.save_for_backward(w_bwd)
         ctx.upsample, ctx.t_dtype, ctx.r_dtype, ctx.x_dtype = upsample, (None if tbias is None else tbias.dtype), (
             None if residual is None else residual.dtype), x.dtype
@@ -1059,14 +1086,16 @@ class _Conv3x3(torch.autograd.Function):
             dt = dyc.float().sum((2, 3)).to(ctx.t_dtype)
         if ctx.r_dtype is not None and ctx.needs_input_grad[5]:
             dr = dyc if dyc.dtype == ctx.r_dtype else dyc.to(ctx.r_dtype)
-        return dx, None, None, None, dt, dr, None
+        return dx, None, None, None, dt, dr, None, None
 
 
-def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
+def conv3x3(conv, x, tbias=None, residual=None, upsample=False, gn_groups=None):
     """`conv(x)` (+ tbias[:, :, None, None]) (+ residual) for an nn.Conv2d with a 3x3 / stride 1 / pad 1 kernel, optionally
     reading x through a nearest 2x upsample. HIP path (implicit-GEMM kernel, channels_last, epilogue-fused adds): device
     tensors, half activations (or half autocast), FROZEN weights, Cin % 64 == 0, Cout % 8 == 0. Anything else runs the
-    plain torch ops (CPU oracle runs, fp32 inference, trainable convolutions, conv_in / conv_out): plumbing."""
+    plain torch ops (CPU oracle runs, fp32 inference, trainable convolutions, conv_in / conv_out): plumbing.
+    gn_groups: the output (probably) feeds a GroupNorm of that many groups -- where that norm would read the map twice
+    (large maps: level 0, the VAE) the kernel's epilogue leaves the norm's statistics with the output (see _attach_gn_stats)."""
     half = x.dtype in (torch.float16, torch.bfloat16)
     ac = torch.is_autocast_enabled('cuda') and torch.get_autocast_dtype('cuda') in (torch.float16, torch.bfloat16)
     ok = (x.is_cuda and (half or ac) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
@@ -1098,7 +1127,11 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False):
         cache = _ConvWeights()
         object.__setattr__(conv, '_mos_conv_cache', cache)
     w_fwd, w_bwd, bias32 = cache.get(conv, dt, need_bwd and x.requires_grad)
-    return _Conv3x3.apply(x, w_fwd, w_bwd, bias32, tbias, residual, bool(upsample))
+    want = False
+    if gn_groups and _gn_from_conv and conv.out_channels % gn_groups == 0:
+        up = 2 if upsample else 1
+        want = ops.groupnorm_reads_twice(x.shape[0], conv.out_channels, x.shape[2] * up * x.shape[3] * up, gn_groups)
+    return _Conv3x3.apply(x, w_fwd, w_bwd, bias32, tbias, residual, bool(upsample), want)
 
 
 _conv_s2_enabled = _os.environ.get('MOS_CONV3X3_S2', '1') != '0'      # host-side A/B switch (read once)

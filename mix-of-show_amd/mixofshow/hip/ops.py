@@ -517,16 +517,32 @@ def _is_nhwc(x):
     return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
 
 
-def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False):
+def groupnorm_reads_twice(B, C, HW, groups):
+    """True where groupnorm_silu_fwd on a channels_last (B, C, ..) map takes the three-launch slice form (statistics pass + apply
+    pass): there the producing convolution's channel statistics (conv3x3_nhwc(..., gn_stats=True)) save a pass over the map."""
+    return bool(_lib.load().mos_groupnorm_nhwc_reads_twice(int(B), int(C), int(HW), int(groups)))
+
+
+def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False, chan_part=None):
     """x (B, C, *spatial) half, contiguous (NCHW) or channels_last (NHWC); gamma/beta fp32.
     Returns (y like x, same memory format; stats (B*G, 2) fp32). force_slices (channels_last): the three-launch slice kernels
-    also where the one-launch column kernel applies (MOS_GN_FORCE_SLICES; parity tests, A/B)."""
-    _dev(x, gamma, beta)
+    also where the one-launch column kernel applies (MOS_GN_FORCE_SLICES; parity tests, A/B). chan_part (channels_last):
+    (B, tiles, C, 2) fp32 per-(pixel tile, channel) sum / sum of squares of x as its producer left them -- the statistics pass
+    over x is skipped (mos_groupnorm_silu_fwd_nhwc_pre)."""
+    _dev(x, gamma, beta, chan_part)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     y = torch.empty_like(x)
     stats = torch.empty((B * groups, 2), dtype=torch.float32, device=x.device)
     L = _lib.load()
+    if _is_nhwc(x) and chan_part is not None:
+        assert chan_part.dtype == torch.float32 and chan_part.is_contiguous() and chan_part.dim() == 4 \
+            and chan_part.shape[0] == B and chan_part.shape[2] == C and chan_part.shape[3] == 2
+        ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
+        _lib.check(L.mos_groupnorm_silu_fwd_nhwc_pre(_p(x), _p(chan_part), int(chan_part.shape[1]), _p(gamma), _p(beta), _p(y),
+                                                     _p(stats), _p(ws), B, C, HW, groups, float(eps), int(bool(silu)), _dt(x),
+                                                     _stream()), 'mos_groupnorm_silu_fwd_nhwc_pre')
+        return y, stats
     if _is_nhwc(x):
         ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
         _lib.check(L.mos_groupnorm_silu_fwd_nhwc(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), _p(ws), B, C, HW, groups,
@@ -732,11 +748,12 @@ def conv3x3_s2_nhwc(x, w_ohwi, bias=None, pad_mode=1, split_k=True):
     return y
 
 
-def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False, split_k=True):
+def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False, split_k=True, gn_stats=False):
     """x: (B, Cin, H, W) half tensor in channels_last memory format; w_ohwi: (Cout, 3, 3, Cin) contiguous half;
     bias fp32 (Cout,); tbias (B, Cout) half; residual like the output. Returns (B, Cout, H', W') channels_last
     (H' = 2H with upsample2x). split_k=False: no workspace is handed over, i.e. the unsplit kernel also on the
-    low-resolution levels (tests)."""
+    low-resolution levels (tests). gn_stats=True: returns (y, chan_part) where chan_part is the (B, tiles, Cout, 2) fp32
+    GroupNorm statistics of y from the kernel's epilogue, or None where this shape's kernel form keeps none."""
     _dev(x, w_ohwi, bias, tbias, residual)
     B, Cin, Hs, Ws = x.shape
     assert _is_nhwc(x) or (Hs == 1 and Ws == 1) or x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_nhwc needs channels_last'
@@ -754,6 +771,11 @@ def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=Fal
     L = _lib.load()
     nbytes = L.mos_conv3x3_nhwc_workspace_bytes(B, H, W, Cin, Cout) if split_k else 0     # > 0: the split-K form of the low-resolution levels
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device) if nbytes > 0 else None
-    _lib.check(L.mos_conv3x3_nhwc_ws(_p(x), _p(w_ohwi), _p(bias), _p(tbias), _p(residual), _p(y), B, H, W, Cin, Cout,
-                                     int(bool(upsample2x)), _dt(x), _p(ws), _stream()), 'mos_conv3x3_nhwc_ws')
-    return y
+    part = None
+    if gn_stats:
+        tiles = L.mos_conv3x3_gn_tiles(B, H, W, Cin, Cout) if split_k else 0
+        if tiles > 0:
+            part = torch.empty((B, tiles, Cout, 2), dtype=torch.float32, device=x.device)
+    _lib.check(L.mos_conv3x3_nhwc_gn(_p(x), _p(w_ohwi), _p(bias), _p(tbias), _p(residual), _p(y), B, H, W, Cin, Cout,
+                                     int(bool(upsample2x)), _dt(x), _p(ws), _p(part), _stream()), 'mos_conv3x3_nhwc_gn')
+    return (y, part) if gn_stats else y

@@ -145,10 +145,13 @@ class ResnetBlock2D(nn.Module):
                 tb = self.time_emb_proj(_act_once(self.nonlinearity, temb))
         # (x feeds norm1 AND the skip path: taking the skip from the norm's tap adds its gradient inside the norm's backward)
         x, h = group_norm_act(self.norm1, x, True, tap=True)
-        h = conv3x3(self.conv1, h, tbias=tb)
+        # (gn_groups: conv1's output feeds norm2, conv2's the GroupNorm of whatever follows the block -- the next resnet's norm1
+        #  or a Transformer2DModel's norm, all of this module family's group count; on large maps the convolution's epilogue
+        #  leaves that norm's statistics with its output, mixofshow.hip.functional._attach_gn_stats)
+        h = conv3x3(self.conv1, h, tbias=tb, gn_groups=self.norm2.num_groups)
         if self.conv_shortcut is not None:
             x = conv1x1(self.conv_shortcut, x)
-        return conv3x3(self.conv2, self.dropout(group_norm_act(self.norm2, h, True)), residual=x)
+        return conv3x3(self.conv2, self.dropout(group_norm_act(self.norm2, h, True)), residual=x, gn_groups=self.norm1.num_groups)
 
 
 class Downsample2D(nn.Module):

@@ -9,7 +9,7 @@ import torch
 
 EMULATED = ('lora_pack', 'lora_down', 'linear_fwd', 'linear_fwd_ex', 'linear_bwd', 'linear_fused_fwd', 'linear_fused_bwd', 'attn_fwd', 'attn_bwd', 'attn_probs', 'attn_pv', 'attn_probs_bwd', 'attn_pv_bwd', 'region_attn_fwd',
             'gram_accumulate', 'lsq_loss_grad', 'groupnorm_silu_fwd', 'groupnorm_silu_bwd', 'layernorm_fwd', 'layernorm_bwd', 'add_layernorm_fwd', 'add_layernorm_bwd',
-            'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc', 'conv3x3_s2_nhwc')
+            'geglu_fwd', 'geglu_bwd', 'quick_gelu_fwd', 'quick_gelu_bwd', 'softmax_rows', 'single_head_attention_nograd', 'conv3x3_nhwc', 'conv3x3_s2_nhwc', 'groupnorm_reads_twice')
 PAD = 16
 
 
@@ -217,7 +217,11 @@ def lsq_loss_grad(W, G, P, c, n_times_cout):
     return loss, 2.0 * R / n_times_cout
 
 
-def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False):
+def groupnorm_reads_twice(B, C, HW, groups):
+    return HW >= 2048
+
+
+def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False, chan_part=None):
     import torch.nn.functional as F
     cd = torch.float64 if x.dtype == torch.float64 else torch.float32
     xf = x.to(cd)
@@ -225,7 +229,16 @@ def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False):
     g = xf.reshape(B, groups, -1)
     mean = g.mean(-1)
     var = g.var(-1, unbiased=False)
-    y = F.group_norm(xf, groups, gamma.to(cd), beta.to(cd), eps)
+    if chan_part is not None:       # the producer's statistics are USED (a stale or foreign chan_part shows in the result)
+        n = float(x.numel() // (B * groups))
+        tot = chan_part.double().sum(1).reshape(B, groups, C // groups, 2).sum(2)          # (B, G, 2)
+        mean = (tot[..., 0] / n).to(cd)
+        var = (tot[..., 1] / n - (tot[..., 0] / n) ** 2).clamp_min(0).to(cd)
+        shp = [B, groups] + [1] * (x.dim() - 1)
+        xh = (xf.reshape(B, groups, C // groups, *x.shape[2:]) - mean.reshape(shp)) * torch.rsqrt(var + eps).reshape(shp)
+        y = xh.reshape(x.shape) * gamma.to(cd).reshape([1, C] + [1] * (x.dim() - 2)) + beta.to(cd).reshape([1, C] + [1] * (x.dim() - 2))
+    else:
+        y = F.group_norm(xf, groups, gamma.to(cd), beta.to(cd), eps)
     if silu:
         y = F.silu(y)
     stats = torch.stack([mean.reshape(-1), torch.rsqrt(var + eps).reshape(-1)], 1).contiguous()
@@ -343,8 +356,14 @@ def single_head_attention_nograd(q, k, v, scale):
     return (p.float() @ v.float()).to(q.dtype)
 
 
-def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False, split_k=True):
-    """fp32 convolution of the half inputs, + bias + per-sample bias, rounded ONCE, then + residual rounded again."""
+def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False, split_k=True, gn_stats=False):
+    """fp32 convolution of the half inputs, + bias + per-sample bias, rounded ONCE, then + residual rounded again.
+    gn_stats: (y, chan_part) with ONE tile per image -- per-channel sum / sum of squares of the stored values."""
+    if gn_stats:
+        y = conv3x3_nhwc(x, w_ohwi, bias, tbias, residual, upsample2x, split_k)
+        yf = y.float()
+        part = torch.stack([yf.sum((2, 3)), (yf * yf).sum((2, 3))], dim=-1)[:, None].contiguous()      # (B, 1, C, 2)
+        return y, part
     import torch.nn.functional as F
     xf = x.float()
     if upsample2x:

@@ -441,3 +441,54 @@ def test_transformer_block_attention_residual_in_the_out_projection_epilogue(gpu
     blk.attn1.set_processor(Foreign())
     out, n = run(True)
     assert n == n_plain + 1 and '_mos_residual' not in blk.attn1.__dict__
+
+
+def test_groupnorm_statistics_travel_with_the_convolution_output(gpu_branches, monkeypatch):
+    """Round 6: on large maps the 3x3 convolution's epilogue leaves the GroupNorm statistics of its output
+    with the output tensor and the norm that consumes it skips its statistics pass (mos_conv3x3_nhwc_gn ->
+    mos_groupnorm_silu_fwd_nhwc_pre; kernels emulated here: the emulated norm really computes from the attached sums). The
+    attachment is only honoured for the very tensor it was made for, unmodified since."""
+    import mixofshow.hip.ops as ops
+    import mixofshow.models.unet_2d_condition as U
+    torch.manual_seed(0)
+    blk = U.ResnetBlock2D(64, 64, 128).half().requires_grad_(False).to(memory_format=torch.channels_last)
+    nxt = U.ResnetBlock2D(64, 64, 128).half().requires_grad_(False).to(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(2, 64, 48, 48, generator=g).half().contiguous(memory_format=torch.channels_last)     # HW = 2304: "large"
+    temb = torch.randn(2, 128, generator=g).half()
+    used = []
+    real = ops.groupnorm_silu_fwd
+
+    def spy(x, gamma, beta, groups, eps, silu, force_slices=False, chan_part=None):
+        used.append(chan_part is not None)
+        return real(x, gamma, beta, groups, eps, silu, force_slices=force_slices, chan_part=chan_part)
+    monkeypatch.setattr(ops, 'groupnorm_silu_fwd', spy)
+
+    def run(flag, grad):
+        monkeypatch.setattr(F_hip, '_gn_from_conv', flag)
+        used.clear()
+        x = x0.clone().requires_grad_(grad)
+        with torch.set_grad_enabled(grad):
+            y = nxt(blk(x, temb), temb)
+            if grad:
+                y.float().square().mean().backward()
+        return y.detach(), (x.grad if grad else None), list(used)
+
+    for grad in (False, True):
+        y1, g1, u1 = run(True, grad)
+        y0, g0, u0 = run(False, grad)
+        # blk.norm1 sees the block input (no producer), blk.norm2 conv1's output, nxt.norm1 conv2's output, nxt.norm2 conv1's
+        assert u1 == [False, True, True, True] and u0 == [False] * 4
+        torch.testing.assert_close(y1.float(), y0.float(), rtol=0, atol=4e-3)
+        if grad:
+            assert (g1.float() - g0.float()).norm() <= 2e-2 * g0.float().norm()
+    # the attachment belongs to ONE tensor in ONE state
+    monkeypatch.setattr(F_hip, '_gn_from_conv', True)
+    with torch.no_grad():
+        y = F_hip.conv3x3(blk.conv1, x0, gn_groups=32)
+        assert F_hip._producer_gn_stats(y) is not None and y._mos_gn_part[0].shape == (2, 1, 64, 2)
+        assert F_hip._producer_gn_stats(y + 0) is None and F_hip._producer_gn_stats(torch.cat([y, y], 1)) is None
+        y.add_(1.0)
+        assert F_hip._producer_gn_stats(y) is None
+        small = F_hip.conv3x3(blk.conv1, x0[:, :, :16, :16].contiguous(memory_format=torch.channels_last), gn_groups=32)
+        assert F_hip._producer_gn_stats(small) is None         # small maps: the one-launch norm needs no help

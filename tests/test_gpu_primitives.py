@@ -966,6 +966,58 @@ def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('B,Cin,Cout,H,W,extras', [
+    (4, 320, 320, 64, 64, 'tr'),      # level-0 ResNet convolutions: 8 x 16 x 64 halo tiles, 5 channel tiles
+    (2, 320, 320, 64, 96, 'r'),       # 512x768 sample
+    (2, 640, 640, 32, 48, 'u'),       # up-sampler into level 0 (64 x 96 output)
+    (1, 128, 128, 512, 500, 't'),     # VAE stage: 16 x 16 x 128 tiles on 32-channel chunks, ragged
+    (1, 512, 512, 130, 100, 'r'),     # ragged in both directions, 8 x 16 x 64 tiles
+    (2, 960, 320, 64, 64, ''),        # last up block (Cin != Cout)
+])
+def test_conv3x3_leaves_groupnorm_statistics(ops, emu, dtype, B, Cin, Cout, H, W, extras):
+    """Round 6: mos_conv3x3_nhwc_gn -- the same convolution, bit for bit, plus per-(tile, channel) sum and sum
+    of squares of the values it stored; mos_groupnorm_silu_fwd_nhwc_pre -- GroupNorm(+SiLU) from those sums (finalize over tiles
+    + apply) against the three-launch form that re-reads the map, and against the fp32 emulation."""
+    g = torch.Generator(device='cpu').manual_seed(35)
+    x = torch.randn(B, Cin, H, W, generator=g).to('cuda', dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to('cuda', dtype)
+    bias = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    up = 'u' in extras
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    tb = torch.randn(B, Cout, generator=g).to('cuda', dtype) if 't' in extras else None
+    res = (torch.randn(B, Cout, Ho, Wo, generator=g) * 2).to('cuda', dtype).contiguous(memory_format=torch.channels_last) \
+        if 'r' in extras else None
+    w_fwd = w.permute(0, 2, 3, 1).contiguous()
+    y_plain = ops.conv3x3_nhwc(x, w_fwd, bias, tb, res, up)
+    y, part = ops.conv3x3_nhwc(x, w_fwd, bias, tb, res, up, gn_stats=True)
+    assert part is not None and part.shape[0] == B and part.shape[2:] == (Cout, 2) and torch.equal(y, y_plain)
+    yf = y.double()
+    tot = part.double().sum(1)                                        # (B, Cout, 2)
+    ref0, ref1 = yf.sum((2, 3)), (yf * yf).sum((2, 3))
+    e0 = ((tot[..., 0] - ref0).abs().max() / ref1.sqrt().max()).item()
+    e1 = ((tot[..., 1] - ref1).abs().max() / ref1.max()).item()
+    print(f'[parity] conv3x3 GroupNorm statistics [{B}x{Cin}->{Cout}x{Ho}x{Wo} {extras}]: tiles {part.shape[1]}, sum err {e0:.2e}, sum-of-squares rel err {e1:.2e}')
+    assert e0 < 1e-4 and e1 < 1e-5
+    assert ops.groupnorm_reads_twice(B, Cout, Ho * Wo, 32)
+    gamma = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    beta = (torch.randn(Cout, generator=g) * 0.2).cuda()
+    for silu, eps in ((True, 1e-5), (False, 1e-6)):
+        z_pre, st_pre = ops.groupnorm_silu_fwd(y, gamma, beta, 32, eps, silu, chan_part=part)
+        z_ref, st_ref = ops.groupnorm_silu_fwd(y, gamma, beta, 32, eps, silu)
+        z_emu, st_emu = emu.groupnorm_silu_fwd(y, gamma, beta, 32, eps, silu)
+        _check(f'groupnorm from the convolution statistics vs emulation (silu={silu})', z_pre, z_emu, dtype, ulps=2.0)
+        _check('groupnorm from the convolution statistics vs the re-reading form', z_pre, z_ref, dtype, ulps=1.0)
+        assert (st_pre - st_emu).abs().max().item() <= 2e-5 * max(1.0, st_emu.abs().max().item())
+        dy = torch.randn_like(y)
+        _check('groupnorm backward from those stats', ops.groupnorm_silu_bwd(dy, y, gamma, beta, st_pre, 32, silu),
+               ops.groupnorm_silu_bwd(dy, y, gamma, beta, st_ref, 32, silu), dtype, ulps=2.0)
+    # small maps keep no statistics (their norm is one launch already)
+    xs = x[:, :, :16, :16].contiguous(memory_format=torch.channels_last)
+    _, none = ops.conv3x3_nhwc(xs, w_fwd, bias, None, None, False, gn_stats=True)
+    assert none is None or not ops.groupnorm_reads_twice(B, Cout, 256, 32)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('pad_mode', [1, 2])
 @pytest.mark.parametrize('B,Cin,Cout,Hin,Win', [
     (2, 320, 320, 64, 96),       # UNet down-sampler of a 512x768 sample, level 0 -> 1
