@@ -493,7 +493,12 @@ template <int D> struct RG {
     static constexpr int VR = PRENORM ? D : D + 1;
     static constexpr int K_ELEMS = KEYS * HD<D>::RS;
     static constexpr int V_ELEMS = VR * TS3;
-    static constexpr int NSP = D <= 40 ? 4 : D <= 80 ? 2 : 1;   // sources resident per pass (<= 77 KB: two blocks per CU)
+    // sources resident per pass. Round 6: 2 at d = 40 (was 4): with 2-D query tiles a workgroup rarely needs more than two sources,
+    // and 38.6 KB of LDS + 166 VGPRs let THREE workgroups share a CU -- the level-0 grid (768 workgroups at 512x768) runs in one
+    // round instead of one and a half: 20.5 -> 17.0 us same box (profiles/r06c9_region_occupancy.txt; the ablation
+    // profiles/r06c8_region_ablation.txt puts 14 of the 20 us in the launch / q-load / store skeleton of a 1.5-round grid).
+    // d = 80 at two per CU (2 x 67 KB) measured level (15.1 vs 14.6 us) and stays at one.
+    static constexpr int NSP = D <= 80 ? 2 : 1;
     static constexpr bool PREFETCH = NSP < 4;                   // next pass's loads fly under this pass's MFMAs
     static constexpr int NK = (KEYS * HD<D>::DCH + 255) / 256;  // 16-byte chunks per thread: K rows
     static constexpr int NV = (KEYS / 2 * HD<D>::DCH + 255) / 256;   // row PAIRS x chunks per thread: V
@@ -506,7 +511,7 @@ struct RegionStage {     // registers of one source in flight
 };
 
 template <typename T, int D>
-__global__ __launch_bounds__(256, (D <= 40 ? 2 : 1)) void region_attn_kernel(AttnArgs a, mos_region_desc reg,
+__global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void region_attn_kernel(AttnArgs a, mos_region_desc reg,
                                                                           const unsigned char* __restrict__ total_count,
                                                                           int accumulate) {
     // total_count / accumulate: a region list longer than one launch holds (MOS_MAX_SOURCES - 1) is walked in chunks. The

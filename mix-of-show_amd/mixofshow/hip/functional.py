@@ -817,6 +817,9 @@ def _affine32(norm):
 # group_norm_act picks them up if the tensor is still that object and has not been written to since -- anything else (a new
 # tensor from an add or a concat, an in-place update) simply finds no statistics and takes the normal path.
 _gn_from_conv = _os.environ.get('MOS_GN_FROM_CONV', '1') != '0'      # host-side A/B switch (read once)
+# '2': ask for the statistics on EVERY map whose convolution can leave them, also where the norm would be the one-launch column
+# kernel (two full-width launches, finalize + apply, against one launch of 32-64 workgroups): same-box A/B only
+_gn_from_conv_always = _os.environ.get('MOS_GN_FROM_CONV', '1') == '2'
 
 
 def _attach_gn_stats(y, part):
@@ -1130,7 +1133,8 @@ def conv3x3(conv, x, tbias=None, residual=None, upsample=False, gn_groups=None):
     want = False
     if gn_groups and _gn_from_conv and conv.out_channels % gn_groups == 0:
         up = 2 if upsample else 1
-        want = ops.groupnorm_reads_twice(x.shape[0], conv.out_channels, x.shape[2] * up * x.shape[3] * up, gn_groups)
+        want = _gn_from_conv_always or ops.groupnorm_reads_twice(x.shape[0], conv.out_channels, x.shape[2] * up * x.shape[3] * up,
+                                                                 gn_groups)
     return _Conv3x3.apply(x, w_fwd, w_bwd, bias32, tbias, residual, bool(upsample), want)
 
 

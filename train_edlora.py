@@ -109,7 +109,12 @@ def save_and_validation(opt, trainer, global_step, logger, rank):
     if opt.get('val', {}).get('val_during_save'):
         from test_edlora import visual_validation
         valset_cfg = opt['datasets']['val_vis']
-        loader = torch.utils.data.DataLoader(PromptDataset(valset_cfg), batch_size=valset_cfg['batch_size_per_gpu'])
+        # the reference shards the validation loader over the ranks (`accelerator.prepare(val_dataloader)`, train_edlora.py:70):
+        # rank r samples prompts r, r + world, ... -- every prompt once, no two ranks writing the same PNG
+        val_set = PromptDataset(valset_cfg)
+        if dp.world_size() > 1:
+            val_set = torch.utils.data.Subset(val_set, range(rank, len(val_set), dp.world_size()))
+        loader = torch.utils.data.DataLoader(val_set, batch_size=valset_cfg['batch_size_per_gpu'])
         for lora_alpha in opt['val']['alpha_list']:
             pipeclass = EDLoRAPipeline if enable_edlora else StableDiffusionPipeline           # reference :179
             pipe = pipeclass.from_pretrained(opt['models']['pretrained_path'], torch_dtype=torch.float16)
@@ -119,6 +124,7 @@ def save_and_validation(opt, trainer, global_step, logger, rank):
             pipe.set_new_concept_cfg(cfg)
             visual_validation(None, pipe, loader, f'Iters-{global_step}_Alpha-{lora_alpha}', opt)     # reference :187
             del pipe
+        dp.barrier()
 
 
 if __name__ == '__main__':
