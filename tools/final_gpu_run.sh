@@ -8,7 +8,7 @@
 #   6. the configs[3] fusion line   (least essential last: the call's time limit is whatever GPU budget is left)
 # Copy gpurun_out/<tag>_* into profiles/ afterwards.        bash tools/final_gpu_run.sh <tag>
 set -u
-TAG="${1:-r05}"
+TAG="${1:-r06}"
 ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 cd "$ROOT"
 O="$ROOT/gpurun_out"; mkdir -p "$O"
@@ -36,7 +36,8 @@ else echo "PMC FAILED"; tail -5 "$O/${TAG}_pmc_run.log"; fi
 fi
 echo "== 3. default bench"
 timeout 900 python bench.py --steps 20 --warmup 5 > "$O/${TAG}_bench_train_n1.json" 2> "$O/${TAG}_bench_train_n1.err"
-tail -2 "$O/${TAG}_bench_train_n1.err"; cut -c1-260 "$O/${TAG}_bench_train_n1.json"
+cp "$O/bench_full.json" "$O/${TAG}_bench_train_n1_full_record.json" 2>/dev/null     # the verbose record (kernel tables, per-case parity) of that line
+grep -E "timed region|captured" "$O/${TAG}_bench_train_n1.err" | cut -c1-330; wc -c "$O/${TAG}_bench_train_n1.json"; cut -c1-400 "$O/${TAG}_bench_train_n1.json"
 cd /tmp && export TMPDIR=/tmp
 echo "== 4. rocprofv3 kernel stats: train"
 rm -rf /tmp/prof
@@ -56,7 +57,7 @@ grep -E "attn_fwd_kernelIDF16_Li40|region_attn_kernel|gn_col_kernel" "$O/${TAG}_
 cut -c1-200 "$O/${TAG}_bench_train_under_rocprof.json"; cut -c1-200 "$O/${TAG}_bench_regional_under_rocprof.json"
 echo "== 5b. the reference's shipped regional example, 1024x2048"
 timeout 400 python bench.py --mode regional --height 1024 --width 2048 --steps 2 --warmup 1 > "$O/${TAG}_bench_regional_1024x2048.json" 2> "$O/${TAG}_bench_regional_1024x2048.err"
-cut -c1-260 "$O/${TAG}_bench_regional_1024x2048.json"
+cp "$O/bench_full.json" "$O/${TAG}_bench_regional_1024x2048_full_record.json" 2>/dev/null; cut -c1-260 "$O/${TAG}_bench_regional_1024x2048.json"
 echo "== 5. train step fed by the JPEG data pipeline (SURVEY 8(f).4)"
 timeout 150 python bench.py --steps 20 --warmup 5 --data jpeg --no-cpu-baseline --no-regional > "$O/${TAG}_bench_train_jpeg.json" 2> "$O/${TAG}_bench_train_jpeg.err"
 tail -1 "$O/${TAG}_bench_train_jpeg.err"; cut -c1-200 "$O/${TAG}_bench_train_jpeg.json"
@@ -65,4 +66,4 @@ PMC_BENCH_ARGS="--ref 0" bash tools/pmc_collect.sh conv1,probs > "$O/${TAG}_pmc_
 cp "$O/pmc_conv1,probs.txt" "$O/${TAG}_pmc_conv_halo_and_probs_kernels.txt" 2>/dev/null; grep -A16 "conv3x3_halo_kernel f16" "$O/${TAG}_pmc_conv_halo_and_probs_kernels.txt" | head -40
 echo "== 6. configs[3]: gradient fusion of 14 synthetic ED-LoRAs"
 timeout 420 python bench.py --mode fusion --concepts 14 --steps 2 --warmup 1 > "$O/${TAG}_bench_fusion.json" 2> "$O/${TAG}_bench_fusion.err"
-echo "rc=$?"; grep "fusion pass" "$O/${TAG}_bench_fusion.err"; cut -c1-300 "$O/${TAG}_bench_fusion.json"
+echo "rc=$?"; cp "$O/bench_full.json" "$O/${TAG}_bench_fusion_full_record.json" 2>/dev/null; grep "fusion pass" "$O/${TAG}_bench_fusion.err"; cut -c1-300 "$O/${TAG}_bench_fusion.json"
