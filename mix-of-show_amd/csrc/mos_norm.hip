@@ -569,6 +569,104 @@ __global__ __launch_bounds__(64) void gn_chan_finalize_kernel(GnNhwcArgs a, cons
     }
 }
 
+// Round 6, second step: GroupNorm(+SiLU) from the producer's statistics in ONE launch. A workgroup owns a channel range of whole
+// groups and whole 16-byte vectors (>= 64 channels where the map has them: 128-byte runs per pixel) and a pixel slice; its
+// prologue adds the producer's per-(tile, channel) sums of ITS groups (a few KB: tiles x range x 2 floats, fixed order, double) --
+// every workgroup of a range repeats that small sum instead of waiting for a finalize launch -- then streams its slice once:
+// y = c0 x + c1 (+ SiLU), the arithmetic of gn_nhwc_apply_kernel. Full-width grid at every map size, one read, one write: replaces
+// finalize + apply on the large maps and (with the statistics present) the 32-64-workgroup column kernel on the middle levels.
+constexpr int GN_PRE_MAXG = 16;
+struct GnPreArgs {
+    const void* x; void* out; const float* gamma; const float* beta; float* stats; const float* chan_part;
+    int B, C, HW, G, cpg, tiles;
+    int cw, ngw, NV, RP, ppb;       // channels / groups / 16-byte vectors per workgroup range, pixels in flight, pixels per slice
+    float eps;
+};
+
+template <typename T, bool SILU>
+__global__ __launch_bounds__(256) void gn_pre_apply_kernel(GnPreArgs a) {
+    typedef typename MT<T>::v8 v8;
+    __shared__ float mean_s[GN_PRE_MAXG], rstd_s[GN_PRE_MAXG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int unit = blockIdx.x, sp = blockIdx.y, b = blockIdx.z;
+    const int c_lo = unit * a.cw, g_lo = c_lo / a.cpg;
+    for (int gi = wave; gi < a.ngw; gi += 4) {          // one wave per group of the range
+        const int n = a.tiles * a.cpg;
+        double t0 = 0.0, t1 = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            const int tile = i / a.cpg, c = (g_lo + gi) * a.cpg + (i - tile * a.cpg);
+            const float2 v = *reinterpret_cast<const float2*>(a.chan_part + (((int64_t)b * a.tiles + tile) * a.C + c) * 2);
+            t0 += (double)v.x; t1 += (double)v.y;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o); t1 += __shfl_xor(t1, o); }
+        if (lane == 0) {
+            const double cnt = (double)a.cpg * a.HW, m = t0 / cnt;
+            double var = t1 / cnt - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            mean_s[gi] = mean; rstd_s[gi] = rstd;
+            if (sp == 0 && a.stats != nullptr) {
+                a.stats[(b * a.G + g_lo + gi) * 2] = mean; a.stats[(b * a.G + g_lo + gi) * 2 + 1] = rstd;
+            }
+        }
+    }
+    __syncthreads();
+    const int r = tid / a.NV, v = tid - r * a.NV;       // pixel lane, vector of the range
+    if (r >= a.RP) return;
+    float c0[8], c1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = c_lo + v * 8 + i, gi = c / a.cpg - g_lo;
+        const float gam = a.gamma[c], bet = a.beta[c];
+        c0[i] = gam * rstd_s[gi];
+        c1[i] = bet - mean_s[gi] * gam * rstd_s[gi];
+    }
+    const int p0 = sp * a.ppb, p1 = min(p0 + a.ppb, a.HW);
+    const T* xb = (const T*)a.x + (int64_t)b * a.HW * a.C + c_lo + v * 8;
+    T* ob = (T*)a.out + (int64_t)b * a.HW * a.C + c_lo + v * 8;
+    constexpr int U = 4;
+    for (int p = p0 + r; p < p1; p += U * a.RP) {
+        u32x4 xr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xr[u] = ld16(xb + (int64_t)min(p + u * a.RP, p1 - 1) * a.C);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u * a.RP >= p1) continue;
+            const v8 xv = as_v8<T>(xr[u]);
+            v8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float z = (float)xv[i] * c0[i] + c1[i];
+                if (SILU) z = silu_f(z);
+                o[i] = (T)z;
+            }
+            st16(ob + (int64_t)(p + u * a.RP) * a.C, from_v8<T>(o));
+        }
+    }
+}
+
+int gn_gcd(int x, int y);
+// channel range of a workgroup: whole groups, whole vectors, >= 64 channels where possible, <= GN_PRE_MAXG groups, <= 256 threads
+bool gn_pre_plan(const GnNhwcArgs& a, GnPreArgs& q, const float* chan_part, int tiles) {
+    const int cpg = a.cpg;
+    int cu = cpg / gn_gcd(cpg, 8) * 8;                  // lcm(cpg, 8)
+    if (a.C % cu != 0) return false;
+    int cw = cu;
+    while (cw < 64 && a.C % (cw * 2) == 0) cw *= 2;     // (cw stays a multiple of cu that divides C)
+    if (cw / cpg > GN_PRE_MAXG || cw / 8 > 256) return false;
+    q.x = a.x; q.out = a.out; q.gamma = a.gamma; q.beta = a.beta; q.stats = a.stats; q.chan_part = chan_part;
+    q.B = a.B; q.C = a.C; q.HW = a.HW; q.G = a.G; q.cpg = cpg; q.tiles = tiles; q.eps = a.eps;
+    q.cw = cw; q.ngw = cw / cpg; q.NV = cw / 8; q.RP = 256 / q.NV;
+    const int units = a.C / cw;
+    int ns = (1024 + a.B * units - 1) / (a.B * units);  // ~1024 workgroups
+    const int maxs = (a.HW + 4 * q.RP - 1) / (4 * q.RP);
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    q.ppb = (a.HW + ns - 1) / ns;
+    return true;
+}
+
 template <typename T>
 int gn_nhwc_run_pre(GnNhwcArgs a, const float* chan_part, int tiles, int silu, hipStream_t st) {
     const int vt = (a.V + 255) / 256;
@@ -576,6 +674,15 @@ int gn_nhwc_run_pre(GnNhwcArgs a, const float* chan_part, int tiles, int silu, h
     char key[96];
     snprintf(key, sizeof(key), "nhwc B%d C%d HW%d%s", a.B, a.C, a.HW, silu ? " +silu" : "");
     const double n = (double)a.B * a.C * a.HW;
+    GnPreArgs q = {};
+    if (gn_pre_plan(a, q, chan_part, tiles)) {          // one launch: statistics of the range in the prologue, then the slice
+        const int nsp = (a.HW + q.ppb - 1) / q.ppb;
+        MosProfScope prof(st, "groupnorm_pre", key, 8.0 * n, 4.0 * n);
+        const dim3 g3((unsigned)(a.C / q.cw), (unsigned)nsp, (unsigned)a.B);
+        if (silu) hipLaunchKernelGGL((gn_pre_apply_kernel<T, true>), g3, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((gn_pre_apply_kernel<T, false>), g3, dim3(256), 0, st, q);
+        return mos_check_launch("gn_pre_apply");
+    }
     {
         MosProfScope prof(st, "groupnorm_finalize_pre", key, 2.0 * a.B * tiles * a.C, 8.0 * a.B * tiles * a.C);
         hipLaunchKernelGGL(gn_chan_finalize_kernel, dim3(a.B * a.G), dim3(64), 0, st, a, chan_part, tiles);
