@@ -816,10 +816,12 @@ def _affine32(norm):
 # channel) sums of its output ON the output tensor (a Python attribute, with the tensor's version counter at that moment);
 # group_norm_act picks them up if the tensor is still that object and has not been written to since -- anything else (a new
 # tensor from an add or a concat, an in-place update) simply finds no statistics and takes the normal path.
-_gn_from_conv = _os.environ.get('MOS_GN_FROM_CONV', '1') != '0'      # host-side A/B switch (read once)
-# '2': ask for the statistics on EVERY map whose convolution can leave them, also where the norm would be the one-launch column
-# kernel (two full-width launches, finalize + apply, against one launch of 32-64 workgroups): same-box A/B only
-_gn_from_conv_always = _os.environ.get('MOS_GN_FROM_CONV', '1') == '2'
+# MOS_GN_FROM_CONV (host-side A/B switch, read once): '0' never; '1' only where the norm would read the map twice (large maps: the
+# three-launch slice form); default '2': on every map whose convolution can leave the statistics -- with them the norm is ONE
+# full-width launch (gn_pre_apply_kernel) instead of the 32-64-workgroup column kernel of the middle levels. Same box,
+# profiles/r06c10_*: GroupNorm kernels 58.9 -> 52.4 ('1') -> 48.6 ms per regional sample, training step 33.63 -> 33.46 -> 33.38 ms.
+_gn_from_conv = _os.environ.get('MOS_GN_FROM_CONV', '2') != '0'
+_gn_from_conv_always = _os.environ.get('MOS_GN_FROM_CONV', '2') == '2'
 
 
 def _attach_gn_stats(y, part):

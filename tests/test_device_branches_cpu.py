@@ -464,6 +464,8 @@ def test_groupnorm_statistics_travel_with_the_convolution_output(gpu_branches, m
         return real(x, gamma, beta, groups, eps, silu, force_slices=force_slices, chan_part=chan_part)
     monkeypatch.setattr(ops, 'groupnorm_silu_fwd', spy)
 
+    monkeypatch.setattr(F_hip, '_gn_from_conv_always', False)       # first: statistics only where the norm would read twice
+
     def run(flag, grad):
         monkeypatch.setattr(F_hip, '_gn_from_conv', flag)
         used.clear()
@@ -490,5 +492,8 @@ def test_groupnorm_statistics_travel_with_the_convolution_output(gpu_branches, m
         assert F_hip._producer_gn_stats(y + 0) is None and F_hip._producer_gn_stats(torch.cat([y, y], 1)) is None
         y.add_(1.0)
         assert F_hip._producer_gn_stats(y) is None
-        small = F_hip.conv3x3(blk.conv1, x0[:, :, :16, :16].contiguous(memory_format=torch.channels_last), gn_groups=32)
-        assert F_hip._producer_gn_stats(small) is None         # small maps: the one-launch norm needs no help
+        xs = x0[:, :, :16, :16].contiguous(memory_format=torch.channels_last)
+        small = F_hip.conv3x3(blk.conv1, xs, gn_groups=32)
+        assert F_hip._producer_gn_stats(small) is None         # MOS_GN_FROM_CONV=1: small maps keep the one-launch column norm
+        monkeypatch.setattr(F_hip, '_gn_from_conv_always', True)
+        assert F_hip._producer_gn_stats(F_hip.conv3x3(blk.conv1, xs, gn_groups=32)) is not None      # the default: every map
