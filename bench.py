@@ -519,13 +519,22 @@ def run_train(args, rank, world, device):
         for i in range(args.steps):
             engine.step(next_batch(i))
             marks[i + 1].record()                   # device-side step boundaries: no host sync inside the region
-        host_ms = (time.perf_counter() - t0) * 1e3 / args.steps      # what the HOST needed to enqueue a step (no sync yet)
         _sync_barrier(world)
         dt = _max_over_ranks(time.perf_counter() - t0, world, device)
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     spread = [round(per_step[0], 2), round(statistics.median(per_step), 2), round(per_step[-1], 2)] if per_step else None
-    _log(f'timed region: {args.steps} steps in {dt:.3f}s; device-side step ms min/median/max {spread}; host enqueue '
-         f'{host_ms:.2f} ms/step; clocks {clocks.summary()}')
+    # what the HOST needs per step, outside the timed region: with the device idle at the start of a step nothing the host does
+    # can block on a full launch queue (inside a pipelined loop a host that runs ahead waits in hipGraphLaunch, so its loop time
+    # only mirrors the device's). A replayed step needs ~5 ms of host time against ~33 ms of device time (tools/host_step_breakdown.py)
+    host_ms = 0.0
+    for i in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        engine.step(next_batch(i))
+        host_ms += (time.perf_counter() - t1) * 1e3 / 5
+    torch.cuda.synchronize()
+    _log(f'timed region: {args.steps} steps in {dt:.3f}s; device-side step ms min/median/max {spread}; host needs '
+         f'{host_ms:.2f} ms/step (device idle at step start); clocks {clocks.summary()}')
     allreduce = None
     if world > 1:
         # the one collective of the path, on its own -- the flat fp32 gradient bucket over RCCL/xGMI (latency-bound at
@@ -569,7 +578,7 @@ def run_train(args, rank, world, device):
                     hipgraph=graphed, graph_capture_s=capture_s, channels_last=bool(args.channels_last),
                     host_cores=os.cpu_count(), kernel_source_sha16=kernel_source_fingerprint(),
                     box=box_info(device.index or 0), clocks_timed_region=clocks.summary(), allreduce=allreduce,
-                    host_enqueue_ms_per_step=round(host_ms, 2),
+                    host_need_ms_per_step=round(host_ms, 2),
                     **_tuning_switches()),
         roofline=roofline_from_profile(recs) if recs else None,
         attention_path=attention_path_aggregate(ATTN_PATH_GFLOP_PER_TRAINED_IMAGE, B, recs, 2) if recs else None,
@@ -938,7 +947,7 @@ def compact_line(res, full_path=None):
     cfg = dict(res.get('config') or {})
     ccfg = _pick(cfg, ('global_batch', 'per_gpu_batch', 'image_size', 'parallelism', 'grad_bucket_bytes', 'preset', 'hipgraph',
                        'graph_capture_s', 'channels_last', 'host_cores', 'kernel_source_sha16', 'height', 'width', 'replicas',
-                       'concepts', 'allreduce', 'box', 'clocks_timed_region', 'host_enqueue_ms_per_step'))
+                       'concepts', 'allreduce', 'box', 'clocks_timed_region', 'host_need_ms_per_step'))
     ccfg = dict(workload=_short(cfg.get('workload', ''), 200), **ccfg)
     out['config'] = ccfg
     out['roofline'] = _pick(res.get('roofline'), rl_keys + ('total_ms', 'dtype'))
