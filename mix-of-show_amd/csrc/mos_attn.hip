@@ -33,6 +33,9 @@
 #ifndef MOS_DQ_OCC
 #define MOS_DQ_OCC 2
 #endif
+#ifndef MOS_ATTN_PV16          // 0: variant build with the 32x32x16 P.V form at d = 40 (same-box A/B)
+#define MOS_ATTN_PV16 1
+#endif
 
 namespace {
 
@@ -47,6 +50,13 @@ constexpr int TS = KV_TILE + 8;
 // the group (the rows its S^T accumulator registers hold, see the header comment): with this order they are 8
 // CONTIGUOUS elements, one ds_read_b128 (256 B/clk) instead of a ds_read2_b64 (128 B/clk).
 __device__ __forceinline__ constexpr int tr_col(int c) { return (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1); }
+
+// Column order of a transposed V tile for the 16x16x32 form of O^T = V^T . P^T (round 6, d = 40 forward): within each 32-key
+// sub-tile the four k-groups of the MFMA (lane >> 4) hold keys {0-3, 8-11}, {16-19, 24-27}, {4-7, 12-15}, {20-23, 28-31} -- what four
+// v_permlane16_swap of the packed S^T accumulator leave in them (see attend) -- each as 8 CONTIGUOUS elements (one ds_read_b128).
+__device__ __forceinline__ constexpr int tr_col16(int c) {
+    return (c & 32) | ((((c >> 2) & 1) * 2 + ((c >> 4) & 1)) << 3) | (((c >> 3) & 1) << 2) | (c & 3);
+}
 
 template <int D>
 struct HD {
@@ -202,13 +212,14 @@ struct TrStage {
             }
         }
     }
+    template <bool MAP16 = false>
     __device__ __forceinline__ void store(T* ldsT, int tid) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int it = tid + NT * i;
             const int p = it & 31, cc = it >> 5;
             if (N * NT <= 32 * DCH || it < 32 * DCH) {
-                uint32_t* dst = reinterpret_cast<uint32_t*>(ldsT + (cc * 8) * TS + tr_col(2 * p));
+                uint32_t* dst = reinterpret_cast<uint32_t*>(ldsT + (cc * 8) * TS + (MAP16 ? tr_col16(2 * p) : tr_col(2 * p)));
                 // word e of the packed pair = {row 2p+1 elem e (high half), row 2p elem e (low half)}:
                 // v_perm_b32 byte selectors over {src0 = r1 word (bytes 4..7), src1 = r0 word (bytes 0..3)}
 #pragma unroll
@@ -228,11 +239,19 @@ struct TrStage {
 // CAUSAL is a template parameter and the ragged last tile is a peeled copy of the loop body (TAIL): as run-time flags
 // both masks were if-converted by hipcc into a compare + select per score element in EVERY tile -- ~350 of the 760
 // instructions of the d = 40 forward loop, for masks the UNet never uses (no causal attention; 4096/1024/256/64 keys).
-template <typename T, int D, int NQ, bool PCOLS, bool LSUM = false, bool CAUSAL = false>
+// PV16 (round 6, d = 40 self-attention forward; VERDICT r05 next #3, measured): O^T = V^T . P^T on v_mfma_f32_16x16x32 with d padded
+// 40 -> 48 (three 16-row tiles) instead of 40 -> 64 (two 32-row tiles of the 32x32x16 form): 24 x 16 instead of 16 x 32 MFMA cycles per
+// 64-key tile and 64 queries, 6 instead of 8 A-fragment reads. The 32x32 accumulator layout of S^T is NOT a 16x16x32 B operand; on
+// gfx950 it becomes two of them (queries 0-15 / 16-31 of the block) with FOUR v_permlane16_swap_b32 per 32x32 tile: the packed
+// accumulator words of key blocks {0, 1} and {2, 3} trade their odd / even 16-lane rows, after which lane l holds query l & 15 and
+// the eight keys of k-group l >> 4 in the order tr_col16 gives the V^T tile. Accumulators o16[iq][u][dm]: query 16 u + (l & 15),
+// rows d = 16 dm + 4 (l >> 4) + r.
+template <typename T, int D, int NQ, bool PCOLS, bool LSUM = false, bool CAUSAL = false, bool PV16 = false>
 __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vbase, int64_t v_rs, int Nkv,
                                        float c /* scale*log2e */, T* Ks_, T* Vt_,
                                        const typename MT<T>::v8 (&qf)[NQ][HD<D>::KS],
-                                       f32x16 (&o)[NQ][HD<D>::DT], float (&m)[NQ], float (&l)[NQ],
+                                       f32x16 (&o)[PV16 ? 1 : NQ][PV16 ? 1 : HD<D>::DT], f32x4 (&o16)[PV16 ? NQ : 1][2][3],
+                                       float (&m)[NQ], float (&l)[NQ],
                                        const int (&tok)[MOS_MAX_PCOLS], int n_pcols,
                                        float (&cap)[NQ][MOS_MAX_PCOLS], int tid, int l31, int hh, int qfirst = 0) {
     typedef typename MT<T>::v8 v8;
@@ -240,10 +259,17 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
         m[iq] = NEG_BIG; l[iq] = 0.f;
+        if constexpr (PV16) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[iq][dt][r] = 0.f;
+                for (int dm = 0; dm < 3; ++dm) o16[iq][u][dm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[iq][dt][r] = 0.f;
+        }
     }
     // Double-buffered LDS tiles (Ks/Vt hold 2 tiles each) + register prefetch: the global loads of tile i+1 are
     // issued before the MFMAs of tile i and written to the other buffer after them; ONE barrier per tile.
@@ -258,7 +284,7 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
     kst.load(ksrc, 0);
     vst.load(vsrc, 0);
     kst.store(Ks_, tid);
-    vst.store(Vt_, tid);
+    vst.template store<PV16>(Vt_, tid);
     __syncthreads();
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the dK/dV kernel
     int cur = 0;
@@ -339,31 +365,74 @@ __device__ __forceinline__ void attend(const T* kbase, int64_t k_rs, const T* vb
                 }
             if constexpr (!LSUM) l[iq] = l[iq] * alpha + ls;
             if (__any(alpha != 1.0f)) {  // wave-uniform: once the running max has settled no lane rescales
+                if constexpr (PV16) {
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+                    for (int u = 0; u < 2; ++u) {       // this lane's accumulators belong to query 16 u + (l & 15)
+                        const float au = __shfl(alpha, 16 * u + (l31 & 15));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[iq][dt][r] *= alpha;
+                        for (int dm = 0; dm < 3; ++dm)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o16[iq][u][dm][r] *= au;
+                    }
+                } else {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[iq][dt][r] *= alpha;
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) pf[iq][t][s2] = acc_to_bfrag<T>(s[iq][t], s2);
         }
+        if constexpr (PV16) {
+            // pf[iq][t][0] = packed words of key blocks 0, 1 (accumulator registers 0..7), pf[iq][t][1] = of key blocks 2, 3: four
+            // row swaps turn the pair into the B operands of query groups u = 0 (lanes' queries 0-15) and u = 1 (16-31)
+            v8 pb[NQ][2][2];
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const T* vrow = Vt + (32 * dt + l31) * TS;
+            for (int iq = 0; iq < NQ; ++iq)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t) {
+                    const u32x4 lo = from_v8<T>(pf[iq][t][0]), hi = from_v8<T>(pf[iq][t][1]);
+                    u32x4 b0, b1;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const v8 a = tr_afrag<T>(vrow, t, s2, hh);
-#pragma unroll
-                    for (int iq = 0; iq < NQ; ++iq) o[iq][dt] = MT<T>::mfma32(a, pf[iq][t][s2], o[iq][dt]);
+                    for (int w = 0; w < 4; ++w) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(lo[w], hi[w], false, false);
+                        b0[w] = sw[0]; b1[w] = sw[1];
+                    }
+                    pb[iq][t][0] = as_v8<T>(b0); pb[iq][t][1] = as_v8<T>(b1);
                 }
+            const int kg = (l31 >> 4) + 2 * hh;              // lane >> 4
+#pragma unroll
+            for (int dm = 0; dm < 3; ++dm) {
+                const T* vrow = Vt + (16 * dm + (l31 & 15)) * TS + 8 * kg;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const v8 a = as_v8<T>(ld16(vrow + 32 * t));
+#pragma unroll
+                    for (int iq = 0; iq < NQ; ++iq)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) o16[iq][u][dm] = MT<T>::mfma16(a, pb[iq][t][u], o16[iq][u][dm]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const T* vrow = Vt + (32 * dt + l31) * TS;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const v8 a = tr_afrag<T>(vrow, t, s2, hh);
+#pragma unroll
+                        for (int iq = 0; iq < NQ; ++iq) o[iq][dt] = MT<T>::mfma32(a, pf[iq][t][s2], o[iq][dt]);
+                    }
+            }
         }
         if (more) {
             kst.store(Ks_ + (cur ^ 1) * HD<D>::ROW_TILE_ELEMS, tid);
-            vst.store(Vt_ + (cur ^ 1) * HD<D>::TR_TILE_ELEMS, tid);
+            vst.template store<PV16>(Vt_ + (cur ^ 1) * HD<D>::TR_TILE_ELEMS, tid);
         }
         __syncthreads();  // tile i+1 visible; every wave is done reading tile i before it is overwritten next round
         cur ^= 1;
@@ -437,11 +506,42 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
             for (int iq = 0; iq < NQ; ++iq) cap[iq][tt] = NEG_BIG;
         }
     }
-    f32x16 o[NQ][HD<D>::DT];
+    // level-0 self attention with 32 queries per wave (small grids: the CFG pair of a sample): the 16x16x32 P.V form. Measured,
+    // same box (profiles/r06c14_*): B2 N6144 (32 queries per wave) 172.9 -> 169.0 us in the sample, 191.0 / 183.9 -> 186.4 / 182.5 in
+    // the kernel table; B4 N4096 with 64 queries per wave 158.8 / 160.2 -> 162.8 / 163.2 us (SLOWER: the A fragments were already
+    // shared by two query blocks there, the extra swaps and the narrower MFMAs cost more than the 14 % of matrix cycles they save)
+    // -- so the retile the round-5 verdict asked to be measured is worth 2 % where it helps: MFMA issue does not bound these kernels.
+    constexpr bool PV16 = MOS_ATTN_PV16 && D == 40 && !PCOLS && !CAUSAL && NQ == 1;
+    f32x16 o[PV16 ? 1 : NQ][PV16 ? 1 : HD<D>::DT];
+    f32x4 o16[PV16 ? NQ : 1][2][3];
     float m[NQ], l[NQ];
     const float c = a.scale * LOG2E;
-    attend<T, D, NQ, PCOLS, LSUM, CAUSAL>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, m, l, tok, a.n_pcols, cap, tid,
-                                          l31, hh, q0);
+    attend<T, D, NQ, PCOLS, LSUM, CAUSAL, PV16>(kp, a.k_rs, vp, a.v_rs, a.Nkv, c, Ks, Vt, qf, o, o16, m, l, tok, a.n_pcols, cap,
+                                                tid, l31, hh, q0);
+    if constexpr (PV16) {
+        const int n = l31 & 15, kg = (l31 >> 4) + 2 * hh;
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qi = q0 + 32 * iq + 16 * u + n;
+                // row D = 40 of O^T (the ones row of V^T: the row sum) = tile dm 2, row 8 = register 0 of the lanes with kg = 2
+                const float lt = __shfl(o16[iq][u][2][0], 32 + n);
+                const float mq = __shfl(m[iq], 16 * u + n);
+                const float inv = 1.0f / lt;
+                if (qi < a.Nq) {
+                    T* orow = op + (int64_t)qi * a.o_rs;
+#pragma unroll
+                    for (int dm = 0; dm < 3; ++dm) {
+                        const int d0 = 16 * dm + 4 * kg;
+                        if (d0 < D)
+                            st8(orow + d0, pack4<T>(o16[iq][u][dm][0] * inv, o16[iq][u][dm][1] * inv, o16[iq][u][dm][2] * inv,
+                                                     o16[iq][u][dm][3] * inv));
+                    }
+                    if (a.lse != nullptr && kg == 0) a.lse[((int64_t)b * a.H + h) * a.Nq + qi] = mq * a.scale + __logf(lt);
+                }
+            }
+    } else {
 
 #pragma unroll
     for (int iq = 0; iq < NQ; ++iq) {
@@ -469,6 +569,7 @@ __global__ __launch_bounds__(256, ((D <= 40 || (D <= 80 && QW == 32)) ? 2 : 1)) 
                         a.pcols[row * a.n_pcols + tt] = __builtin_amdgcn_exp2f((sv - m[iq]) * c) * inv;
                 }
         }
+    }
     }
 }
 
