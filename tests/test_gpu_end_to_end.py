@@ -1088,3 +1088,99 @@ def test_fusion_reduces_layer_loss_on_real_features():
     print(f'[parity] spatial-layer LSQ: loss0={l0:.4e} hip(gram,fp64)={direct:.6e} gram_loss={loss:.6e} oracle(fp32 direct)={lr:.6e}')
     # `loss` is the Gram-form value at the fp64 iterate; `direct` re-evaluates the fp32-rounded W the API returns
     assert loss <= direct * (1 + 1e-6) and direct < 1e-3 * l0 and direct <= lr * (1 + 5e-2)
+
+
+@pytest.mark.timeout(1500)
+def test_cli_chain_on_the_device_train_test_fuse_regional_sample(tmp_path):
+    """The reference's four command lines, run as a user runs them (subprocesses of the repo's scripts) on the device, chained
+    through their on-disk formats: `train_edlora.py -opt` (two concepts; hipGraph step) -> `.pth` delta checkpoints ->
+    `test_edlora.py -opt` (merge at alpha, sample the validation prompt) -> `gradient_fusion.py --concept_cfg ...` (fused
+    model directory + new_concept_cfg.json) -> `regionally_controlable_sampling.py --pretrained_model <that directory>
+    --prompt_rewrite ...` (PNG + run record). `small` preset (SD-1.5 head dims 40 / 80, 768-wide text tower), 256 px."""
+    import glob
+    import json
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+
+    def run(argv, cwd):
+        p = subprocess.run([sys.executable] + argv, cwd=cwd, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, f'{argv[0]} failed:\n{p.stdout[-1500:]}\n{p.stderr[-3000:]}'
+        return p
+
+    with open(os.path.join(root, 'options', 'train', 'EDLoRA', 'synthetic', '8101_EDLoRA_potter_synthetic_B4.yml')) as f:
+        base = yaml.safe_load(f)
+    ckpts = []
+    for name, toks in (('potter', '<potter1>+<potter2>'), ('thanos', '<thanos1>+<thanos2>')):
+        opt = json.loads(json.dumps(base))
+        opt['name'] = f'cli_gpu_{name}'
+        opt['models'].update(pretrained_path='synthetic://small?seed=0', new_concept_token=toks)
+        tr = opt['datasets']['train']
+        tr.update(num_images=4, dataset_enlarge_ratio=2, batch_size_per_gpu=2, image_size=256,
+                  replace_mapping={'<TOK>': toks.replace('+', ' ')})
+        tr['instance_transform'][0]['size'] = 256
+        opt['datasets']['val_vis'].update(latent_size=[4, 32, 32], num_samples_per_prompt=1, batch_size_per_gpu=1,
+                                          replace_mapping={'<TOK>': toks.replace('+', ' ')})
+        opt['val'].update(val_during_save=False, alpha_list=[0.7], sample=dict(num_inference_steps=4, guidance_scale=7.5))
+        opt['logger'] = dict(print_freq=1, save_checkpoint_freq=1000)
+        recipe = str(tmp_path / f'{name}.yml')
+        with open(recipe, 'w') as f:
+            yaml.safe_dump(opt, f)
+        # train_edlora.py resolves experiments/ under the directory of the script: run a copy of the entry script from tmp_path
+        run([os.path.join(root, 'train_edlora.py'), '-opt', recipe], cwd=root)
+        found = glob.glob(os.path.join(root, 'experiments', f'cli_gpu_{name}', 'models', 'edlora_model-latest.pth'))
+        assert found, 'no checkpoint written'
+        sd = torch.load(found[0], weights_only=False)['params']
+        assert set(sd) == {'new_concept_embedding', 'text_encoder', 'unet'} and len(sd['new_concept_embedding']) == 2
+        ups = [v for k, v in sd['unet'].items() if k.endswith('lora_up.weight')]
+        assert ups and all(torch.isfinite(u).all() for u in ups) and any(u.abs().max() > 0 for u in ups)
+        ckpts.append((found[0], toks.replace('+', ' '), recipe, opt))
+    try:
+        # test_edlora.py on the first checkpoint
+        ck, words, recipe, opt = ckpts[0]
+        opt = json.loads(json.dumps(opt))
+        opt['name'] = 'cli_gpu_test'
+        opt['path'] = dict(lora_path=ck)
+        opt['models']['alpha'] = 0.7
+        tpath = str(tmp_path / 'test.yml')
+        with open(tpath, 'w') as f:
+            yaml.safe_dump(opt, f)
+        run([os.path.join(root, 'test_edlora.py'), '-opt', tpath], cwd=root)
+        pngs = glob.glob(os.path.join(root, 'results', 'cli_gpu_test', 'visualization', '**', '*.png'), recursive=True)
+        assert len(pngs) == 1 and '<potter1>' in os.path.basename(pngs[0])
+        from PIL import Image
+        assert Image.open(pngs[0]).size == (256, 256)
+        # gradient_fusion.py over both checkpoints
+        cfg = str(tmp_path / 'fuse.json')
+        with open(cfg, 'w') as f:
+            json.dump([dict(lora_path=c[0], unet_alpha=1.0, text_encoder_alpha=1.0, concept_name=c[1]) for c in ckpts], f)
+        fused_dir = str(tmp_path / 'fused')
+        run([os.path.join(root, 'gradient_fusion.py'), '--concept_cfg', cfg, '--save_path', fused_dir, '--pretrained_models',
+             'synthetic://small?seed=0', '--optimize_textenc_iters', '20', '--optimize_unet_iters', '5'], cwd=root)
+        model = os.path.join(fused_dir, 'combined_model_base')
+        with open(os.path.join(model, 'new_concept_cfg.json')) as f:
+            new_cfg = json.load(f)
+        assert list(new_cfg) == ['<potter1>', '<potter2>', '<thanos1>', '<thanos2>']
+        assert os.path.exists(os.path.join(model, 'unet', 'diffusion_pytorch_model.safetensors'))
+        # regionally_controlable_sampling.py on the fused directory: two regions, 256 x 384
+        out = str(tmp_path / 'regional')
+        rewrite = ('[a <potter1> <potter2>, in the park]-*-[blurry]-*-[8, 8, 250, 180]|'
+                   '[a <thanos1> <thanos2>, purple armor]-*-[blurry]-*-[4, 200, 256, 376]')
+        run([os.path.join(root, 'regionally_controlable_sampling.py'), '--pretrained_model', model, '--prompt',
+             'two people in the park', '--prompt_rewrite', rewrite, '--negative_prompt', 'lowres', '--seed', '14', '--height', '256',
+             '--width', '384', '--save_dir', out, '--suffix', 'cli'], cwd=root)
+        imgs = glob.glob(os.path.join(out, 'seed_14', '*.png'))
+        recs = glob.glob(os.path.join(out, 'seed_14', '*.txt'))
+        assert len(imgs) == 1 and len(recs) == 1 and Image.open(imgs[0]).size == (384, 256)
+        import numpy as np
+        px = np.asarray(Image.open(imgs[0]), dtype=np.float32)
+        assert np.isfinite(px).all() and px.std() > 1.0           # an image, not a constant / NaN frame
+        print(f'[parity] CLI chain on the device: 2 x train_edlora.py -> test_edlora.py -> gradient_fusion.py -> '
+              f'regionally_controlable_sampling.py ok ({os.path.basename(imgs[0])})')
+    finally:
+        import shutil
+        for d in ('cli_gpu_potter', 'cli_gpu_thanos'):
+            shutil.rmtree(os.path.join(root, 'experiments', d), ignore_errors=True)
+        shutil.rmtree(os.path.join(root, 'results', 'cli_gpu_test'), ignore_errors=True)
