@@ -392,6 +392,11 @@ int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamm
 int mos_groupnorm_silu_bwd_nhwc_res(const void* dy, const void* ds, const void* x, const float* gamma, const float* beta,
                                     const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu, int dtype,
                                     void* stream);
+/* ... with `ds` read in place from a channel slice of a wider channels-last tensor (the gradient of one input of a torch.cat along
+ * the channels: the UNet's skip concatenations): ds_pixel_stride = elements between consecutive pixels of ds (>= C, % 8 == 0). */
+int mos_groupnorm_silu_bwd_nhwc_res_ps(const void* dy, const void* ds, int64_t ds_pixel_stride, const void* x, const float* gamma,
+                                       const float* beta, const float* stats, void* dx, void* ws, int B, int C, int HW, int G,
+                                       int silu, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolution on channels-last activations as an implicit GEMM (the ResnetBlock2D, Upsample2D
@@ -427,6 +432,12 @@ int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const v
 int mos_conv3x3_gn_tiles(int B, int H, int W, int Cin, int Cout);
 int mos_conv3x3_nhwc_gn(const void* x, const void* w, const float* bias, const void* tbias, const void* residual, void* y,
                         int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws, void* gn_part, void* stream);
+/* ... with x read in place from a channel slice of a wider channels-last tensor: x_pixel_stride = elements between consecutive
+ * pixels of x (>= Cin, % 8 == 0; mos_conv3x3_nhwc_gn is this with x_pixel_stride = Cin). The dX convolution of a layer whose
+ * output went into a torch.cat reads its slice of the concatenation's gradient this way, without a contiguous copy. */
+int mos_conv3x3_nhwc_px(const void* x, int64_t x_pixel_stride, const void* w, const float* bias, const void* tbias,
+                        const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws,
+                        void* gn_part, void* stream);
 int mos_conv3x3_s2_nhwc(const void* x, const void* w, const float* bias, void* y, int B, int Hin, int Win, int Cin, int Cout,
                         int pad_mode, int dtype, void* ws, void* stream);
 

@@ -40,6 +40,8 @@ struct ConvArgs {
     int B, H, Wd, Cin, Cout;      // Wd = image width
     int M, mt, nt, cpt;           // M = B*H*W ; cpt = Cin / 64 channel chunks per tap
     int up;                       // 1: the input is read through a nearest 2x upsample (x is (B, H/2, W/2, Cin))
+    int ldx;                      // PIXEL stride of x in elements: Cin for a dense map, wider when x is a channel slice of a wider
+                                  // channels-last tensor (a concatenation's gradient read in place by the dX convolution: round 6)
     int Hin, Win;                 // stride-2 form only: the source image size (H, Wd are the OUTPUT size)
     float* gn_part;               // halo form only, or NULL: per-(pixel tile, output channel) sum and sum of squares of the stored values
     int ksplit, kt_per;           // split-K form: K tiles [z * kt_per, (z + 1) * kt_per) per workgroup, z < ksplit
@@ -96,11 +98,11 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: the LDS-DMA destinations (M0) become SALU values
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lg = lane >> 4;
     const int n0 = n_tile * BN, m0 = m_tile * BM;
-    const int M = a.M, N = a.Cout, C = a.Cin, H = a.H, Wd = a.Wd;
+    const int M = a.M, N = a.Cout, C = a.Cin, LX = a.ldx, H = a.H, Wd = a.Wd;
     const int K = 9 * C;
     const int Hs = S2 ? a.Hin : (UP ? H / 2 : H), Ws_ = S2 ? a.Win : (UP ? Wd / 2 : Wd);     // source image size
 
-    const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((int64_t)a.B * Hs * Ws_ * C * (int64_t)sizeof(T)));
+    const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((((int64_t)a.B * Hs * Ws_ - 1) * LX + C) * (int64_t)sizeof(T)));
     const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * K + K) * (int64_t)sizeof(T)));
     constexpr int OOB = 0x7FFFFF00;
 
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
         if (m < M) {
             const int b = m / (H * Wd), p = m - b * (H * Wd);
             py[i] = p / Wd; px[i] = p - py[i] * Wd;
-            rowoff[i] = UP ? b * Hs : (((b * Hs + ST * py[i]) * Ws_ + ST * px[i]) * C + cc8) * (int)sizeof(T);
+            rowoff[i] = UP ? b * Hs : (((b * Hs + ST * py[i]) * Ws_ + ST * px[i]) * LX + cc8) * (int)sizeof(T);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int yy = ST * py[i] + t / 3 - PD, xx = ST * px[i] + t % 3 - PD;
@@ -147,13 +149,13 @@ __global__ __launch_bounds__(256) void conv3x3_nhwc_kernel(const ConvArgs a) {
         const int dy = tap / 3 - PD, dx = tap - (tap / 3) * 3 - PD;
         T* xs = Xs + buf * BM * CBK + wave * 512;
         T* ws = Ws + buf * BN * CBK + wave * 512;
-        const int delta = ((dy * Ws_ + dx) * C + cch * CBK) * (int)sizeof(T);      // non-upsampled source: linear in the tap
+        const int delta = ((dy * Ws_ + dx) * LX + cch * CBK) * (int)sizeof(T);      // non-upsampled source: linear in the tap
         if constexpr (UP) {
 #pragma unroll
             for (int i = 0; i < XCH; ++i) {
                 const int yy = py[i] + dy, xx = px[i] + dx;
                 const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
-                const int off = (((rowoff[i] + (yy >> 1)) * Ws_ + (xx >> 1)) * C + cch * CBK + cc8) * (int)sizeof(T);
+                const int off = (((rowoff[i] + (yy >> 1)) * Ws_ + (xx >> 1)) * LX + cch * CBK + cc8) * (int)sizeof(T);
                 dma16(xsrc, xs + i * 2048, ok ? off : OOB);
             }
         } else {
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lg = lane >> 4;
-    const int N = a.Cout, C = a.Cin, H = a.H, Wd = a.Wd;
+    const int N = a.Cout, C = a.Cin, LX = a.ldx, H = a.H, Wd = a.Wd;
     const int K = 9 * C;
     const int tx_n = (Wd + 15) / 16, ty_n = (H + TH - 1) / TH;
     const int b = m_tile / (tx_n * ty_n), tr = m_tile - b * (tx_n * ty_n);
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
     // UP: the input is read through a nearest 2x upsample -- halo pixel (yy, xx) of the H x Wd image the taps walk is source
     // pixel (yy >> 1, xx >> 1) of the (H/2) x (Wd/2) tensor; the zero border is the border of the UPSAMPLED image
     const int Hsrc = UP ? H / 2 : H, Wsrc = UP ? Wd / 2 : Wd;
-    const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((int64_t)a.B * Hsrc * Wsrc * C * (int64_t)sizeof(T)));
+    const rsrc_t xsrc = make_rsrc(a.X, (uint32_t)((((int64_t)a.B * Hsrc * Wsrc - 1) * LX + C) * (int64_t)sizeof(T)));
     const rsrc_t wsrc = make_rsrc(a.W, (uint32_t)((((int64_t)N - 1) * K + K) * (int64_t)sizeof(T)));
     // Addressing without per-step VALU work (the unrolled tap loop used to spend ~1 v_add per MFMA on it):
     //   * DMA sources: the lane part (pixel / weight row, swizzled chunk) is a loop-invariant VGPR -- 0x80000000, past any
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvArgs a) {
         const int yy = y0 + hy - 1, xx = x0 + hx - 1;
         const int lc = (lane % CPR) ^ halo_swz<CK>(hr);
         const int ys = UP ? (yy >> 1) : yy, xs = UP ? (xx >> 1) : xx;
-        hoff[i] = (hr < HR && yy >= 0 && yy < H && xx >= 0 && xx < Wd) ? (((b * Hsrc + ys) * Wsrc + xs) * C + lc * 8) * (int)sizeof(T) : OOB;
+        hoff[i] = (hr < HR && yy >= 0 && yy < H && xx >= 0 && xx < Wd) ? (((b * Hsrc + ys) * Wsrc + xs) * LX + lc * 8) * (int)sizeof(T) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
@@ -738,7 +740,20 @@ int mos_conv3x3_nhwc_ws(const void* x, const void* w, const float* bias, const v
 
 int mos_conv3x3_nhwc_gn(const void* x, const void* w, const float* bias, const void* tbias, const void* residual, void* y,
                         int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws, void* gn_part, void* stream) {
+    return mos_conv3x3_nhwc_px(x, (int64_t)Cin, w, bias, tbias, residual, y, B, H, W, Cin, Cout, upsample2x, dtype, ws, gn_part, stream);
+}
+
+/* The same with x read in place from a channel slice of a wider channels-last tensor (round 6): x_pixel_stride = elements between
+ * consecutive pixels of x (>= Cin, a multiple of 8; rows and images follow at W and H * W pixels). This is how the dX convolution
+ * of a layer whose output went into a torch.cat reads its slice of the concatenation's gradient without a contiguous copy. */
+int mos_conv3x3_nhwc_px(const void* x, int64_t x_pixel_stride, const void* w, const float* bias, const void* tbias,
+                        const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int upsample2x, int dtype, void* ws,
+                        void* gn_part, void* stream) {
     MOS_REQUIRE(x && w && y, "mos_conv3x3_nhwc: NULL argument");
+    MOS_REQUIRE(x_pixel_stride >= Cin && x_pixel_stride % 8 == 0 && ((uint64_t)x & 15) == 0 &&
+                    (int64_t)B * H * W * x_pixel_stride * 2 < (1ll << 31),
+                "mos_conv3x3_nhwc_px: x pixel stride %lld (need >= Cin, a multiple of 8, a 16-byte aligned base, < 2 GiB in all)",
+                (long long)x_pixel_stride);
     MOS_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 8 == 0,
                 "mos_conv3x3_nhwc: B=%d H=%d W=%d Cin=%d Cout=%d (need Cin %% 64 == 0, Cout %% 8 == 0)", B, H, W, Cin, Cout);
     MOS_REQUIRE(!upsample2x || (H % 2 == 0 && W % 2 == 0), "mos_conv3x3_nhwc: upsample2x needs even output H, W");
@@ -747,7 +762,7 @@ int mos_conv3x3_nhwc_gn(const void* x, const void* w, const float* bias, const v
     ConvArgs a;
     a.X = x; a.W = w; a.bias = bias; a.tbias = tbias; a.R = residual; a.Y = y;
     a.B = B; a.H = H; a.Wd = W; a.Cin = Cin; a.Cout = Cout; a.M = B * H * W; a.cpt = Cin / 64; a.up = upsample2x ? 1 : 0;
-    a.mt = a.nt = 0; a.Hin = H; a.Win = W; a.gn_part = (float*)gn_part;
+    a.mt = a.nt = 0; a.Hin = H; a.Win = W; a.gn_part = (float*)gn_part; a.ldx = (int)x_pixel_stride;
     a.ksplit = 1; a.kt_per = 0; a.partial = (float*)ws;
     if (dtype == MOS_F16) return launch_conv<f16_t>(a, (hipStream_t)stream);
     if (dtype == MOS_BF16) return launch_conv<bf16_t>(a, (hipStream_t)stream);
@@ -777,7 +792,7 @@ int mos_conv3x3_s2_nhwc(const void* x, const void* w, const float* bias, void* y
     ConvArgs a;
     a.X = x; a.W = w; a.bias = bias; a.tbias = nullptr; a.R = nullptr; a.Y = y;
     a.B = B; a.H = H; a.Wd = W; a.Cin = Cin; a.Cout = Cout; a.M = B * H * W; a.cpt = Cin / 64; a.up = 0;
-    a.mt = a.nt = 0; a.Hin = Hin; a.Win = Win; a.gn_part = nullptr;
+    a.mt = a.nt = 0; a.Hin = Hin; a.Win = Win; a.gn_part = nullptr; a.ldx = Cin;
     a.ksplit = 1; a.kt_per = 0; a.partial = (float*)ws;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MOS_F16) return pad_mode == 1 ? launch_conv_s2<f16_t, 1>(a, st) : launch_conv_s2<f16_t, 2>(a, st);

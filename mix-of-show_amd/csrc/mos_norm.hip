@@ -258,19 +258,20 @@ struct GnNhwcArgs {
     int B, C, HW, G, cpg, nsplit, V, TP, R, ppb;   // V = C/8 vectors per pixel, TP threads per pixel, R pixel rows per block
     float eps;
     const void* ds;                                // backward only: gradient that bypasses the norm (added to dx), or NULL
+    int64_t ds_ps;                                 // its PIXEL stride in elements (C = dense; > C: a channel slice of a wider NHWC
+                                                   // tensor -- the gradient of one input of a concatenation, read in place: round 6)
 };
 
 template <typename T, int VT, bool BWD, bool SILU>
 __global__ __launch_bounds__(256) void gn_nhwc_reduce_kernel(GnNhwcArgs a) {
     typedef typename MT<T>::v8 v8;
-    extern __shared__ float gn_lds[];               // [C][2] per-channel sums, then reused
+    extern __shared__ float gn_lds[];               // [R][C][2] per-(pixel row of the block, channel) sums
     float* red = gn_lds;
     __shared__ float mean_s[64], rstd_s[64];
     const int tid = threadIdx.x;
     const int r = tid / a.TP, tp = tid - r * a.TP;
     const int b = blockIdx.x, sp = blockIdx.y;
     const int p0 = sp * a.ppb, p1 = min(p0 + a.ppb, a.HW);
-    for (int i = tid; i < 2 * a.C; i += blockDim.x) red[i] = 0.f;
     if (BWD && tid < a.G) { mean_s[tid] = a.stats[(b * a.G + tid) * 2]; rstd_s[tid] = a.stats[(b * a.G + tid) * 2 + 1]; }
     __syncthreads();
     float s0[VT][8], s1[VT][8];
@@ -328,16 +329,25 @@ __global__ __launch_bounds__(256) void gn_nhwc_reduce_kernel(GnNhwcArgs a) {
             }
         }
     }
+    // Block sums in a FIXED order (round 6; LDS float atomics made the statistics of this form differ in the last bit from run to
+    // run): every pixel row r of the block leaves its per-channel sums in its own LDS row, the rows are added in order
+    const int C2 = 2 * a.C;
 #pragma unroll
     for (int k = 0; k < VT; ++k) {
         const int v = tp + a.TP * k;
         if (v < a.V) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                atomicAdd(&red[(v * 8 + i) * 2], s0[k][i]);
-                atomicAdd(&red[(v * 8 + i) * 2 + 1], s1[k][i]);
+                red[r * C2 + (v * 8 + i) * 2] = s0[k][i];
+                red[r * C2 + (v * 8 + i) * 2 + 1] = s1[k][i];
             }
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < C2; i += blockDim.x) {
+        float t = red[i];
+        for (int q = 1; q < a.R; ++q) t += red[q * C2 + i];
+        red[i] = t;
     }
     __syncthreads();
     if (tid < a.G) {
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
     const T* xb = (const T*)a.x + (int64_t)b * a.HW * a.C;
     const T* db = BWD ? (const T*)a.dy + (int64_t)b * a.HW * a.C : nullptr;
     T* ob = (T*)a.out + (int64_t)b * a.HW * a.C;
-    [[maybe_unused]] const T* sb = DS ? (const T*)a.ds + (int64_t)b * a.HW * a.C : nullptr;
+    [[maybe_unused]] const T* sb = DS ? (const T*)a.ds + (int64_t)b * a.HW * a.ds_ps : nullptr;
     constexpr int U = 4;
     for (int p = p0 + r; p < p1; p += U * a.R) {
         u32x4 xr[U][VT], dr[U][VT];
@@ -400,7 +410,7 @@ __global__ __launch_bounds__(256) void gn_nhwc_apply_kernel(GnNhwcArgs a) {
                 const int64_t off = (int64_t)min(p + u * a.R, p1 - 1) * a.C + v * 8;
                 xr[u][k] = ld16(xb + off);
                 if (BWD) dr[u][k] = ld16(db + off);
-                if constexpr (DS) sr[u][k] = ld16(sb + off);
+                if constexpr (DS) sr[u][k] = ld16(sb + (int64_t)min(p + u * a.R, p1 - 1) * a.ds_ps + v * 8);
             }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -504,7 +514,7 @@ template <typename T, bool BWD>
 int gn_nhwc_run(GnNhwcArgs a, int silu, hipStream_t st) {
     const int vt = (a.V + 255) / 256;
     const dim3 grid(a.B, a.nsplit), block(a.TP * a.R);
-    const size_t lds = (size_t)2 * a.C * sizeof(float);
+    const size_t lds = (size_t)2 * a.C * a.R * sizeof(float);      // <= 32 KB: R * C <= 256 threads x 8 channels x vt
     char key[96];
     snprintf(key, sizeof(key), "nhwc B%d C%d HW%d%s", a.B, a.C, a.HW, silu ? " +silu" : "");
     const double n = (double)a.B * a.C * a.HW;
@@ -724,6 +734,7 @@ struct GnColArgs {
     const float* gamma; const float* beta;
     float* stats;                                  // [B*G][2] = mean, rstd (written forward, read backward)
     int B, C, HW, G, cpg;
+    int64_t ds_ps;                                 // pixel stride of ds (see GnNhwcArgs)
     int NV, ng, units, S, RP, npass;               // vectors / groups per unit, units per image, active threads, rows per pass
     float eps;
 };
@@ -784,7 +795,7 @@ __global__ __launch_bounds__(GN_COL_T) void gn_col_kernel(GnColArgs a) {
     const int64_t img = (int64_t)b * a.HW * a.C;
     const T* xb = (const T*)a.x + img + cbase;
     [[maybe_unused]] const T* db = BWD ? (const T*)a.dy + img + cbase : nullptr;
-    [[maybe_unused]] const T* sb = DS ? (const T*)a.ds + img + cbase : nullptr;
+    [[maybe_unused]] const T* sb = DS ? (const T*)a.ds + (int64_t)b * a.HW * a.ds_ps + cbase : nullptr;
     T* ob = (T*)a.out + img + cbase;
     const double ninv = 1.0 / ((double)a.cpg * (double)a.HW);
 
@@ -895,7 +906,7 @@ __global__ __launch_bounds__(GN_COL_T) void gn_col_kernel(GnColArgs a) {
             for (int i = 0; i < 8; ++i)
                 o[i] = (T)((i < nb ? r0 : r1) * (gg[i] - (i < nb ? mg0 : mg1) - xh[i] * (i < nb ? mx0 : mx1)));
             if constexpr (DS) {
-                const v8 sv = as_v8<T>(ld16(sb + (int64_t)p * a.C));
+                const v8 sv = as_v8<T>(ld16(sb + (int64_t)p * a.ds_ps));
 #pragma unroll
                 for (int i = 0; i < 8; ++i) o[i] = (T)((float)o[i] + (float)sv[i]);
             }
@@ -927,7 +938,7 @@ bool gn_col_plan(const GnNhwcArgs& a, GnColArgs& c) {
     c.RP = c.S / c.NV;
     c.npass = (a.HW + c.RP - 1) / c.RP;
     if (c.npass > GN_COL_K) return false;       // larger slabs (level 0, VAE): the slice kernels
-    c.x = a.x; c.dy = a.dy; c.ds = a.ds; c.out = a.out; c.gamma = a.gamma; c.beta = a.beta; c.stats = a.stats;
+    c.x = a.x; c.dy = a.dy; c.ds = a.ds; c.ds_ps = a.ds_ps; c.out = a.out; c.gamma = a.gamma; c.beta = a.beta; c.stats = a.stats;
     return true;
 }
 
@@ -1063,12 +1074,24 @@ int mos_groupnorm_silu_bwd_nhwc(const void* dy, const void* x, const float* gamm
 int mos_groupnorm_silu_bwd_nhwc_res(const void* dy, const void* ds, const void* x, const float* gamma, const float* beta,
                                     const float* stats, void* dx, void* ws, int B, int C, int HW, int G, int silu, int dtype,
                                     void* stream) {
+    return mos_groupnorm_silu_bwd_nhwc_res_ps(dy, ds, (int64_t)C, x, gamma, beta, stats, dx, ws, B, C, HW, G, silu, dtype, stream);
+}
+
+/* The same with `ds` read in place from a channel slice of a wider channels-last tensor (round 6): ds_pixel_stride = elements
+ * between consecutive pixels of ds (>= C, a multiple of 8; the batch stride is HW * ds_pixel_stride) -- the gradient autograd hands
+ * to one input of a torch.cat along the channels (the UNet's skip concatenations) without the contiguous copy. */
+int mos_groupnorm_silu_bwd_nhwc_res_ps(const void* dy, const void* ds, int64_t ds_pixel_stride, const void* x, const float* gamma,
+                                       const float* beta, const float* stats, void* dx, void* ws, int B, int C, int HW, int G,
+                                       int silu, int dtype, void* stream) {
     GnNhwcArgs a = {};
     a.x = x; a.dy = dy; a.out = dx; a.gamma = gamma; a.beta = beta; a.stats = const_cast<float*>(stats); a.partial = (float*)ws;
-    a.B = B; a.C = C; a.HW = HW; a.G = G; a.eps = 0.f; a.ds = ds;
+    a.B = B; a.C = C; a.HW = HW; a.G = G; a.eps = 0.f; a.ds = ds; a.ds_ps = ds_pixel_stride;
     int rc = gn_nhwc_check(x, dx, gamma, beta, ws, a, "mos_groupnorm_silu_bwd_nhwc_res");
     if (rc) return rc;
     MOS_REQUIRE(dy && stats && ds, "mos_groupnorm_silu_bwd_nhwc_res: NULL dy / ds / stats");
+    MOS_REQUIRE(ds_pixel_stride >= C && ds_pixel_stride % 8 == 0 && ((uint64_t)ds & 15) == 0,
+                "mos_groupnorm_silu_bwd_nhwc_res_ps: ds pixel stride %lld (need >= C, a multiple of 8, 16-byte aligned base)",
+                (long long)ds_pixel_stride);
     return gn_nhwc_dispatch<true>(a, silu, dtype, (hipStream_t)stream, "mos_groupnorm_silu_bwd_nhwc_res");
 }
 

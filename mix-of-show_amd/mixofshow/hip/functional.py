@@ -786,8 +786,8 @@ class _GroupNormSiLUTap(torch.autograd.Function):
         if ds is None:
             return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu), None, None, None, None, None, None
         if ops._is_nhwc(x) and ds.dtype == x.dtype and ds.shape == x.shape:
-            if not ops._same_layout(ds, x):            # e.g. a channel slice of a concatenated gradient
-                ds = ds.contiguous(memory_format=torch.channels_last)
+            if not _grads_in_place or ops.nhwc_pixel_stride(ds) is None:   # a channel slice of a concatenation's gradient is
+                ds = ds.contiguous(memory_format=torch.channels_last)      # read in place (its pixel stride goes to the kernel)
             return (ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu, ds=ds), None, None, None, None,
                     None, None)
         return ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, ctx.groups, ctx.silu) + ds, None, None, None, None, None, None
@@ -955,6 +955,11 @@ class _AddLayerNorm(torch.autograd.Function):
 
 
 # A/B switches (tests, bench): '0' routes through the separate add + norm kernels of round 2
+# Round 6: a layer whose output went into a torch.cat along the channels (the UNet's skip concatenations) receives a CHANNEL SLICE of
+# the concatenation's gradient. The kernels that consume it -- the tapped GroupNorm's bypass gradient, the dX 3x3 convolution -- take
+# the slice's pixel stride and read it where it is (`ops.nhwc_pixel_stride`); MOS_GRADS_IN_PLACE=0 restores the contiguous copies
+# (14 strided clones per SD-1.5 training step) for a same-box A/B. Read once.
+_grads_in_place = _os.environ.get('MOS_GRADS_IN_PLACE', '1') != '0'
 _fuse_add_ln = _os.environ.get('MOS_FUSE_ADD_LN', '1') != '0'
 _fuse_gn_res = _os.environ.get('MOS_FUSE_GN_RES', '1') != '0'
 
@@ -1079,7 +1084,11 @@ class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (w_bwd, ) = ctx.saved_tensors
-        dyc = _as_nhwc(dy, w_bwd.dtype if w_bwd is not None else dy.dtype)
+        cd = w_bwd.dtype if w_bwd is not None else dy.dtype
+        if _grads_in_place and dy.dtype == cd and ops.nhwc_pixel_stride(dy) is not None:
+            dyc = dy              # dense channels_last, or a channel slice of a concatenation's gradient: read in place
+        else:
+            dyc = _as_nhwc(dy, cd)
         dx = dt = dr = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv3x3_nhwc(dyc, w_bwd)

@@ -172,10 +172,12 @@ SIGNATURES = {
     'mos_groupnorm_nhwc_workspace_bytes': (_i64, [_i, _i, _i, _i]),
     'mos_groupnorm_silu_fwd_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     'mos_groupnorm_silu_bwd_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'mos_groupnorm_silu_bwd_nhwc_res_ps': (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_groupnorm_silu_bwd_nhwc_res': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_conv3x3_nhwc': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'mos_conv3x3_nhwc_workspace_bytes': (_i64, [_i, _i, _i, _i, _i]),
     'mos_conv3x3_gn_tiles': (_i, [_i, _i, _i, _i, _i]),
+    'mos_conv3x3_nhwc_px': (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mos_conv3x3_nhwc_gn': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'mos_groupnorm_nhwc_reads_twice': (_i, [_i, _i, _i, _i]),
     'mos_groupnorm_silu_fwd_nhwc_pre': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),

@@ -517,6 +517,24 @@ def _is_nhwc(x):
     return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
 
 
+def nhwc_pixel_stride(t):
+    """Pixel stride (elements) of a (B, C, H, W) tensor whose memory is a CHANNEL SLICE of a channels_last tensor -- what autograd
+    hands to one input of a torch.cat along the channels (the UNet's skip concatenations) -- or of a dense channels_last tensor
+    (stride C); None for any other layout. The kernels that take a pixel stride read such a gradient in place."""
+    if t.dim() != 4:
+        return None
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    ps = sw if W > 1 else (sh if H > 1 else (sb // max(H * W, 1) if B > 1 else C))
+    if C > 1 and sc != 1:
+        return None
+    if ps < C or ps % 8 or (W > 1 and sw != ps) or (H > 1 and sh != W * ps) or (B > 1 and sb != H * W * ps):
+        return None
+    if t.data_ptr() % 16:
+        return None
+    return int(ps)
+
+
 def groupnorm_reads_twice(B, C, HW, groups):
     """True where groupnorm_silu_fwd on a channels_last (B, C, ..) map takes the three-launch slice form (statistics pass + apply
     pass): there the producing convolution's channel statistics (conv3x3_nhwc(..., gn_stats=True)) save a pass over the map."""
@@ -567,10 +585,11 @@ def groupnorm_silu_bwd(dy, x, gamma, beta, stats, groups, silu, ds=None, force_s
         assert _same_layout(dy, x)
         ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
         if ds is not None:
-            assert _same_layout(ds, x) and ds.dtype == x.dtype
-            _lib.check(L.mos_groupnorm_silu_bwd_nhwc_res(_p(dy), _p(ds), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws),
-                                                         B, C, HW, groups, int(bool(silu)) | (2 if force_slices else 0), _dt(x), _stream()),
-                       'mos_groupnorm_silu_bwd_nhwc_res')
+            ps = nhwc_pixel_stride(ds)     # C for a dense map; wider for a channel slice of a concatenation's gradient
+            assert ds.shape == x.shape and ps is not None and ds.dtype == x.dtype
+            _lib.check(L.mos_groupnorm_silu_bwd_nhwc_res_ps(_p(dy), _p(ds), ps, _p(x), _p(gamma), _p(beta), _p(stats), _p(dx),
+                                                            _p(ws), B, C, HW, groups, int(bool(silu)) | (2 if force_slices else 0),
+                                                            _dt(x), _stream()), 'mos_groupnorm_silu_bwd_nhwc_res_ps')
             return dx
         _lib.check(L.mos_groupnorm_silu_bwd_nhwc(_p(dy), _p(x), _p(gamma), _p(beta), _p(stats), _p(dx), _p(ws), B, C, HW,
                                                  groups, int(bool(silu)) | (2 if force_slices else 0), _dt(x), _stream()), 'mos_groupnorm_silu_bwd_nhwc')
@@ -749,14 +768,16 @@ def conv3x3_s2_nhwc(x, w_ohwi, bias=None, pad_mode=1, split_k=True):
 
 
 def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=False, split_k=True, gn_stats=False):
-    """x: (B, Cin, H, W) half tensor in channels_last memory format; w_ohwi: (Cout, 3, 3, Cin) contiguous half;
+    """x: (B, Cin, H, W) half tensor in channels_last memory format, or a channel slice of one (`nhwc_pixel_stride`: read in place);
+    w_ohwi: (Cout, 3, 3, Cin) contiguous half;
     bias fp32 (Cout,); tbias (B, Cout) half; residual like the output. Returns (B, Cout, H', W') channels_last
     (H' = 2H with upsample2x). split_k=False: no workspace is handed over, i.e. the unsplit kernel also on the
     low-resolution levels (tests). gn_stats=True: returns (y, chan_part) where chan_part is the (B, tiles, Cout, 2) fp32
     GroupNorm statistics of y from the kernel's epilogue, or None where this shape's kernel form keeps none."""
     _dev(x, w_ohwi, bias, tbias, residual)
     B, Cin, Hs, Ws = x.shape
-    assert _is_nhwc(x) or (Hs == 1 and Ws == 1) or x.is_contiguous(memory_format=torch.channels_last), 'conv3x3_nhwc needs channels_last'
+    ps = nhwc_pixel_stride(x)
+    assert ps is not None, 'conv3x3_nhwc needs channels_last (or a channel slice of a channels_last tensor)'
     Cout = w_ohwi.shape[0]
     assert w_ohwi.shape == (Cout, 3, 3, Cin) and w_ohwi.is_contiguous() and w_ohwi.dtype == x.dtype
     H, W = (2 * Hs, 2 * Ws) if upsample2x else (Hs, Ws)
@@ -776,6 +797,6 @@ def conv3x3_nhwc(x, w_ohwi, bias=None, tbias=None, residual=None, upsample2x=Fal
         tiles = L.mos_conv3x3_gn_tiles(B, H, W, Cin, Cout) if split_k else 0
         if tiles > 0:
             part = torch.empty((B, tiles, Cout, 2), dtype=torch.float32, device=x.device)
-    _lib.check(L.mos_conv3x3_nhwc_gn(_p(x), _p(w_ohwi), _p(bias), _p(tbias), _p(residual), _p(y), B, H, W, Cin, Cout,
-                                     int(bool(upsample2x)), _dt(x), _p(ws), _p(part), _stream()), 'mos_conv3x3_nhwc_gn')
+    _lib.check(L.mos_conv3x3_nhwc_px(_p(x), ps, _p(w_ohwi), _p(bias), _p(tbias), _p(residual), _p(y), B, H, W, Cin, Cout,
+                                     int(bool(upsample2x)), _dt(x), _p(ws), _p(part), _stream()), 'mos_conv3x3_nhwc_px')
     return (y, part) if gn_stats else y

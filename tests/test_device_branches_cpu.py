@@ -113,6 +113,50 @@ def test_group_norm_tap_is_bit_identical_to_autograd_accumulation(gpu_branches, 
     assert ((gf.float() - xr.grad).norm() / xr.grad.norm()).item() <= 2e-3
 
 
+def test_group_norm_tap_reads_a_concatenation_gradient_slice_in_place(gpu_branches, monkeypatch):
+    """The skip path of a tapped GroupNorm ends in a torch.cat along the channels (the UNet's up blocks): autograd hands the tap a
+    CHANNEL SLICE of the concatenation's gradient. The backward passes it to the kernel as it is (pixel stride of the wide tensor,
+    `ops.nhwc_pixel_stride`) -- no contiguous copy -- and the result is the dense one bit for bit."""
+    import mixofshow.hip.ops as ops
+    torch.manual_seed(6)
+    norm = torch.nn.GroupNorm(4, 64).requires_grad_(False)
+    cl = torch.channels_last
+    x0 = torch.randn(2, 64, 8, 8).half().contiguous(memory_format=cl)
+    other = torch.randn(2, 32, 8, 8).half().contiguous(memory_format=cl)
+    wy = torch.randn(2, 64, 8, 8).half().contiguous(memory_format=cl)
+    wc = torch.randn(2, 96, 8, 8).half().contiguous(memory_format=cl)
+    seen = []
+    real = ops.groupnorm_silu_bwd
+
+    def spy(dy, x, gamma, beta, stats, groups, silu, ds=None, **kw):
+        seen.append(None if ds is None else (tuple(ds.stride()), ops.nhwc_pixel_stride(ds)))
+        return real(dy, x, gamma, beta, stats, groups, silu, ds=ds, **kw)
+
+    monkeypatch.setattr(ops, 'groupnorm_silu_bwd', spy)
+
+    def run(first):
+        x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        skip, y = F_hip.group_norm_act(norm, x, True, tap=True)
+        cat = torch.cat([skip, other] if first else [other, skip], dim=1)
+        torch.autograd.backward([y, cat], [wy, wc])          # channels_last gradients, as the UNet's kernels produce them
+        return x.grad
+
+    for first in (True, False):
+        seen.clear()
+        g = run(first)
+        assert seen == [((96 * 64, 1, 96 * 8, 96), 96)], seen            # the slice itself reached the kernel call
+        lo = 0 if first else 32
+        xr = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        skip, y = F_hip.group_norm_act(norm, xr, True, tap=True)
+        torch.autograd.backward([y, skip], [wy, wc[:, lo:lo + 64].contiguous(memory_format=cl)])
+        assert torch.equal(g, xr.grad)
+    # layouts the kernels do not take in place: not a channel slice of a channels_last tensor / misaligned channel offset
+    assert ops.nhwc_pixel_stride(torch.zeros(2, 64, 8, 8).half()) is None
+    assert ops.nhwc_pixel_stride(wc[:, 4:68]) is None                    # 8-byte offset: 16-byte loads need channel offsets % 8
+    assert ops.nhwc_pixel_stride(wc[:, 32:]) == 96 and ops.nhwc_pixel_stride(wc) == 96
+    assert ops.nhwc_pixel_stride(wc[:, :, ::2]) is None
+
+
 def _tiny_trainer_loss_and_grads(fuse, autocast=torch.float16):
     from tests.test_host_cpu import _batch, _trainer
     F_hip._fuse_add_ln = F_hip._fuse_gn_res = fuse
@@ -497,3 +541,48 @@ def test_groupnorm_statistics_travel_with_the_convolution_output(gpu_branches, m
         assert F_hip._producer_gn_stats(small) is None         # MOS_GN_FROM_CONV=1: small maps keep the one-launch column norm
         monkeypatch.setattr(F_hip, '_gn_from_conv_always', True)
         assert F_hip._producer_gn_stats(F_hip.conv3x3(blk.conv1, xs, gn_groups=32)) is not None      # the default: every map
+
+
+def test_conv3x3_backward_reads_a_concatenation_gradient_slice_in_place(gpu_branches, monkeypatch):
+    """A ResnetBlock2D whose output goes into a torch.cat (every up-block layer): conv2's backward receives a channel slice of the
+    concatenation's gradient and hands it to the dX convolution -- and, as the residual's gradient, to the tapped norm1 -- as it is;
+    MOS_GRADS_IN_PLACE=0 (the round-5 behaviour: a contiguous copy first) gives the same input gradient bit for bit."""
+    import mixofshow.hip.ops as ops
+    import mixofshow.models.unet_2d_condition as U
+    torch.manual_seed(1)
+    cl = torch.channels_last
+    blk = U.ResnetBlock2D(64, 64, 128).half().requires_grad_(False).to(memory_format=cl)
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(2, 64, 16, 16, generator=g).half().contiguous(memory_format=cl)
+    skip = torch.randn(2, 64, 16, 16, generator=g).half().contiguous(memory_format=cl)
+    temb = torch.randn(2, 128, generator=g).half()
+    gcat = torch.randn(2, 128, 16, 16, generator=g).half().contiguous(memory_format=cl)
+    conv_in, tap_ds = [], []
+    real_conv, real_gn = ops.conv3x3_nhwc, ops.groupnorm_silu_bwd
+
+    def spy_conv(x, *a, **k):
+        conv_in.append(ops.nhwc_pixel_stride(x))
+        return real_conv(x, *a, **k)
+
+    def spy_gn(dy, x, gamma, beta, stats, groups, silu, ds=None, **kw):
+        tap_ds.append(None if ds is None else ops.nhwc_pixel_stride(ds))
+        return real_gn(dy, x, gamma, beta, stats, groups, silu, ds=ds, **kw)
+
+    monkeypatch.setattr(ops, 'conv3x3_nhwc', spy_conv)
+    monkeypatch.setattr(ops, 'groupnorm_silu_bwd', spy_gn)
+
+    def run(in_place, first):
+        monkeypatch.setattr(F_hip, '_grads_in_place', in_place)
+        x = x0.clone(memory_format=torch.preserve_format).requires_grad_(True)
+        y = blk(x, temb)
+        cat = torch.cat([y, skip] if first else [skip, y], dim=1)
+        conv_in.clear(), tap_ds.clear()
+        cat.backward(gcat)
+        return x.grad, list(conv_in), list(tap_ds)
+
+    for first in (True, False):
+        g1, c1, t1 = run(True, first)
+        g0, c0, t0 = run(False, first)
+        assert c1 == [128, 64] and c0 == [64, 64]        # dX of conv2 reads the slice (pixel stride of the 128-channel tensor)
+        assert t1 == [None, 128] and t0 == [None, 64]     # norm2: no bypass; norm1's tap: the residual's gradient, the same slice
+        assert torch.equal(g1, g0)

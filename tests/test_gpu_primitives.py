@@ -753,12 +753,24 @@ def test_groupnorm_bwd_with_bypass_gradient(ops, emu, dtype, silu, B, C, H, W):
     plain = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu)
     fused = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu, ds=ds)
     assert fused.stride() == x.stride()
+    # run-to-run bit equality, also of the slice form (64 x 64 maps; its block sums were LDS float atomics until round 6)
+    _, stats2 = ops.groupnorm_silu_fwd(x, gamma, beta, 32, 1e-5, silu)
+    assert torch.equal(stats, stats2) and torch.equal(fused, ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu, ds=ds))
     exact = torch.equal(fused, plain + ds)
     print(f'[parity] groupnorm_bwd_res[{B}x{C}x{H}x{W} silu={silu}] bit-identical to kernel + add: {exact}')
     if not exact:
         _check('groupnorm_bwd_res vs kernel + add', fused, plain + ds, dtype, ulps=1.0)
     _check('groupnorm_bwd_res vs emulation', fused, emu.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu, ds=ds), dtype,
            ulps=4.0)
+    # round 6: ds read IN PLACE from a channel slice of a wider channels_last tensor (the gradient autograd hands to one input of
+    # a torch.cat along the channels) -- both halves of a concatenation's gradient, bit-identical to the dense read
+    for lo, wide in ((0, C + 320), (640, C + 640)):
+        big = torch.randn(B, wide, H, W, generator=g).to('cuda', dtype).contiguous(memory_format=cl)
+        sl = big[:, lo:lo + C]
+        assert ops.nhwc_pixel_stride(sl) == wide and ops.nhwc_pixel_stride(ds) == C and not sl.is_contiguous(memory_format=cl)
+        got = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu, ds=sl)
+        want = ops.groupnorm_silu_bwd(dy, x, gamma, beta, stats, 32, silu, ds=sl.contiguous(memory_format=cl))
+        assert torch.equal(got, want), f'sliced bypass gradient (channels {lo}..{lo + C} of {wide}) differs from its dense copy'
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -1111,6 +1123,15 @@ def test_conv3x3_nhwc(ops, emu, dtype, B, Cin, Cout, H, W, extras):
     xf = torch.zeros(B, Cin, Ho, Wo, device='cuda', requires_grad=True)
     (dx_ref, ) = torch.autograd.grad(torch.nn.functional.conv2d(xf, w.float(), None, padding=1), xf, dy.float())
     _check('conv3x3 backward-data', dx, dx_ref, dtype)
+    # round 6: the same gradient read IN PLACE from a channel slice of a wider channels_last tensor (a torch.cat's gradient): every
+    # kernel form (halo / raster / split-K) takes the pixel stride; bit-identical to the dense read
+    for lo, wide in ((0, Cout + 320), (128, Cout + 192)):
+        big = torch.zeros(B, wide, Ho, Wo, dtype=dtype, device='cuda').contiguous(memory_format=torch.channels_last)
+        big.normal_(generator=torch.Generator(device='cuda').manual_seed(5))
+        big[:, lo:lo + Cout] = dy
+        sl = big[:, lo:lo + Cout]
+        assert ops.nhwc_pixel_stride(sl) == wide
+        assert torch.equal(ops.conv3x3_nhwc(sl, w_bwd), dx), f'dX from channels {lo}..{lo + Cout} of {wide} differs from the dense read'
     from mixofshow.hip import lib as _lib
     if _lib.load().mos_conv3x3_nhwc_workspace_bytes(B, Ho, Wo, Cin, Cout) > 0:
         # this shape took the split-K form: the unsplit kernel (same entry point without a workspace) must agree to the
