@@ -65,6 +65,7 @@ def blas_reference(shapes, dtype, iters):
         W = torch.randn(N, K, device='cuda', dtype=dtype) / math.sqrt(K)
         for _ in range(3):
             torch.nn.functional.linear(x, W)
+            ops.linear_fwd(x, W)             # (both warmed: the first libmos launch of a process carries the module load)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
@@ -234,7 +235,7 @@ def gram_case(n, cin, cout, dtype, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,gn,conv1,convvae,convvae1,probs")
+    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,ffgemm,ffsweep,gn,conv1,convvae,convvae1,convs2,probs")
     ap.add_argument('--dtype', default='f16')
     ap.add_argument('--legacy', type=int, default=0, help='gemm: also time the round-1 multi-launch LoRA path')
     ap.add_argument('--ref', type=int, default=1, help='0: skip the MIOpen / hipBLASLt reference timings')
@@ -301,6 +302,9 @@ def main():
         blas_dx_reference([(16384, 2560, 320), (4096, 5120, 640), (1024, 10240, 1280), (256, 10240, 1280),   # FF1 backward-data
                            (4096, 640, 2560), (1024, 1280, 5120), (256, 1280, 5120),                          # FF2 backward-data
                            (4928, 3072, 768), (4928, 768, 3072)], dt, args.iters)                             # CLIP fc1 / fc2
+    if 'ffsweep' in only:        # FF1 forward of level 0 (N 2560, K 320) over M: is M = 16384 (a training batch) on a cliff?
+        blas_reference([(m, 2560, 320) for m in (8192, 12288, 14336, 15360, 16384, 17408, 18432, 20480, 24576, 32768)], dt, args.iters)
+        blas_reference([(16384, n, 320) for n in (1280, 2304, 2432, 2560, 2688, 2816, 5120)], dt, args.iters)
     if 'ff' in only:
         ff_reference([(12288, 320), (3072, 640), (768, 1280), (192, 1280), (16384, 320), (4096, 640), (1024, 1280), (256, 1280)],
                      dt, args.iters)
