@@ -380,6 +380,11 @@ int64_t mos_groupnorm_nhwc_workspace_bytes(int B, int C, int HW, int G);
 int mos_groupnorm_silu_fwd_nhwc(const void* x, const float* gamma, const float* beta, void* y, float* stats,
                                 void* ws, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
 int mos_groupnorm_nhwc_reads_twice(int B, int C, int HW, int G);
+/* (`silu` of the _pre form: bit 0 = SiLU; MOS_GN_PRE_TWO_LAUNCHES / MOS_GN_PRE_ONE_LAUNCH pin the form the library otherwise picks
+ * from the cost of re-adding the producer's tile sums in every workgroup -- one launch on the UNet's maps, a small finalize launch
+ * + the streaming launch on the VAE's, whose 512 x 512 images carry 1024 tiles: parity tests and tools.) */
+#define MOS_GN_PRE_TWO_LAUNCHES 4
+#define MOS_GN_PRE_ONE_LAUNCH 8
 int mos_groupnorm_silu_fwd_nhwc_pre(const void* x, const float* chan_part, int tiles_per_image, const float* gamma,
                                     const float* beta, void* y, float* stats, void* ws, int B, int C, int HW, int G, float eps,
                                     int silu, int dtype, void* stream);

@@ -11,6 +11,10 @@
 #include <cstdlib>
 #include "mos_common.h"
 
+#ifndef MOS_GN_PRE_MAX_STEPS
+#define MOS_GN_PRE_MAX_STEPS 32   // prologue steps per wave up to which GroupNorm-from-producer-statistics is ONE launch (see gn_nhwc_run_pre)
+#endif
+
 namespace {
 
 constexpr int GN_SLICE = 16384;   // elements per workgroup slice (256 threads x 8 elements x 8 iterations)
@@ -553,21 +557,37 @@ int gn_nhwc_run(GnNhwcArgs a, int silu, hipStream_t st) {
 }
 
 // Round 6: statistics that arrive WITH the map -- the producing convolution's epilogue left, per (pixel tile, channel), the sum and
-// the sum of squares of the stored values (conv3x3_halo_kernel, mos_conv.hip). One 64-thread block per (image, group) adds its
+// the sum of squares of the stored values (conv3x3_halo_kernel, mos_conv.hip). One 256-thread block per (image, group) adds its
 // cpg channels over all tiles in a fixed order, in double, and writes the per-group constants where gn_nhwc_apply_kernel reads them
 // (and `stats` for the backward): the statistics pass over the activation and its finalize launch are replaced by this one.
-__global__ __launch_bounds__(64) void gn_chan_finalize_kernel(GnNhwcArgs a, const float* __restrict__ chan_part, int tiles) {
-    const int b = blockIdx.x / a.G, g = blockIdx.x - b * a.G, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void gn_chan_finalize_kernel(GnNhwcArgs a, const float* __restrict__ chan_part, int tiles) {
+    __shared__ double red[4][2];
+    const int b = blockIdx.x / a.G, g = blockIdx.x - b * a.G, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = tiles * a.cpg;
     double t0 = 0.0, t1 = 0.0;
-    for (int i = lane; i < n; i += 64) {
+    int i = tid;
+    for (; i + 768 < n; i += 1024) {            // four independent loads in flight per thread (the VAE's maps: n = 4096 .. 12288)
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = i + 256 * u, tile = e / a.cpg, c = g * a.cpg + (e - tile * a.cpg);
+            v[u] = *reinterpret_cast<const float2*>(chan_part + (((int64_t)b * tiles + tile) * a.C + c) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { t0 += (double)v[u].x; t1 += (double)v[u].y; }
+    }
+    for (; i < n; i += 256) {
         const int tile = i / a.cpg, c = g * a.cpg + (i - tile * a.cpg);
         const float2 v = *reinterpret_cast<const float2*>(chan_part + (((int64_t)b * tiles + tile) * a.C + c) * 2);
         t0 += (double)v.x; t1 += (double)v.y;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { t0 += __shfl_xor(t0, o); t1 += __shfl_xor(t1, o); }
-    if (lane == 0) {
+    if (lane == 0) { red[wave][0] = t0; red[wave][1] = t1; }
+    __syncthreads();
+    if (tid == 0) {
+        t0 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        t1 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
         const double cnt = (double)a.cpg * a.HW;
         const double m = t0 / cnt;
         double var = t1 / cnt - m * m;
@@ -588,6 +608,7 @@ __global__ __launch_bounds__(64) void gn_chan_finalize_kernel(GnNhwcArgs a, cons
 constexpr int GN_PRE_MAXG = 16;
 struct GnPreArgs {
     const void* x; void* out; const float* gamma; const float* beta; float* stats; const float* chan_part;
+    const float* fin;               // NULL, or [B][G][2] mean / rstd already combined by gn_chan_finalize_kernel: no prologue
     int B, C, HW, G, cpg, tiles;
     int cw, ngw, NV, RP, ppb;       // channels / groups / 16-byte vectors per workgroup range, pixels in flight, pixels per slice
     float eps;
@@ -600,6 +621,12 @@ __global__ __launch_bounds__(256) void gn_pre_apply_kernel(GnPreArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int unit = blockIdx.x, sp = blockIdx.y, b = blockIdx.z;
     const int c_lo = unit * a.cw, g_lo = c_lo / a.cpg;
+    if (a.fin != nullptr) {                             // two-launch form: the constants are there, the workgroup only streams
+        if (tid < a.ngw) {
+            mean_s[tid] = a.fin[((int64_t)b * a.G + g_lo + tid) * 2];
+            rstd_s[tid] = a.fin[((int64_t)b * a.G + g_lo + tid) * 2 + 1];
+        }
+    } else
     for (int gi = wave; gi < a.ngw; gi += 4) {          // one wave per group of the range
         const int n = a.tiles * a.cpg;
         double t0 = 0.0, t1 = 0.0;
@@ -677,28 +704,55 @@ bool gn_pre_plan(const GnNhwcArgs& a, GnPreArgs& q, const float* chan_part, int 
     return true;
 }
 
+// The one-launch form's prologue is repeated by EVERY workgroup of a channel range: tiles x cpg partial pairs per group, a wave per
+// group, 64 pairs per step. On the UNet's maps that is 2 .. 16 steps per wave; on the VAE's (1024 tiles of 16 x 16 pixels per 512 x
+// 512 image) it was 256 steps -- as many bytes out of L2 as the map itself, and the launch ran at 2.3 TB/s. There the per-group
+// constants come from one small launch (gn_chan_finalize_kernel) and the SAME full-width grid only streams (fin != NULL). Measured
+// (profiles/r06c20_groupnorm_pre_forms.txt, us one / two launches): B4 C128 512x512 248 / 117 (4.4 TB/s), B1 C128 512x768 177 / 40,
+// B1 C256 512x768 273 / 100, B4 C256 256x256 78 / 58, B4 C256 128x128 (16 steps) 22.5 / 18.7; the other way round on maps that sit
+// on the launch floor: B4 C320 64x64 (10 steps) 14.9 / 16.7, B2 C320 64x96 (16 steps, 3.9 M elements) 15.2 / 16.6.
+constexpr int GN_PRE_SMALL_STEPS = 12;              // up to here: one launch
+constexpr double GN_PRE_BIG_MAP = 8.0e6;            // elements; from GN_PRE_SMALL_STEPS + 1 steps on, maps this big take two launches
+constexpr int GN_PRE_MAX_PROLOGUE_STEPS = MOS_GN_PRE_MAX_STEPS;
+
 template <typename T>
-int gn_nhwc_run_pre(GnNhwcArgs a, const float* chan_part, int tiles, int silu, hipStream_t st) {
+int gn_nhwc_run_pre(GnNhwcArgs a, const float* chan_part, int tiles, int flags, hipStream_t st) {
+    const int silu = flags & 1;
     const int vt = (a.V + 255) / 256;
     const dim3 grid(a.B, a.nsplit), block(a.TP * a.R);
     char key[96];
     snprintf(key, sizeof(key), "nhwc B%d C%d HW%d%s", a.B, a.C, a.HW, silu ? " +silu" : "");
     const double n = (double)a.B * a.C * a.HW;
     GnPreArgs q = {};
-    if (gn_pre_plan(a, q, chan_part, tiles)) {          // one launch: statistics of the range in the prologue, then the slice
-        const int nsp = (a.HW + q.ppb - 1) / q.ppb;
+    const bool planned = gn_pre_plan(a, q, chan_part, tiles);
+    bool one = planned;
+    if (one) {
+        const int steps = ((tiles * a.cpg + 63) / 64) * ((q.ngw + 3) / 4);
+        if (flags & 4) one = false;                      // (tests / tools: the two-launch form)
+        else if (!(flags & 8))                           // (8: the one-launch form whatever the prologue costs)
+            one = steps <= GN_PRE_SMALL_STEPS || (steps <= GN_PRE_MAX_PROLOGUE_STEPS && n < GN_PRE_BIG_MAP);
+    }
+    const int nsp = planned ? (a.HW + q.ppb - 1) / q.ppb : 0;
+    const dim3 g3(planned ? (unsigned)(a.C / q.cw) : 1u, (unsigned)nsp, (unsigned)a.B);
+    if (one) {                                           // one launch: statistics of the range in the prologue, then the slice
         MosProfScope prof(st, "groupnorm_pre", key, 8.0 * n, 4.0 * n);
-        const dim3 g3((unsigned)(a.C / q.cw), (unsigned)nsp, (unsigned)a.B);
         if (silu) hipLaunchKernelGGL((gn_pre_apply_kernel<T, true>), g3, dim3(256), 0, st, q);
         else hipLaunchKernelGGL((gn_pre_apply_kernel<T, false>), g3, dim3(256), 0, st, q);
         return mos_check_launch("gn_pre_apply");
     }
     {
         MosProfScope prof(st, "groupnorm_finalize_pre", key, 2.0 * a.B * tiles * a.C, 8.0 * a.B * tiles * a.C);
-        hipLaunchKernelGGL(gn_chan_finalize_kernel, dim3(a.B * a.G), dim3(64), 0, st, a, chan_part, tiles);
+        hipLaunchKernelGGL(gn_chan_finalize_kernel, dim3(a.B * a.G), dim3(256), 0, st, a, chan_part, tiles);
     }
     int rc = mos_check_launch("gn_chan_finalize");
     if (rc) return rc;
+    if (planned) {                                       // ... then the same full-width streaming grid, its prologue skipped
+        q.fin = a.partial + (int64_t)a.B * a.nsplit * a.G * 2;
+        MosProfScope prof(st, "groupnorm_pre_stream", key, 8.0 * n, 4.0 * n);
+        if (silu) hipLaunchKernelGGL((gn_pre_apply_kernel<T, true>), g3, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((gn_pre_apply_kernel<T, false>), g3, dim3(256), 0, st, q);
+        return mos_check_launch("gn_pre_apply");
+    }
     MosProfScope prof(st, "groupnorm_apply", key, 8.0 * n, 4.0 * n);
 #define GN_APPLY(VTN, S) hipLaunchKernelGGL((gn_nhwc_apply_kernel<T, VTN, false, S, false>), grid, block, 0, st, a)
     if (vt == 1) { if (silu) GN_APPLY(1, true); else GN_APPLY(1, false); }
@@ -1052,8 +1106,8 @@ int mos_groupnorm_silu_fwd_nhwc_pre(const void* x, const float* chan_part, int t
     int rc = gn_nhwc_check(x, y, gamma, beta, ws, a, "mos_groupnorm_silu_fwd_nhwc_pre");
     if (rc) return rc;
     MOS_REQUIRE(chan_part && tiles_per_image > 0, "mos_groupnorm_silu_fwd_nhwc_pre: no channel statistics");
-    if (dtype == MOS_F16) return gn_nhwc_run_pre<f16_t>(a, chan_part, tiles_per_image, silu & 1, (hipStream_t)stream);
-    if (dtype == MOS_BF16) return gn_nhwc_run_pre<bf16_t>(a, chan_part, tiles_per_image, silu & 1, (hipStream_t)stream);
+    if (dtype == MOS_F16) return gn_nhwc_run_pre<f16_t>(a, chan_part, tiles_per_image, silu, (hipStream_t)stream);
+    if (dtype == MOS_BF16) return gn_nhwc_run_pre<bf16_t>(a, chan_part, tiles_per_image, silu, (hipStream_t)stream);
     return mos_set_error(MOS_ERR_UNSUPPORTED, "mos_groupnorm_silu_fwd_nhwc_pre: dtype %d", dtype);
 }
 

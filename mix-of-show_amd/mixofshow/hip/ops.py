@@ -541,12 +541,14 @@ def groupnorm_reads_twice(B, C, HW, groups):
     return bool(_lib.load().mos_groupnorm_nhwc_reads_twice(int(B), int(C), int(HW), int(groups)))
 
 
-def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False, chan_part=None):
+def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False, chan_part=None, pre_form=0):
     """x (B, C, *spatial) half, contiguous (NCHW) or channels_last (NHWC); gamma/beta fp32.
     Returns (y like x, same memory format; stats (B*G, 2) fp32). force_slices (channels_last): the three-launch slice kernels
     also where the one-launch column kernel applies (MOS_GN_FORCE_SLICES; parity tests, A/B). chan_part (channels_last):
     (B, tiles, C, 2) fp32 per-(pixel tile, channel) sum / sum of squares of x as its producer left them -- the statistics pass
-    over x is skipped (mos_groupnorm_silu_fwd_nhwc_pre)."""
+    over x is skipped (mos_groupnorm_silu_fwd_nhwc_pre; pre_form 4 / 8 = MOS_GN_PRE_TWO_LAUNCHES / MOS_GN_PRE_ONE_LAUNCH pin the
+    form the library otherwise picks: tests, tools)."""
+    assert pre_form in (0, 4, 8)
     _dev(x, gamma, beta, chan_part)
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
@@ -558,8 +560,8 @@ def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False, ch
             and chan_part.shape[0] == B and chan_part.shape[2] == C and chan_part.shape[3] == 2
         ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)
         _lib.check(L.mos_groupnorm_silu_fwd_nhwc_pre(_p(x), _p(chan_part), int(chan_part.shape[1]), _p(gamma), _p(beta), _p(y),
-                                                     _p(stats), _p(ws), B, C, HW, groups, float(eps), int(bool(silu)), _dt(x),
-                                                     _stream()), 'mos_groupnorm_silu_fwd_nhwc_pre')
+                                                     _p(stats), _p(ws), B, C, HW, groups, float(eps), int(bool(silu)) | pre_form,
+                                                     _dt(x), _stream()), 'mos_groupnorm_silu_fwd_nhwc_pre')
         return y, stats
     if _is_nhwc(x):
         ws = torch.empty((L.mos_groupnorm_nhwc_workspace_bytes(B, C, HW, groups) + 3) // 4, dtype=torch.float32, device=x.device)

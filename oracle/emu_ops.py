@@ -221,7 +221,7 @@ def groupnorm_reads_twice(B, C, HW, groups):
     return HW >= 2048
 
 
-def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False, chan_part=None):
+def groupnorm_silu_fwd(x, gamma, beta, groups, eps, silu, force_slices=False, chan_part=None, pre_form=0):
     import torch.nn.functional as F
     cd = torch.float64 if x.dtype == torch.float64 else torch.float32
     xf = x.to(cd)

@@ -989,6 +989,7 @@ def test_softmax_rows_and_vae_single_head_attention(ops, emu, dtype):
     (4, 1280, 640, 32, 32, 't'),      # level 1, training batch, Cin != Cout
     (1, 256, 256, 128, 120, 'r'),     # VAE stage, cpg 8
     (2, 1920, 960, 32, 48, ''),       # cpg 30: a 120-channel range per workgroup
+    (1, 128, 128, 512, 496, 'r'),     # VAE 512-px stage: 992 tiles per image -> the two-launch form of the consuming norm
 ])
 def test_conv3x3_leaves_groupnorm_statistics(ops, emu, dtype, B, Cin, Cout, H, W, extras):
     """Round 6: mos_conv3x3_nhwc_gn -- the same convolution, bit for bit, plus per-(tile, channel) sum and sum
@@ -1023,6 +1024,14 @@ def test_conv3x3_leaves_groupnorm_statistics(ops, emu, dtype, B, Cin, Cout, H, W
         _check(f'groupnorm from the convolution statistics vs emulation (silu={silu})', z_pre, z_emu, dtype, ulps=2.0)
         _check('groupnorm from the convolution statistics vs the re-reading form', z_pre, z_ref, dtype, ulps=1.0)
         assert (st_pre - st_emu).abs().max().item() <= 2e-5 * max(1.0, st_emu.abs().max().item())
+        # the two forms of the _pre entry (one launch: every workgroup re-adds its groups' tile sums; two launches: a finalize
+        # launch + the streaming launch -- the library picks by the prologue's cost, 512 x 512 VAE maps take the second): the same
+        # sums in the same order up to the last double addition, then the same arithmetic
+        z1, s1 = ops.groupnorm_silu_fwd(y, gamma, beta, 32, eps, silu, chan_part=part, pre_form=8)
+        z2, s2 = ops.groupnorm_silu_fwd(y, gamma, beta, 32, eps, silu, chan_part=part, pre_form=4)
+        assert (s1 - s2).abs().max().item() <= 1e-6 * max(1.0, s1.abs().max().item())
+        _check('groupnorm _pre: one launch vs two launches', z1, z2, dtype, ulps=1.0)
+        assert torch.equal(z_pre, z1) or torch.equal(z_pre, z2)
         dy = torch.randn_like(y)
         _check('groupnorm backward from those stats', ops.groupnorm_silu_bwd(dy, y, gamma, beta, st_pre, 32, silu),
                ops.groupnorm_silu_bwd(dy, y, gamma, beta, st_ref, 32, silu), dtype, ulps=2.0)

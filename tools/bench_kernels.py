@@ -208,6 +208,27 @@ def gn_reference(shapes, dtype, iters):
         print(f"{f'B{B} C{C} {H}x{W}':24s} " + ' '.join(f'{v:9.1f}' for v in row) + f' {x.numel() * 2 / 1e6:7.2f}')
 
 
+def gn_pre_reference(shapes, dtype, iters):
+    """GroupNorm(+SiLU) from the producing convolution's tile statistics: the ONE-launch form (every workgroup re-adds its groups'
+    tile sums), the TWO-launch form (finalize + streaming apply), the library's choice, and the norm without producer statistics
+    (it reads the map twice) -- us per call and the effective GB/s (one read + one write of the map) of the library's choice."""
+    print(f"{'GroupNorm B C HxW':26s} {'tiles':>6s} {'one':>8s} {'two':>8s} {'auto':>8s} {'no stats':>9s} {'auto GB/s':>10s}")
+    for B, C, H, W in shapes:
+        x = torch.randn(B, C, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(C, 3, 3, 64, device='cuda', dtype=dtype) * 0.05).contiguous()
+        xin = torch.randn(B, 64, H, W, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last)
+        y, part = ops.conv3x3_nhwc(xin, w, gn_stats=True)
+        if part is None:
+            print(f"{f'B{B} C{C} {H}x{W}':26s}   (this shape's convolution keeps no statistics)")
+            continue
+        gamma, beta = torch.ones(C, device='cuda'), torch.zeros(C, device='cuda')
+        t1 = _timed(lambda: ops.groupnorm_silu_fwd(y, gamma, beta, 32, 1e-5, True, chan_part=part, pre_form=8), iters)
+        t2 = _timed(lambda: ops.groupnorm_silu_fwd(y, gamma, beta, 32, 1e-5, True, chan_part=part, pre_form=4), iters)
+        ta = _timed(lambda: ops.groupnorm_silu_fwd(y, gamma, beta, 32, 1e-5, True, chan_part=part), iters)
+        t0 = _timed(lambda: ops.groupnorm_silu_fwd(y, gamma, beta, 32, 1e-5, True), iters)
+        print(f"{f'B{B} C{C} {H}x{W}':26s} {part.shape[1]:6d} {t1:8.1f} {t2:8.1f} {ta:8.1f} {t0:9.1f} {y.numel() * 4 / ta / 1e3:10.1f}")
+
+
 def region_case(fh, fw, d, dtype, iters):
     B, H = 2, 8
     C = H * d
@@ -235,7 +256,7 @@ def gram_case(n, cin, cout, dtype, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,ffgemm,ffsweep,gn,conv1,convvae,convvae1,convs2,probs")
+    ap.add_argument('--only', default='', help="'' = everything, or a comma-separated subset of attn,gemm,region,gram,conv,blas,ff,ffgemm,ffsweep,gn,gnpre,conv1,convvae,convvae1,convs2,probs")
     ap.add_argument('--dtype', default='f16')
     ap.add_argument('--legacy', type=int, default=0, help='gemm: also time the round-1 multi-launch LoRA path')
     ap.add_argument('--ref', type=int, default=1, help='0: skip the MIOpen / hipBLASLt reference timings')
@@ -308,6 +329,11 @@ def main():
     if 'ff' in only:
         ff_reference([(12288, 320), (3072, 640), (768, 1280), (192, 1280), (16384, 320), (4096, 640), (1024, 1280), (256, 1280)],
                      dt, args.iters)
+    if 'gnpre' in only:          # VAE encoder of a training batch, VAE decoder of a 512x768 sample, UNet levels of both
+        gn_pre_reference([(4, 128, 512, 512), (4, 128, 256, 256), (4, 256, 256, 256), (4, 256, 128, 128), (4, 512, 128, 128),
+                          (4, 512, 64, 64), (1, 128, 512, 768), (1, 256, 512, 768), (1, 256, 256, 384), (1, 512, 256, 384),
+                          (1, 512, 128, 192), (1, 512, 64, 96), (4, 320, 64, 64), (4, 640, 32, 32), (4, 1280, 16, 16),
+                          (2, 320, 64, 96), (2, 640, 32, 48), (2, 1280, 16, 24)], dt, args.iters)
     if 'gn' in only:
         gn_reference([(2, 320, 64, 96), (2, 640, 64, 96), (2, 960, 64, 96), (2, 640, 32, 48), (2, 1280, 32, 48), (2, 1920, 32, 48),
                       (2, 960, 32, 48), (2, 1280, 16, 24), (2, 2560, 16, 24), (2, 1920, 16, 24), (2, 1280, 8, 12),

@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--preset', default='sd15')
+    ap.add_argument('--top', type=int, default=0, help='also list the N largest (kernel, shape) records')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     trainer = bench.build_trainer(args.preset, dev)
@@ -43,6 +44,13 @@ def main():
     print(f'{"kernel family":34s} {"calls/step":>10s} {"ms/step":>9s} {"avg us":>8s}')
     for k, (c, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         print(f'{k:34s} {c / args.steps:10.1f} {ms / args.steps:9.3f} {ms * 1e3 / max(c, 1):8.1f}')
+    if args.top:
+        print()
+        for r in sorted(recs, key=lambda r: -r['total_ms'])[:args.top]:
+            gb = r['bytes'] / max(r['avg_us'], 1e-9) / 1e3
+            tf = r['flops'] / max(r['avg_us'], 1e-9) / 1e6
+            print(f"{r['name'][:78]:78s} {r['calls'] / args.steps:6.1f} {r['avg_us']:8.1f} us {r['total_ms'] / args.steps:7.3f} ms {tf:7.1f} TF/s {gb:7.0f} GB/s")
+        print()
     print(f'{"all":34s} {sum(c for c, _ in fam.values()) / args.steps:10.1f} {sum(m for _, m in fam.values()) / args.steps:9.3f}')
 
 
