@@ -84,7 +84,8 @@ struct AttnArgs {
 
 struct AttnBwdArgs {
     const void* q; const void* k; const void* v; const void* dO;
-    const float* lse; const float* Dvec; const int32_t* tok_idx; const float* dpcols; int n_pcols;
+    const void* o; int64_t o_bs, o_rs; const float* pcols;     // dQ kernel only: it forms D = rowsum(dO o O) (+ sum_t dpcols pcols)
+    const float* lse; float* Dvec; const int32_t* tok_idx; const float* dpcols; int n_pcols;   // in its prologue and leaves it in Dvec
     void* dq; void* dk; void* dv; float* part;  // part: fp32 split partials [2][nsplit][B*H][Nkv][D]
     int B, H, Nq, Nkv, nqb, nkb, nsplit, q_per_split;
     int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, do_bs, do_rs, dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
@@ -907,34 +908,6 @@ __global__ __launch_bounds__(256, (D <= 40 ? 3 : 1)) void region_attn_kernel(Att
     store_out_rows<T, D>(op + (int64_t)qi * a.o_rs, qi < a.Nq, fin, 1.0f, hh);
 }
 
-// ---- backward: D = rowsum(dO * O) + sum_t dpcols * pcols -------------------------------------------
-template <typename T, int D>
-__global__ void attn_bwd_prep_kernel(const T* __restrict__ o, int64_t o_bs, int64_t o_rs, const T* __restrict__ dO,
-                                     int64_t do_bs, int64_t do_rs, const float* __restrict__ pcols,
-                                     const float* __restrict__ dpcols, int n_pcols, float* __restrict__ Dvec, int B,
-                                     int H, int Nq) {
-    typedef typename MT<T>::v8 v8;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, q, h), h fastest
-    if (idx >= (int64_t)B * Nq * H) return;
-    const int h = idx % H;
-    const int64_t bq = idx / H;
-    const int q = bq % Nq;
-    const int b = bq / Nq;
-    const T* op = o + (int64_t)b * o_bs + (int64_t)q * o_rs + h * D;
-    const T* dp = dO + (int64_t)b * do_bs + (int64_t)q * do_rs + h * D;
-    float s = 0.f;
-#pragma unroll
-    for (int cc = 0; cc < D / 8; ++cc) {
-        const v8 x = as_v8<T>(ld16(op + cc * 8)), y = as_v8<T>(ld16(dp + cc * 8));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += (float)x[e] * (float)y[e];
-    }
-    const int64_t row = ((int64_t)b * H + h) * Nq + q;
-    if (pcols != nullptr && dpcols != nullptr)
-        for (int t = 0; t < n_pcols; ++t) s += pcols[row * n_pcols + t] * dpcols[row * n_pcols + t];
-    Dvec[row] = s;
-}
-
 // ---- backward dQ: one wave = 32 queries, loop over key tiles -----------------------------------------
 //   S^T = K Q^T ; P^T = exp(scale*S^T - lse) ; dP^T = V dO^T ; dS^T = P^T o (dP^T - D) ; dQ^T += K^T dS^T
 // NW waves per block share each staged K / V / K^T tile. NW = 8 (512 threads, two blocks per CU = 4 waves per
@@ -974,18 +947,32 @@ __global__ __launch_bounds__(64 * NW, (D <= 40 ? MOS_DQ_OCC : (D <= 80 && !PCOLS
     load_row_frags<T, D>(dof, (const T*)a.dO + (int64_t)b * a.do_bs + (int64_t)qc * a.do_rs + h * D, qvalid, hh);
     const int64_t row = ((int64_t)b * a.H + h) * a.Nq + qc;
     const float lse2 = a.lse[row] * LOG2E;
-    const float Dq = a.Dvec[row];
     const float c = a.scale * LOG2E;
     int tok[MOS_MAX_PCOLS] = {-1, -1, -1, -1};
     float dpc[MOS_MAX_PCOLS] = {0.f, 0.f, 0.f, 0.f};
+    // D = rowsum(dO o O) + sum_t dpcols pcols of this lane's query, formed HERE (round 6: it was a launch of its own -- 44 per SD-1.5
+    // training step) from the dO row the lane holds anyway and the O row beside it; the two half-waves of a query hold alternate
+    // 8-element chunks of the row. Left in Dvec for the dK/dV kernel, which runs after this one on the same stream.
+    float Dq = 0.f;
+    {
+        v8 of[KS];
+        load_row_frags<T, D>(of, (const T*)a.o + (int64_t)b * a.o_bs + (int64_t)qc * a.o_rs + h * D, qvalid, hh);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Dq += (float)of[ks][e] * (float)dof[ks][e];
+        Dq += __shfl_xor(Dq, 32);
+    }
     if constexpr (PCOLS) {
 #pragma unroll
         for (int tt = 0; tt < MOS_MAX_PCOLS; ++tt)
             if (tt < a.n_pcols) {
                 tok[tt] = a.tok_idx[b * a.n_pcols + tt];
                 dpc[tt] = a.dpcols[row * a.n_pcols + tt];
+                Dq += a.pcols[row * a.n_pcols + tt] * dpc[tt];
             }
     }
+    if (qvalid && hh == 0) a.Dvec[row] = Dq;
     f32x16 dq[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -1748,19 +1735,10 @@ int launch_bwd(const void* q, const void* k, const void* v, const void* o, const
     float* Dvec = (float*)ws;
     const int64_t nrows = (int64_t)s->B * s->H * s->Nq;
     float* part = Dvec + ((nrows + 3) / 4) * 4;
-    {
-        const int64_t tot = nrows;
-        AttnKey key(tname<T>(), s, 0.0);
-        MosProfScope prof(st, "attn_bwd_prep", key.s, 2.0 * nrows * D, 4.0 * nrows * D);
-        hipLaunchKernelGGL((attn_bwd_prep_kernel<T, D>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st,
-                           (const T*)o, s->o_bs, s->o_rs, (const T*)dO, g->do_bs, g->do_rs, pcols, dpcols, np, Dvec,
-                           s->B, s->H, s->Nq);
-        int rc = mos_check_launch("attn_bwd_prep");
-        if (rc) return rc;
-    }
     AttnBwdArgs a;
     a.q = q; a.k = k; a.v = v; a.dO = dO; a.lse = lse; a.Dvec = Dvec; a.tok_idx = tok; a.dpcols = dpcols;
-    a.n_pcols = (dpcols != nullptr) ? np : 0;
+    a.o = o; a.o_bs = s->o_bs; a.o_rs = s->o_rs; a.pcols = pcols;
+    a.n_pcols = (dpcols != nullptr && pcols != nullptr) ? np : 0;
     a.dq = dq; a.dk = dk; a.dv = dv; a.part = part;
     a.B = s->B; a.H = s->H; a.Nq = s->Nq; a.Nkv = s->Nkv; a.nqb = p.nqb; a.nkb = p.nkb;
     a.nsplit = p.nsplit; a.q_per_split = p.q_per_split;

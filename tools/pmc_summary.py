@@ -8,7 +8,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r'(attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkdv_kernel|attn_bwd_dkdv_pipe_kernel|attn_bwd_prep_kernel|region_attn_kernel|'
+    m = re.search(r'(attn_fwd_kernel|attn_bwd_dq_kernel|attn_bwd_dkdv_kernel|attn_bwd_dkdv_pipe_kernel|region_attn_kernel|'
                   r'conv3x3_halo_kernel|attn_probs_kernel|attn_pv_kernel|gn_col_kernel|'
                   r'gemm_lora_kernel|conv3x3_nhwc_kernel|gn_nhwc_reduce_kernel|gn_nhwc_apply_kernel|lora_grad_kernel|'
                   r'gram_kernel|lsq_grad_mfma_kernel)', name)
