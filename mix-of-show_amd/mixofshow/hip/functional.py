@@ -285,9 +285,10 @@ class _PackGroup:
 
 class LoraPackRegistry:
     """fp32 master LoRA factors -> packed half MFMA operands (A16, A16T, Bp16, BpT; include/mos_hip.h). Groups register
-    on first use; whenever any group's parameters changed since the last pack (tensor version counters: optimiser step,
-    load_state_dict, manual edits) ALL groups are repacked by one `mos_lora_pack_all` launch — 1 launch per training step
-    instead of one per projection call. Inside a captured hipGraph the launch sits where the first projection asked
+    on first use; whenever any group's parameters changed since the last pack (tensor version counters: load_state_dict,
+    manual edits, foreach optimisers) or a backward pass formed gradients of LoRA factors (an optimiser step follows, and
+    torch's FUSED AdamW updates parameters without touching their version counters: round 6) ALL groups are repacked by one
+    `mos_lora_pack_all` launch — 1 launch per training step instead of one per projection call. Inside a captured hipGraph the launch sits where the first projection asked
     for its operands (`invalidate()` before capture guarantees it is there).
 
     The descriptor table lives in ONE device buffer of fixed capacity that is only ever updated IN PLACE (a captured graph
@@ -495,6 +496,12 @@ class _LoRALinear(torch.autograd.Function):
         else:
             targets = None
             if any(ctx.needs_input_grad[6:]):
+                # gradients of the LoRA factors are being formed: an optimiser is about to change the masters, and not every
+                # optimiser tells (torch.optim.AdamW(fused=True) leaves `_version` alone) -- the packed operands are repacked at
+                # their next use (one launch for all groups). Python-side counter only: nothing is launched here.
+                reg = _registries.get((dy2.device.type, dy2.device.index, x2.dtype))
+                if reg is not None:
+                    reg.invalidate()
                 targets = []
                 for g in range(ctx.n_sites):
                     pair, accs = [], []

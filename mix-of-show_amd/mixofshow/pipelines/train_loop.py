@@ -223,6 +223,11 @@ class TrainEngine:
             g['lr'] = base * self.lr_factor(self.global_step)
         self.scaler.step(self.optimizer)
         self.scaler.update()
+        if tr.concept_embedding.is_cuda:
+            # torch's fused AdamW writes the fp32 masters without bumping their version counters: tell the operand cache
+            # (an eager step would otherwise run on the factors of the step before; replays repack inside the graph)
+            from mixofshow.hip import functional as F_hip
+            F_hip.invalidate_lora_packs()
         with torch.no_grad():
             rows = tr.concept_embedding
             # freeze rule: rows stay at their snapshot once stop_flag is set (reference :123-126,135-136)

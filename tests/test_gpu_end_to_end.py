@@ -733,6 +733,63 @@ def test_training_steps_match_reference_path_and_engine_runs():
     assert engine.global_step == 3 and not bool(engine.stop_flag)   # synthetic CLIP rows have real-CLIP-like norms
 
 
+def test_eager_steps_run_on_the_updated_lora_factors():
+    """torch.optim.AdamW(fused=True) -- the engine's optimiser on the device -- updates the fp32 LoRA masters WITHOUT bumping their
+    tensor version counters, which is what the packed-operand cache (functional.LoraPackRegistry) watched: found in round 6, an
+    eager step (train.hipgraph false, gradient accumulation, a batch of another shape) ran its forward on the factors of the step
+    before. Now a backward that forms LoRA gradients and the engine's optimiser step both invalidate the cache. Check: after two
+    eager steps at a learning rate that matters, the loss of the state the engine left behind equals, bit for bit, the loss after
+    an explicit invalidation; and a foreign loop (plain torch fused AdamW, no engine) sees its own update in the next forward."""
+    from bench import TRAIN_OPT, build_trainer, synthetic_batch
+    from mixofshow.hip import functional as F_hip
+    from mixofshow.pipelines.train_loop import TrainEngine
+    tr = build_trainer('small', torch.device(DEV))
+    torch.manual_seed(2)
+    with torch.no_grad():
+        for l in list(tr.text_encoder_lora) + list(tr.unet_lora):
+            l.lora_up.weight.normal_(0, 0.05)
+    opt = dict(TRAIN_OPT, optim_g=dict(TRAIN_OPT['optim_g']))
+    engine = TrainEngine(tr, opt, total_iter=100, mixed_precision='bf16')
+    for grp in engine.optimizer.param_groups:
+        grp['lr'] = 3e-2
+    engine.base_lrs = [3e-2 for _ in engine.base_lrs]
+    g = torch.Generator().manual_seed(4)
+    B = 2
+    b = synthetic_batch(B, 256, 'cpu', 60)
+    extra = dict(latents=torch.randn(B, 4, 32, 32, generator=g), noise=torch.randn(B, 4, 32, 32, generator=g),
+                 timesteps=torch.randint(0, 1000, (B, ), generator=g))
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in {**b, **extra}.items()}
+    batch['images'] = None
+
+    def loss_now():
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            return tr(None, batch['prompts'], batch['masks'], batch['img_masks'], latents=batch['latents'], noise=batch['noise'],
+                      timesteps=batch['timesteps']).float().item()
+
+    l0 = loss_now()
+    for _ in range(2):
+        engine.step(batch)
+    l_engine = loss_now()                    # whatever operands the cache holds after the engine's steps
+    F_hip.invalidate_lora_packs()
+    l_fresh = loss_now()
+    print(f'[parity] eager steps and the LoRA operand cache: loss before {l0:.6f}, after two steps {l_engine:.6f}, after an explicit repack {l_fresh:.6f}')
+    assert l_engine == l_fresh and abs(l_engine - l0) > 1e-4 * abs(l0)
+    # a foreign training loop: backward through the fused layers + torch's fused AdamW, no engine
+    params = [p for l in tr.unet_lora for p in (l.lora_down.weight, l.lora_up.weight)]
+    foreign = torch.optim.AdamW(params, lr=3e-2, fused=True)
+    foreign.zero_grad(set_to_none=True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        loss = tr(None, batch['prompts'], batch['masks'], batch['img_masks'], latents=batch['latents'], noise=batch['noise'],
+                  timesteps=batch['timesteps'])
+    loss.backward()
+    v0 = params[0]._version
+    foreign.step()
+    assert params[0]._version == v0          # (the premise: this optimiser does not tell; if torch ever changes that, fine)
+    l_after = loss_now()
+    F_hip.invalidate_lora_packs()
+    assert l_after == loss_now() and l_after != l_fresh
+
+
 def test_sd15_fp16_train_step_through_vae_vs_cpu_twin():
     """BASELINE configs[1] itself: SD-1.5 architecture, 512x512, batch 4, fp16 autocast + GradScaler, images THROUGH the
     VAE (posterior-sample noise injected), attention regulariser on — one forward+backward against the oracle twin
