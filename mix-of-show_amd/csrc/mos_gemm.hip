@@ -34,8 +34,10 @@
 // workgroups the token reduction of ONE LoRA group aims at. 1024 while every group was its own launch (rounds 2-4); since the groups
 // of a backward pass share one launch per rank class (mos_lora_grad_all, ~15 k blocks) fewer, longer blocks per group win: fewer
 // partial sums to write and to sum, fewer re-reads of the 16-wide t / dt rows -- same box, per step: 0.81 ms at 1024, 0.61 at 512,
-// 0.51 at 256 (3.0 TB/s; profiles/r05c7_ab_same_box_lora_grad_tuning.txt)
-#define MOS_GRAD_TARGET_WG 256
+// 0.51 at 256 (3.0 TB/s; profiles/r05c7_ab_same_box_lora_grad_tuning.txt). Round 6, same box, the three launches of a step:
+// 0.598 ms at 512, 0.505 at 256, 0.456 at 128, 0.462 at 96, 0.450 at 64, 0.464 at 32 (the rank-12 class of the text encoder:
+// 311 -> 270 us; profiles/r06c26_lora_grad_block_target.txt)
+#define MOS_GRAD_TARGET_WG 128
 #endif
 #ifndef MOS_GEMM_DEEP_MAX_WG
 #define MOS_GEMM_DEEP_MAX_WG 96   // GEMMs with at most this many workgroups use the deep-stage variants (measured: a win only
