@@ -1,5 +1,6 @@
-"""Library launches of ONE eager ED-LoRA training step (configs[1]) by kernel family: calls, total and average time, from the
-library's own HIP-event profiler (mixofshow.hip.profiler). GPU only.   python tools/count_library_launches.py [--steps 2]"""
+"""Library launches of ONE eager ED-LoRA training step (configs[1]) -- or, --mode regional, of ONE eager 512x768 regional sample
+(configs[4]: adapter, 50 UNet steps, VAE decode) -- by kernel family: calls, total and average time, from the library's own
+HIP-event profiler (mixofshow.hip.profiler). GPU only.   python tools/count_library_launches.py [--steps 2] [--top 40]"""
 import argparse
 import collections
 import os
@@ -19,9 +20,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--preset', default='sd15')
+    ap.add_argument('--mode', default='train', choices=['train', 'regional'])
     ap.add_argument('--top', type=int, default=0, help='also list the N largest (kernel, shape) records')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
+    if args.mode == 'regional':
+        return regional(args, dev)
     trainer = bench.build_trainer(args.preset, dev)
     trainer.unet.train(), trainer.text_encoder.train()
     engine = TrainEngine(trainer, dict(bench.TRAIN_OPT, optim_g=dict(bench.TRAIN_OPT['optim_g'])), total_iter=1e9,
@@ -35,13 +39,44 @@ def main():
         for i in range(args.steps):
             engine.step(batches[i % 2])
         torch.cuda.synchronize()
+    report(recs, args.steps, args.top, 'step')
+
+
+def regional(args, dev):
+    H, W = 512, 768
+    pipe = bench.build_regional_pipe(args.preset, dev)
+    pipe.unet.to(memory_format=torch.channels_last)
+    pipe.vae.to(memory_format=torch.channels_last)
+    prompt, neg = bench.regional_prompt(H, W)
+    latents = torch.randn((1, 4, H // 8, W // 8), generator=torch.manual_seed(14))
+    pipe.keypose_adapter, pose, _ = bench.synthetic_keypose_adapter(pipe, H, W, dev, torch.float16)
+    b = bench.region_px(H, W)[0]
+
+    def sample():
+        return pipe(prompt=prompt, negative_prompt=[neg], height=H, width=W, num_inference_steps=50, guidance_scale=7.5,
+                    latents=latents.clone(), output_type='pil', hipgraph=False, keypose_adapter_input=pose,
+                    keypose_adaptor_weight=1.0, region_keypose_adaptor_weight=f'[{b[0]}, {b[1]}, {b[2]}, {b[3]}]-0.6').images
+    sample()
+    torch.cuda.synchronize()
+    recs = []
+    with profiler.profile(recs):
+        sample()
+        torch.cuda.synchronize()
+    report(recs, 1, args.top, 'sample')
+
+
+def report(recs, steps, top, unit):
+    class A:
+        pass
+    args = A()
+    args.steps, args.top = steps, top
     fam = collections.OrderedDict()
     for r in recs:
         k = r['name'].split(' ')[0]
         f = fam.setdefault(k, [0, 0.0])
         f[0] += r['calls']
         f[1] += r['total_ms']
-    print(f'{"kernel family":34s} {"calls/step":>10s} {"ms/step":>9s} {"avg us":>8s}')
+    print(f'{"kernel family":34s} {"calls/" + unit:>12s} {"ms/" + unit:>10s} {"avg us":>8s}')
     for k, (c, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
         print(f'{k:34s} {c / args.steps:10.1f} {ms / args.steps:9.3f} {ms * 1e3 / max(c, 1):8.1f}')
     if args.top:
