@@ -586,3 +586,66 @@ def test_conv3x3_backward_reads_a_concatenation_gradient_slice_in_place(gpu_bran
         assert c1 == [128, 64] and c0 == [64, 64]        # dX of conv2 reads the slice (pixel stride of the 128-channel tensor)
         assert t1 == [None, 128] and t0 == [None, 64]     # norm2: no bypass; norm1's tap: the residual's gradient, the same slice
         assert torch.equal(g1, g0)
+
+
+def test_lora_operand_cache_repacks_after_a_backward_and_after_silent_updates(gpu_branches, monkeypatch):
+    """functional.LoraPackRegistry (host logic; the pack launch replaced by a counter that really packs): one repack for any number
+    of groups when something changed; NONE while nothing did; a repack after an update the version counters do not show
+    (torch's fused AdamW writes parameters without bumping `_version`: emulated here with `.data` writes under no version bump)
+    once a backward pass has formed LoRA gradients -- round 6, the eager training steps ran on stale operands before."""
+    import mixofshow.hip.ops as ops
+    dev = torch.device('cpu')
+    reg = F_hip.LoraPackRegistry(dev, torch.float16)
+    monkeypatch.setitem(F_hip._registries, ('cpu', None, torch.float16), reg)
+    packs = []
+
+    def fake_pack_all(desc_dev, n_groups, max_elems, dtype):
+        packs.append(n_groups)
+        for g in reg.groups.values():                       # what the kernel does: masters -> packed half operands
+            downs, ups = g.params()
+            A16, A16T, Bp16, BpT = ops.lora_pack(downs, ups, g.alphas, g.K, dtype, dev)
+            for dst, src in zip(g.bufs, (A16, A16T, Bp16, BpT)):
+                dst.copy_(src)
+
+    monkeypatch.setattr(ops, 'lora_pack_all', fake_pack_all)
+    from mixofshow.hip import lib as _lib
+    monkeypatch.setattr(ops, 'lora_group_desc', lambda *a, **k: _lib.LoraGroup())      # (descriptors hold device pointers: unused here)
+    torch.manual_seed(0)
+    K, N, r = 64, 32, 4
+    d1, u1 = torch.randn(r, K).requires_grad_(True), torch.randn(N, r).requires_grad_(True)
+    d2, u2 = torch.randn(r, K).requires_grad_(True), torch.randn(N, r).requires_grad_(True)
+    if True:
+        reg.get((d1, ), (u1, ), (1.0, ), K)
+        reg.get((d2, ), (u2, ), (0.5, ), K)
+        n0 = len(packs)
+        for _ in range(3):                                  # steady state: nothing changed, nothing launched
+            reg.get((d1, ), (u1, ), (1.0, ), K)
+            reg.get((d2, ), (u2, ), (0.5, ), K)
+        assert len(packs) == n0
+        with torch.no_grad():
+            d1.mul_(2.0)                                    # a visible update (version counter): ONE repack for both groups
+        a1 = reg.get((d1, ), (u1, ), (1.0, ), K)[0].clone()
+        reg.get((d2, ), (u2, ), (0.5, ), K)
+        assert len(packs) == n0 + 1 and packs[-1] == 2
+        torch.testing.assert_close(a1[:r].float(), d1.detach().half().float())
+        # a silent update: .data writes leave `_version` alone, like torch.optim.AdamW(fused=True)
+        v = d1._version
+        d1.data.mul_(0.5)
+        assert d1._version == v
+        stale = reg.get((d1, ), (u1, ), (1.0, ), K)[0]
+        assert len(packs) == n0 + 1 and not torch.allclose(stale[:r].float(), d1.detach().half().float())     # the cache cannot see it ...
+        # ... but a backward pass through a fused LoRA layer announces that an optimiser step follows
+        x = torch.randn(8, K).half().requires_grad_(True)
+        W = torch.randn(N, K).half()
+        with torch.autocast('cpu', dtype=torch.float16):
+            y = F_hip.lora_linear(x, W, W.t().contiguous(), None, [(d2, u2, 0.5)])
+        e0 = reg.epoch
+        y.float().sum().backward()
+        assert reg.epoch > e0
+        fresh = reg.get((d1, ), (u1, ), (1.0, ), K)[0]
+        assert len(packs) == n0 + 2
+        torch.testing.assert_close(fresh[:r].float(), d1.detach().half().float())
+        # and the engine says so itself after its optimiser step
+        e1 = reg.epoch
+        F_hip.invalidate_lora_packs()
+        assert reg.epoch == e1 + 1
